@@ -1,0 +1,65 @@
+"""ctypes binding of libd3feat_amd.so (the C ABI declared in include/d3feat_amd.h).
+
+The library is the ONLY compute path: there is no CPU or PyTorch fallback.  If the shared object has not been
+built (python -c "import __graft_entry__ as g; g.build()"  or  make -C d3feat_amd/csrc) every op raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libd3feat_amd.so")
+
+D3F_OK = 0
+ERRORS = {-1: "HIP runtime / kernel launch failure", -2: "workspace too small", -3: "invalid argument"}
+ST_EMPTY_ELEMENT, ST_NEG_CELL, ST_KEY_RANGE, ST_HIT_OVERFLOW = 1, 2, 4, 8
+NEIGHBOR_CAP = 1024
+MAX_BATCH = 255
+
+_vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+
+# name -> (restype, argtypes): mirrors include/d3feat_amd.h one to one (checked by tests/test_cabi.py)
+SIGNATURES = {
+    "d3f_version": (_i, []),
+    "d3f_grid_subsample_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "d3f_batch_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
+    "d3f_batch_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_workspace_bytes": (_sz, [_i]),
+    "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _sz,
+                                  _vp]),
+    "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
+    "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp]),
+    "d3f_detect_head": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class D3FeatLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libd3feat_amd.so; raises D3FeatLibraryError when it is missing (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise D3FeatLibraryError(
+            "d3feat_amd: %s not found -- the HIP extension is the only compute path. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C d3feat_amd/csrc`." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != D3F_OK:
+        raise D3FeatLibraryError("d3feat_amd.%s failed: %s (code %d)" % (what, ERRORS.get(rc, "unknown"), rc))

@@ -1,0 +1,215 @@
+// fp32 GEMM on the gfx950 matrix cores with the D3Feat inference epilogue fused.
+//
+// Reference ops replaced: kernels/convolution_ops.py:90-99 (unary_convolution = tf.matmul), :243-253 (KPConv
+// kernel-weight contraction, sum over kernel points, neighbour-count normalisation), followed by
+// models/network_blocks.py:149-160 (batch_norm, inference) and :185-186 (leaky_relu) and the residual add of
+// the resnet blocks (:368, :612):
+//   C[m,n] = act( acc[m,n] * row_scale[m] * col_scale[n] + col_shift[n] + residual[m,n] ),  acc = A @ B
+//
+// v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, 64 cycles, exact fp32: bitwise an fmaf chain in k order) --
+// the 1e-4 parity bar is an fp32 bar, so the contraction stays in fp32 on the MFMA pipe (157 TF peak).
+// 256-thread workgroup = 4 wavefronts, each owning one 32x32 accumulator tile; workgroup tile 64x64 (2x2 waves)
+// or 128x32 (4x1, for Cout <= 32); BK = 32.  A and B tiles are staged through LDS (A rows padded to 33 floats:
+// the MFMA A fragment reads a column of the tile, 33 is odd so the 32 lanes hit 32 banks), next tile prefetched
+// into registers while the current one is multiplied.  Skinny problems (few output tiles, long K: the deep
+// KPConv layers) are split along K into slabs that a second kernel reduces in a fixed order (deterministic).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GM_BK 32
+#define GM_SA (GM_BK + 1)
+
+struct GemmEpi {
+    const float* row_scale;
+    const float* col_scale;
+    const float* col_shift;
+    const float* residual;
+    int ldr;
+    int leaky;
+    float alpha;
+};
+
+__device__ __forceinline__ float gemm_epilogue(float v, int m, int n, const GemmEpi& E) {
+    if (E.row_scale) v *= E.row_scale[m];
+    if (E.col_scale) v *= E.col_scale[n];
+    if (E.col_shift) v += E.col_shift[n];
+    if (E.residual) v += E.residual[(size_t)m * E.ldr + n];
+    if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+    return v;
+}
+
+template <int WM, int WN>  // waves along M / N; WM*WN == 4
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                int M, int N, int K, int vecA, int vecB, int tiles_per_split, float* __restrict__ slab, GemmEpi E) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int A_F4 = BM * GM_BK / 4 / 256;  // float4 loads per thread for the A tile
+    constexpr int B_F4 = GM_BK * BN / 4 / 256;  // ... for the B tile (>= 1)
+    static_assert(B_F4 >= 1, "tile too small");
+    __shared__ float As[BM * GM_SA];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // x walks M: neighbouring blocks share the B panel in L2
+    const int nt_all = (K + GM_BK - 1) / GM_BK;
+    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_end = min(nt_all, t_begin + tiles_per_split);
+
+    float4 ra[A_F4], rb[B_F4];
+
+    auto load_tile = [&](int t) {
+        const int k0 = t * GM_BK;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int e = tid + i * 256;          // float4 slot: row = e / 8, k4 = e % 8
+            const int r = e >> 3, k = k0 + ((e & 7) << 2);
+            const int gm = m0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < M) {
+                const float* p = A + (size_t)gm * lda + k;
+                if (vecA && k + 3 < K) v = *(const float4*)p;
+                else {
+                    if (k < K) v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                    if (k + 3 < K) v.w = p[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int e = tid + i * 256;          // row = e / (BN/4), n4 = e % (BN/4)
+            const int r = e / (BN / 4), n = n0 + ((e % (BN / 4)) << 2);
+            const int gk = k0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K) {
+                const float* p = B + (size_t)gk * ldb + n;
+                if (vecB && n + 3 < N) v = *(const float4*)p;
+                else {
+                    if (n < N) v.x = p[0];
+                    if (n + 1 < N) v.y = p[1];
+                    if (n + 2 < N) v.z = p[2];
+                    if (n + 3 < N) v.w = p[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int e = tid + i * 256;
+            const int r = e >> 3, k = (e & 7) << 2;
+            float* d = &As[r * GM_SA + k];
+            d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int e = tid + i * 256;
+            const int r = e / (BN / 4), n = (e % (BN / 4)) << 2;
+            *(float4*)&Bs[r * BN + n] = rb[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile();
+    }
+    __syncthreads();
+    const int arow = (wm * 32 + (lane & 31)) * GM_SA + (lane >> 5);
+    const int bcol = (lane >> 5) * BN + wn * 32 + (lane & 31);
+    for (int t = t_begin; t < t_end; ++t) {
+        if (t + 1 < t_end) load_tile(t + 1);
+#pragma unroll
+        for (int kk = 0; kk < GM_BK / 2; ++kk) {
+            const float a = As[arow + kk * 2];
+            const float b = Bs[bcol + kk * 2 * BN];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (t + 1 < t_end) store_tile();
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int gn = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < M && gn < N) {
+            if (slab) slab[((size_t)blockIdx.z * M + gm) * N + gn] = acc[r];
+            else C[(size_t)gm * ldc + gn] = gemm_epilogue(acc[r], gm, gn, E);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += slab[((size_t)s * M + m) * N + n];
+    C[(size_t)m * ldc + n] = gemm_epilogue(v, m, n, E);
+}
+
+static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
+    if (N <= 32) { bm = 128; bn = 32; } else { bm = 64; bn = 64; }
+    const long long blocks = (long long)d3f_cdiv(M, bm) * d3f_cdiv(N, bn);
+    const int nt = d3f_cdiv(K, GM_BK);
+    S = 1;
+    if (blocks < 192 && nt >= 16) {
+        long long want = (512 + blocks - 1) / blocks;
+        long long maxs = nt / 8;  // >= 8 k-tiles (256 k) per split
+        S = (int)(want < maxs ? want : maxs);
+        if (S > 32) S = 32;
+        if (S < 1) S = 1;
+    }
+    tps = d3f_cdiv(nt, S);
+    S = d3f_cdiv(nt, tps);
+}
+
+extern "C" size_t d3f_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 256;
+    int bm, bn, S, tps;
+    gemm_plan(M, N, K, bm, bn, S, tps);
+    return S > 1 ? d3f_align((size_t)S * M * N * sizeof(float)) + 256 : 256;
+}
+
+extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                            const float* row_scale, const float* col_scale, const float* col_shift,
+                            const float* residual, int ldr, int leaky, float alpha,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || N < 0 || K < 0 || lda < K || ldb < N || ldc < N || (residual && ldr < N)) return D3F_ERR_ARG;
+    if (M == 0 || N == 0) return D3F_OK;
+    if (!C || (K > 0 && (!A || !B))) return D3F_ERR_ARG;
+    GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
+    int bm, bn, S, tps;
+    gemm_plan(M, N, K > 0 ? K : 1, bm, bn, S, tps);
+    float* slab = nullptr;
+    if (S > 1) {
+        const size_t need = (size_t)S * M * N * sizeof(float);
+        if (!workspace || workspace_bytes < need) return D3F_ERR_WORKSPACE;
+        slab = (float*)workspace;
+    }
+    const int vecA = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
+    const int vecB = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    if (d3f_cdiv(N, bn) > 65535) return D3F_ERR_ARG;
+    dim3 grid(d3f_cdiv(M, bm), d3f_cdiv(N, bn), S);
+    if (bn == 32)
+        gemm_f32_kernel<4, 1><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E);
+    else
+        gemm_f32_kernel<2, 2><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E);
+    if (S > 1)
+        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}

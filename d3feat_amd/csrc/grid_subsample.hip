@@ -1,0 +1,413 @@
+// Voxel-grid barycentre subsampling on gfx950, bit-identical to the reference INCLUDING output row order.
+//
+// Reference: tf_custom_ops/tf_subsampling/grid_subsampling/grid_subsampling.cpp:5-97 (one cloud) and :101-149
+// (batch); cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-105 (features / classes).
+//
+// The reference walks the points once, keeps one accumulator per voxel in a std::unordered_map and emits
+// the map in iteration order.  Three things must be reproduced exactly:
+//   (1) voxel keys: fp32 origin = floor(min*(1/dl))*dl, per-axis index floor((p-origin)/dl) with a true
+//       IEEE divide, key = ix + NX*iy + NX*NY*iz in 64 bits;
+//   (2) barycentre = fp32 sum of the voxel's points IN INPUT ORDER times (float)(1.0/count);
+//   (3) row order = libstdc++ unordered_map iteration order for keys inserted in first-occurrence order.
+//
+// MI355X design (all HBM/L2-bound integer + gather work, no MFMA):
+//   * keys -> open-addressing hash table in HBM (atomicCAS), first-occurrence index by atomicMin;
+//   * first-occurrence flags -> exclusive scan = voxel ids in insertion order;
+//   * per-voxel point lists in input order WITHOUT a sort: lock-free chains (atomicExch), then each point
+//     ranks itself inside its chain and scatters its index -> a thread per voxel sums sequentially;
+//   * (3) has a closed form: inserting a sequence into a fresh table of nb buckets yields the list
+//     "buckets by DEscending first-insertion position, inside a bucket by DEscending position", and a
+//     rehash re-inserts the current list order.  So the order is ~log2(M) rounds of
+//     {bucket first-position (atomicMin), bucket sizes, reverse scan, rank inside bucket chain}, each fully
+//     parallel; one 1024-thread workgroup per batch element runs all rounds inside one launch (total work
+//     ~2M element-steps), batch elements in parallel.
+#include "common.h"
+
+#define GS_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define GS_KEYBITS 56
+#define GS_KEYMASK ((1ull << GS_KEYBITS) - 1ull)
+
+__constant__ unsigned long long D3F_CHAIN_DEV[D3F_NCHAIN] = {
+    13ull, 29ull, 59ull, 127ull, 257ull, 541ull, 1109ull, 2357ull, 5087ull, 10273ull, 20753ull, 42043ull, 85229ull,
+    172933ull, 351061ull, 712697ull, 1447153ull, 2938679ull, 5967347ull, 12117689ull, 24607243ull, 49969847ull,
+    101473717ull, 206062531ull, 418451333ull, 849749479ull, 1725587117ull, 3504151727ull};
+
+struct GsElem {
+    float org[3];
+    int pad0;
+    unsigned long long NX, NY;
+    long long bbase;  // base of this element's bucket scratch
+};
+
+static unsigned long long gs_chain_ge(long long n) {
+    for (int j = 0; j < D3F_NCHAIN; ++j)
+        if ((long long)D3F_CHAIN_HOST[j] >= n) return D3F_CHAIN_HOST[j];
+    return D3F_CHAIN_HOST[D3F_NCHAIN - 1];
+}
+
+__device__ __forceinline__ unsigned long long gs_mix(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+// ---- per-element origin / grid dims (grid_subsampling.cpp:24-30), one thread per element -------------
+__global__ void gs_prep_kernel(const unsigned* __restrict__ bbox, const int* __restrict__ offs, int B, float dl,
+                               GsElem* __restrict__ el, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    GsElem e;
+    e.pad0 = 0;
+    const int len = offs[b + 1] - offs[b];
+    if (len <= 0) {
+        atomicOr(&status[1], D3F_ST_EMPTY_ELEMENT);
+        e.org[0] = e.org[1] = e.org[2] = 0.f;
+        e.NX = e.NY = 1;
+    } else {
+        const float inv = __fdiv_rn(1.0f, dl);  // `1/sampleDl`
+        float mx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float mn = d3f_ord2f(bbox[b * 6 + d]);
+            mx[d] = d3f_ord2f(bbox[b * 6 + 3 + d]);
+            e.org[d] = __fmul_rn(floorf(__fmul_rn(mn, inv)), dl);
+        }
+        e.NX = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(mx[0], e.org[0]), dl)) + 1ull;
+        e.NY = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(mx[1], e.org[1]), dl)) + 1ull;
+    }
+    // bucket scratch base: prefix over elements of chain_ge(len)
+    long long base = 0;
+    for (int j = 0; j < b; ++j) {
+        long long l = offs[j + 1] - offs[j];
+        unsigned long long nb = D3F_CHAIN_DEV[D3F_NCHAIN - 1];
+        for (int c = 0; c < D3F_NCHAIN; ++c)
+            if ((long long)D3F_CHAIN_DEV[c] >= l) { nb = D3F_CHAIN_DEV[c]; break; }
+        base += (long long)nb;
+    }
+    e.bbase = base;
+    el[b] = e;
+}
+
+// ---- voxel key per point + hash insert (grid_subsampling.cpp:49-59) ----------------------------------
+__global__ void __launch_bounds__(256) gs_insert_kernel(const float* __restrict__ pts, int N, const int* __restrict__ offs,
+                                                        int B, float dl, const GsElem* __restrict__ el,
+                                                        unsigned long long* __restrict__ tkey, int* __restrict__ tfirst,
+                                                        unsigned long long capmask, int* __restrict__ slot,
+                                                        int* __restrict__ status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int b = d3f_find_elem(offs, B, i);
+    const GsElem e = el[b];
+    const float fx = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 0], e.org[0]), dl));
+    const float fy = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], e.org[1]), dl));
+    const float fz = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], e.org[2]), dl));
+    int st = 0;
+    if (fx < 0.f || fy < 0.f || fz < 0.f) st |= D3F_ST_NEG_CELL;
+    const unsigned long long ix = (unsigned long long)fmaxf(fx, 0.f), iy = (unsigned long long)fmaxf(fy, 0.f),
+                             iz = (unsigned long long)fmaxf(fz, 0.f);
+    const unsigned long long key = ix + e.NX * iy + e.NX * e.NY * iz;
+    if (key > GS_KEYMASK) st |= D3F_ST_KEY_RANGE;
+    if (st) atomicOr(&status[1], st);
+    const unsigned long long word = ((unsigned long long)b << GS_KEYBITS) | (key & GS_KEYMASK);
+    unsigned long long h = gs_mix(word) & capmask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&tkey[h], GS_EMPTY, word);
+        if (prev == GS_EMPTY || prev == word) break;
+        h = (h + 1) & capmask;
+    }
+    atomicMin(&tfirst[h], i);
+    slot[i] = (int)h;
+}
+
+__global__ void __launch_bounds__(256) gs_mark_kernel(int N, const int* __restrict__ slot, const int* __restrict__ tfirst,
+                                                      int* __restrict__ isfirst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) isfirst[i] = (tfirst[slot[i]] == i) ? 1 : 0;
+}
+
+// ---- voxel ids, voxel keys, per-voxel chains ----------------------------------------------------------
+__global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restrict__ slot, const int* __restrict__ tfirst,
+                                                       const unsigned long long* __restrict__ tkey,
+                                                       const int* __restrict__ vscan, int* __restrict__ pvid,
+                                                       unsigned long long* __restrict__ vkey, int* __restrict__ vhead,
+                                                       int* __restrict__ vcnt, int* __restrict__ pnext) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int s = slot[i];
+    const int fi = tfirst[s];
+    const int v = vscan[fi];
+    pvid[i] = v;
+    if (fi == i) vkey[v] = tkey[s] & GS_KEYMASK;
+    pnext[i] = atomicExch(&vhead[v], i);
+    atomicAdd(&vcnt[v], 1);
+}
+
+__global__ void gs_moffs_kernel(const int* __restrict__ offs, int B, const int* __restrict__ vscan,
+                                const int* __restrict__ status, int* __restrict__ moffs, int* __restrict__ sub_lens) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    const int M = status[0];
+    // vscan[offs[b]] = number of voxels created by points before element b (empty tail -> M)
+    const int N = offs[B];
+    const int lo = (b == B || offs[b] >= N) ? M : vscan[offs[b]];
+    moffs[b] = lo;
+    if (b < B) {
+        const int hi = (b + 1 == B || offs[b + 1] >= N) ? M : vscan[offs[b + 1]];
+        sub_lens[b] = hi - lo;
+    }
+}
+
+// ---- rank of each point inside its voxel chain (= number of chain members with a smaller index) ----------
+__global__ void __launch_bounds__(256) gs_rank_kernel(int N, const int* __restrict__ pvid, const int* __restrict__ vhead,
+                                                      const int* __restrict__ pnext, const int* __restrict__ vstart,
+                                                      int* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int v = pvid[i];
+    int r = 0;
+    for (int j = vhead[v]; j >= 0; j = pnext[j]) r += (j < i) ? 1 : 0;
+    sorted[vstart[v] + r] = i;
+}
+
+// ---- libstdc++ unordered_map iteration order (closed form, see file header) --------------------------
+__device__ __forceinline__ int gs_ld(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(1024) gs_order_kernel(const unsigned long long* __restrict__ vkey,
+                                                        const int* __restrict__ moffs, const int* __restrict__ offs,
+                                                        const GsElem* __restrict__ el, int* L0, int* L1, int* nx,
+                                                        int* cd, int* bf, int* bc, int* bh, int* __restrict__ vpos) {
+    __shared__ int wsum[16];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int M = moffs[b + 1] - moffs[b];
+    if (M <= 0) return;
+    const unsigned long long* key = vkey + moffs[b];
+    int* La = L0 + offs[b];
+    int* Lb = L1 + offs[b];
+    int* NXT = nx + offs[b];
+    int* CD = cd + offs[b];
+    int* BF = bf + el[b].bbase;
+    int* BC = bc + el[b].bbase;
+    int* BH = bh + el[b].bbase;
+    int* VP = vpos + moffs[b];
+    int lo = 0;
+    for (int j = 0; j < D3F_NCHAIN; ++j) {
+        const unsigned long long nbl = D3F_CHAIN_DEV[j];  // bucket count of this round (N <= 2^30 keeps it < 2^31)
+        const int nb = (int)nbl;
+        const bool last = M <= nb;
+        const int hi = last ? M : nb;  // elements in the table at the end of this round
+        for (int t = tid; t < nb; t += 1024) { BF[t] = 0x7fffffff; BC[t] = 0; BH[t] = -1; }
+        __syncthreads();
+        // insertion sequence of this round: the previous round's list order (rehash), then the new keys
+        for (int t = tid; t < hi; t += 1024) {
+            const int id = (t < lo) ? gs_ld(&La[t]) : t;
+            const int bk = (int)(key[id] % nbl);
+            atomicMin(&BF[bk], t);
+            atomicAdd(&BC[bk], 1);
+            NXT[t] = atomicExch(&BH[bk], t);
+        }
+        __syncthreads();
+        // CD[t] = sum over t' > t of c[t'],  c[t] = (t is the first insertion of its bucket) ? bucket size : 0
+        int carry = 0;
+        for (int c0 = 0; c0 < hi; c0 += 1024) {
+            const int u = c0 + tid;
+            const int t = hi - 1 - u;
+            int c = 0;
+            if (u < hi) {
+                const int id = (t < lo) ? gs_ld(&La[t]) : t;
+                const int bk = (int)(key[id] % nbl);
+                c = (gs_ld(&BF[bk]) == t) ? gs_ld(&BC[bk]) : 0;
+            }
+            int x = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) wsum[w] = x;
+            __syncthreads();
+            int base = 0, tot = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int s = wsum[q];
+                if (q < w) base += s;
+                tot += s;
+            }
+            __syncthreads();
+            if (u < hi) CD[t] = carry + base + x - c;
+            carry += tot;
+        }
+        __syncthreads();
+        // list position = (elements of buckets first-inserted later) + (later insertions into the same bucket)
+        for (int t = tid; t < hi; t += 1024) {
+            const int id = (t < lo) ? gs_ld(&La[t]) : t;
+            const int bk = (int)(key[id] % nbl);
+            int r = 0;
+            for (int q = gs_ld(&BH[bk]); q >= 0; q = gs_ld(&NXT[q])) r += (q > t) ? 1 : 0;
+            const int dest = gs_ld(&CD[gs_ld(&BF[bk])]) + r;
+            Lb[dest] = id;
+            if (last) VP[id] = dest;
+        }
+        __syncthreads();
+        if (last) break;
+        int* tmp = La; La = Lb; Lb = tmp;
+        lo = hi;
+    }
+}
+
+// ---- per-voxel in-order accumulation + emit (grid_subsampling.cpp:63-70, :81-92) -----------------------
+__global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__ pts, const float* __restrict__ feat,
+                                                       int fdim, const int* __restrict__ status,
+                                                       const int* __restrict__ moffs, int B,
+                                                       const int* __restrict__ vstart, const int* __restrict__ vcnt,
+                                                       const int* __restrict__ sorted, const int* __restrict__ vpos,
+                                                       float* __restrict__ out_p, float* __restrict__ out_f) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= status[0]) return;
+    const int b = d3f_find_elem(moffs, B, v);
+    const int n = vcnt[v], st = vstart[v];
+    const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const size_t i = (size_t)sorted[st + t];
+        sx = __fadd_rn(sx, pts[3 * i + 0]);
+        sy = __fadd_rn(sy, pts[3 * i + 1]);
+        sz = __fadd_rn(sz, pts[3 * i + 2]);
+    }
+    const float sc = (float)(1.0 / (double)n);  // `1.0 / v.second.count` is a double, narrowed by operator*(PointXYZ, float)
+    out_p[3 * dest + 0] = __fmul_rn(sx, sc);
+    out_p[3 * dest + 1] = __fmul_rn(sy, sc);
+    out_p[3 * dest + 2] = __fmul_rn(sz, sc);
+    if (fdim > 0) {
+        const float cf = (float)n;
+        for (int f = 0; f < fdim; ++f) {
+            float s = 0.f;
+            for (int t = 0; t < n; ++t) s = __fadd_rn(s, feat[(size_t)sorted[st + t] * fdim + f]);
+            out_f[dest * fdim + f] = __fdiv_rn(s, cf);
+        }
+    }
+}
+
+// classes: the reference's max_element over unordered_map<int,int> compares (label, count) pairs, label
+// first, i.e. returns the LARGEST label id present in the voxel (grid_subsampling.cpp:94).
+__global__ void __launch_bounds__(256) gs_fill_kernel(int* __restrict__ p, size_t n, int v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(256) gs_labels_kernel(int N, int ldim, const int* __restrict__ cls,
+                                                        const int* __restrict__ pvid, const int* __restrict__ moffs, int B,
+                                                        const int* __restrict__ vpos, int* __restrict__ out_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int v = pvid[i];
+    const int b = d3f_find_elem(moffs, B, v);
+    const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
+    for (int l = 0; l < ldim; ++l) atomicMax(&out_c[dest * ldim + l], cls[(size_t)i * ldim + l]);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GsLayout {
+    size_t cap;
+    long long bucket_total;
+};
+static GsLayout gs_layout(int N, int B) {
+    GsLayout L;
+    L.cap = 64;
+    while (L.cap < (size_t)2 * (size_t)(N > 0 ? N : 1)) L.cap <<= 1;
+    // sum_b chain_ge(len_b) <= chain_ge-ratio bound: every chain step is < 2.24x, so chain_ge(l) < 2.24*l + 13
+    L.bucket_total = (long long)(2.24 * (double)N) + 16ll * B + 64;
+    return L;
+}
+
+extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int ldim) {
+    (void)fdim; (void)ldim;
+    if (N < 0 || B < 1) return 0;
+    GsLayout L = gs_layout(N, B);
+    size_t n = (size_t)(N > 0 ? N : 1);
+    size_t bytes = 0;
+    bytes += d3f_align((B + 1) * sizeof(int)) * 2;          // offs, moffs
+    bytes += d3f_align(B * 6 * sizeof(unsigned));           // bbox
+    bytes += d3f_align(B * sizeof(GsElem));
+    bytes += d3f_align(L.cap * sizeof(unsigned long long)); // tkey
+    bytes += d3f_align(L.cap * sizeof(int));                // tfirst
+    bytes += d3f_align(n * sizeof(unsigned long long));     // vkey
+    bytes += 12 * d3f_align(n * sizeof(int));               // slot isfirst/vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx cd (13, one shared)
+    bytes += 2 * d3f_align(n * sizeof(int));
+    bytes += 3 * d3f_align((size_t)L.bucket_total * sizeof(int));
+    bytes += d3f_align(d3f_scan_tmp_ints(N) * sizeof(int));
+    return bytes + 4096;
+}
+
+extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
+                                        const float* features, int fdim, const int* classes, int ldim,
+                                        float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
+                                        int* status_dev, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || N > (1 << 30) || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f) || fdim < 0 || ldim < 0) return D3F_ERR_ARG;
+    if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
+    if ((fdim > 0 && (!features || !sub_features)) || (ldim > 0 && (!classes || !sub_classes))) return D3F_ERR_ARG;
+    D3F_HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int), stream));
+    if (N == 0) {
+        D3F_HIP_TRY(hipMemsetAsync(sub_lens_dev, 0, B * sizeof(int), stream));
+        return D3F_OK;
+    }
+    GsLayout L = gs_layout(N, B);
+    D3fArena ar(workspace, workspace_bytes);
+    const size_t n = (size_t)N;
+    int* offs = ar.take<int>(B + 1);
+    int* moffs = ar.take<int>(B + 1);
+    unsigned* bbox = ar.take<unsigned>(B * 6);
+    GsElem* el = ar.take<GsElem>(B);
+    unsigned long long* tkey = ar.take<unsigned long long>(L.cap);
+    int* tfirst = ar.take<int>(L.cap);
+    unsigned long long* vkey = ar.take<unsigned long long>(n);
+    int* slot = ar.take<int>(n);
+    int* vscan = ar.take<int>(n);
+    int* pvid = ar.take<int>(n);
+    int* vhead = ar.take<int>(n);
+    int* vcnt = ar.take<int>(n);
+    int* pnext = ar.take<int>(n);
+    int* vstart = ar.take<int>(n);
+    int* sorted = ar.take<int>(n);
+    int* vpos = ar.take<int>(n);
+    int* L0 = ar.take<int>(n);
+    int* L1 = ar.take<int>(n);
+    int* nx = ar.take<int>(n);
+    int* cd = ar.take<int>(n);
+    int* bf = ar.take<int>((size_t)L.bucket_total);
+    int* bc = ar.take<int>((size_t)L.bucket_total);
+    int* bh = ar.take<int>((size_t)L.bucket_total);
+    int* stmp = ar.take<int>(d3f_scan_tmp_ints(N));
+    if (!ar.ok) return D3F_ERR_WORKSPACE;
+
+    int rc;
+    if ((rc = d3f_offsets_launch(lens_dev, B, offs, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_bbox_launch(points, offs, B, N, bbox, stream)) != D3F_OK) return rc;
+    gs_prep_kernel<<<d3f_cdiv(B, 64), 64, 0, stream>>>(bbox, offs, B, dl, el, status_dev);
+    D3F_HIP_TRY(hipMemsetAsync(tkey, 0xFF, L.cap * sizeof(unsigned long long), stream));
+    D3F_HIP_TRY(hipMemsetAsync(tfirst, 0x7F, L.cap * sizeof(int), stream));  // 0x7F7F7F7F > any index
+    const int nblk = d3f_cdiv(N, 256);
+    gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
+                                               slot, status_dev);
+    gs_mark_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, vscan);
+    D3F_LAUNCH_CHECK();
+    if ((rc = d3f_exclusive_scan_i32(vscan, vscan, N, stmp, &status_dev[0], stream)) != D3F_OK) return rc;
+    D3F_HIP_TRY(hipMemsetAsync(vhead, 0xFF, n * sizeof(int), stream));
+    D3F_HIP_TRY(hipMemsetAsync(vcnt, 0, n * sizeof(int), stream));
+    gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, pvid, vkey, vhead, vcnt, pnext);
+    gs_moffs_kernel<<<d3f_cdiv(B + 1, 64), 64, 0, stream>>>(offs, B, vscan, status_dev, moffs, sub_lens_dev);
+    D3F_LAUNCH_CHECK();
+    if ((rc = d3f_exclusive_scan_i32(vcnt, vstart, N, stmp, nullptr, stream)) != D3F_OK) return rc;
+    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, pvid, vhead, pnext, vstart, sorted);
+    gs_order_kernel<<<B, 1024, 0, stream>>>(vkey, moffs, offs, el, L0, L1, nx, cd, bf, bc, bh, vpos);
+    gs_accum_kernel<<<nblk, 256, 0, stream>>>(points, features, fdim, status_dev, moffs, B, vstart, vcnt, sorted, vpos,
+                                              sub_points, sub_features);
+    if (ldim > 0) {
+        const size_t tot = n * (size_t)ldim;
+        gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);
+        gs_labels_kernel<<<nblk, 256, 0, stream>>>(N, ldim, classes, pvid, moffs, B, vpos, sub_classes);
+    }
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}

@@ -1,0 +1,214 @@
+// KPConv phase 1 on gfx950: neighbour gather + kernel-point influences + weighted aggregation.
+//
+// Reference: kernels/convolution_ops.py:161-255 (KPConv_ops).  The TF graph materialises
+// [n, K, 15, 3] differences and an [n, K, Cin] gather in memory (:200-205, :237); here both stay on chip:
+//   wf[n,p,c]  = sum_k h(|| (s[idx[n,k]] - q[n]) - KP[p] ||) * f[idx[n,k], c]          (:194-240)
+//   inv_cnt[n] = 1 / max(#{k : sum_c f[idx[n,k], c] > 0}, 1)                          (:250-252)
+// The dense contraction wf[n, 15*Cin] x K_values[15*Cin, Cout] (:243-247) and the division (:253) run on the
+// matrix cores in gemm_f32.hip (row_scale = inv_cnt).
+//
+// MI355X mapping (bandwidth/VALU bound; the feature rows live in L2 / Infinity Cache after the first touch):
+//  * kpconv_agg_vec4 (Cin % 4 == 0): a 256-thread workgroup owns TQ = 256/LQ queries, LQ = Cin/4 lanes per
+//    query, each lane owns 4 channels x 15 kernel points (60 accumulators in VGPRs).  Neighbours are processed
+//    in chunks of KC = LQ: first every thread computes the 15 influences of ONE (query, neighbour) pair and
+//    parks them in LDS (64 B per pair) together with the neighbour index; then each lane walks its query's
+//    chunk: one coalesced 16-byte feature load per neighbour (the LQ lanes of a query read one contiguous
+//    Cin*4-byte row), 4 LDS b128 broadcasts for the influences, 60 FMAs.  Shadow neighbours (idx >= Ns) are
+//    skipped: their influence is exactly 0 in the reference (shadow point at 1e6) and their feature row is 0.
+//  * kpconv_agg_scalar (any Cin, used for the Cin = 1 input layer): one thread per (query, channel).
+#include "common.h"
+
+#define KP_MAXP D3F_NUM_KP_MAX  // 16 slots, 15 used by the reference
+
+struct KpParams {
+    float kp[KP_MAXP * 3];
+    int num_kp;
+    float extent;
+    int influence;    // 0 constant, 1 linear, 2 gaussian
+    int aggregation;  // 0 sum, 1 closest
+};
+
+// influences of one neighbour (relative position r) for all kernel points
+__device__ __forceinline__ void kp_influences(const KpParams& P, float rx, float ry, float rz, float* w) {
+    float best = 3.4e38f;
+    int bestp = 0;
+#pragma unroll
+    for (int p = 0; p < KP_MAXP; ++p) {
+        if (p < P.num_kp) {
+            const float dx = rx - P.kp[3 * p], dy = ry - P.kp[3 * p + 1], dz = rz - P.kp[3 * p + 2];
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            float v;
+            if (P.influence == 1) v = fmaxf(1.0f - sqrtf(d2 + 1e-10f) / (2.0f * P.extent), 0.0f);
+            else if (P.influence == 0) v = 1.0f;
+            else { const float sig = P.extent * 0.3f; v = expf(-d2 / (2.0f * sig * sig + 1e-9f)); }
+            w[p] = v;
+            if (d2 < best) { best = d2; bestp = p; }
+        } else {
+            w[p] = 0.f;
+        }
+    }
+    if (P.aggregation == 1) {
+#pragma unroll
+        for (int p = 0; p < KP_MAXP; ++p)
+            if (p != bestp) w[p] = 0.f;
+    }
+}
+
+// row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
+// the support row, so it is evaluated once per support instead of once per (query, neighbour).
+__global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict__ f, int Ns, int ldf, int Cin,
+                                                        unsigned char* __restrict__ pos) {
+    // one wavefront per row
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= Ns) return;
+    float s = 0.f;
+    for (int c = lane; c < Cin; c += 64) s += f[(size_t)row * ldf + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) pos[row] = s > 0.f ? 1 : 0;
+}
+
+template <int LQ>  // lanes per query = Cin / 4
+__global__ void __launch_bounds__(256)
+kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                KpParams P, float* __restrict__ wf, float* __restrict__ inv_cnt) {
+    constexpr int TQ = 256 / LQ;  // queries per workgroup
+    constexpr int KC = LQ;        // neighbours per chunk (TQ*KC = 256 pairs = one per thread)
+    constexpr int WS = KC * 16 + 4;  // per-query stride in floats (+4: de-phase the b128 broadcasts of adjacent queries)
+    __shared__ __attribute__((aligned(16))) float lw[TQ * WS];
+    __shared__ int lidx[TQ * KC];
+    __shared__ int lcnt[TQ];
+    const int tid = threadIdx.x;
+    const int ql = tid / LQ, cl = tid % LQ;  // query-in-block, channel group
+    const int qg = blockIdx.x * TQ + ql;
+    const int Cin = LQ * 4;
+    if (tid < TQ) lcnt[tid] = 0;
+    float acc[KP_MAXP - 1][4];
+#pragma unroll
+    for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (qg < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
+        {
+            const int k = k0 + cl;
+            int id = Ns;
+            if (qg < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
+            float w[KP_MAXP];
+            if (id >= 0 && id < Ns) {
+                const float rx = s[3 * (size_t)id] - qx, ry = s[3 * (size_t)id + 1] - qy, rz = s[3 * (size_t)id + 2] - qz;
+                kp_influences(P, rx, ry, rz, w);
+                if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
+            } else {
+                id = -1;
+#pragma unroll
+                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
+            }
+            lidx[ql * KC + cl] = id;
+            float4* dst = (float4*)&lw[ql * WS + cl * 16];
+            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
+            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
+            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
+        }
+        __syncthreads();
+        // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
+        const int kend = min(KC, K - k0);
+        for (int kk = 0; kk < kend; ++kk) {
+            const int id = lidx[ql * KC + kk];
+            if (id < 0) continue;
+            const float4 fv = *(const float4*)&f[(size_t)id * ldf + 4 * cl];
+            const float4* src = (const float4*)&lw[ql * WS + kk * 16];
+            const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                 w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+            for (int p = 0; p < KP_MAXP - 1; ++p) {
+                acc[p][0] = fmaf(w[p], fv.x, acc[p][0]);
+                acc[p][1] = fmaf(w[p], fv.y, acc[p][1]);
+                acc[p][2] = fmaf(w[p], fv.z, acc[p][2]);
+                acc[p][3] = fmaf(w[p], fv.w, acc[p][3]);
+            }
+        }
+        __syncthreads();
+    }
+    if (qg < Nq) {
+        float* o = wf + (size_t)qg * P.num_kp * Cin + 4 * cl;
+#pragma unroll
+        for (int p = 0; p < KP_MAXP - 1; ++p)
+            if (p < P.num_kp) *(float4*)&o[(size_t)p * Cin] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+        if (cl == 0) inv_cnt[qg] = 1.0f / fmaxf((float)lcnt[ql], 1.0f);
+    }
+}
+
+// generic path: one thread per (query, channel); every thread recomputes the influences of its query's
+// neighbours (free for Cin = 1, the only shipped use: the all-ones input features of layer 0).
+__global__ void __launch_bounds__(256)
+kpconv_agg_scalar(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                  int ld_idx, int K, const float* __restrict__ f, int ldf, int Cin,
+                  const unsigned char* __restrict__ rowpos, KpParams P, float* __restrict__ wf,
+                  float* __restrict__ inv_cnt) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)Nq * Cin) return;
+    const int qg = (int)(t / Cin), c = (int)(t % Cin);
+    const float qx = q[3 * (size_t)qg], qy = q[3 * (size_t)qg + 1], qz = q[3 * (size_t)qg + 2];
+    float acc[KP_MAXP];
+#pragma unroll
+    for (int p = 0; p < KP_MAXP; ++p) acc[p] = 0.f;
+    int cnt = 0;
+    for (int k = 0; k < K; ++k) {
+        const int id = idx[(size_t)qg * ld_idx + k];
+        if (id < 0 || id >= Ns) continue;
+        float w[KP_MAXP];
+        kp_influences(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
+        const float fv = f[(size_t)id * ldf + c];
+        cnt += rowpos[id] ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < KP_MAXP; ++p) acc[p] = fmaf(w[p], fv, acc[p]);
+    }
+    for (int p = 0; p < P.num_kp; ++p) wf[((size_t)qg * P.num_kp + p) * Cin + c] = acc[p];
+    if (c == 0) inv_cnt[qg] = 1.0f / fmaxf((float)cnt, 1.0f);
+}
+
+extern "C" size_t d3f_kpconv_workspace_bytes(int Ns) { return d3f_align((size_t)(Ns > 0 ? Ns : 1)) + 256; }
+
+extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                                    const float* f, int ldf, int Cin, const float* kp_host, int num_kp, float KP_extent,
+                                    int influence, int aggregation, float* wf, float* inv_cnt,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || Cin < 1 || ldf < Cin || num_kp < 1 || num_kp > KP_MAXP - 1 ||
+        influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f))
+        return D3F_ERR_ARG;
+    if (Nq == 0) return D3F_OK;
+    if (!q || !s || !idx || !f || !kp_host || !wf || !inv_cnt) return D3F_ERR_ARG;
+    KpParams P;
+    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
+    P.num_kp = num_kp; P.extent = KP_extent; P.influence = influence; P.aggregation = aggregation;
+    // per-support "row sum > 0" flags
+    D3fArena ar(workspace, workspace_bytes);
+    unsigned char* rowpos = ar.take<unsigned char>((size_t)(Ns > 0 ? Ns : 1));
+    if (!ar.ok) return D3F_ERR_WORKSPACE;
+    if (Ns > 0) kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, ldf, Cin, rowpos);
+    const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0);
+#define D3F_AGG(LQ_)                                                                                          \
+    kpconv_agg_vec4<LQ_><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, \
+                                                                      P, wf, inv_cnt)
+    if (vec && Cin == 4) D3F_AGG(1);
+    else if (vec && Cin == 8) D3F_AGG(2);
+    else if (vec && Cin == 16) D3F_AGG(4);
+    else if (vec && Cin == 32) D3F_AGG(8);
+    else if (vec && Cin == 64) D3F_AGG(16);
+    else if (vec && Cin == 128) D3F_AGG(32);
+    else if (vec && Cin == 256) D3F_AGG(64);
+    else if (vec && Cin == 512) D3F_AGG(128);
+    else if (vec && Cin == 1024) D3F_AGG(256);
+    else
+        kpconv_agg_scalar<<<d3f_cdiv((long long)Nq * Cin, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf,
+                                                                                   Cin, rowpos, P, wf, inv_cnt);
+#undef D3F_AGG
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}

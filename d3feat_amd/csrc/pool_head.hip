@@ -1,0 +1,265 @@
+// Gather-type ops of the D3Feat network on gfx950: strided-shortcut max pooling, nearest upsampling (+ skip
+// concatenation) and the descriptor / detection head.  All are row gathers: lanes map to channels so that each
+// gathered row is one contiguous, coalesced read (16 B per lane where the channel count allows).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// ind_max_pool -- models/network_blocks.py:51-66.  x' = x with one extra row holding the per-channel minimum
+// of x (the "shadow" row); out[n,c] = max_k x'[idx[n,k], c].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colmin_init_kernel(unsigned* __restrict__ cm, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) cm[c] = 0xFFFFFFFFu;
+}
+
+__global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x, int N1, int ldx, int C,
+                                                     unsigned* __restrict__ cm) {
+    // thread = channel (coalesced across a row); each block strides over rows
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    unsigned m = 0xFFFFFFFFu;
+    for (int r = blockIdx.y; r < N1; r += gridDim.y) m = min(m, d3f_f2ord(x[(size_t)r * ldx + c]));
+    atomicMin(&cm[c], m);
+}
+
+__global__ void __launch_bounds__(256) colmin_decode_kernel(unsigned* __restrict__ cm, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) ((float*)cm)[c] = d3f_ord2f(cm[c]);
+}
+
+__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, int N1, int ldx, int C,
+                                                      const int* __restrict__ idx, int N2, int ld_idx, int K,
+                                                      const float* __restrict__ colmin, float* __restrict__ out, int ldo) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N2 * C) return;
+    const int n = (int)(t / C), c = (int)(t % C);
+    const float sh = colmin[c];
+    float m = -3.402823466e38f;
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+        const int id = idx[(size_t)n * ld_idx + k];
+        const float v = (id >= 0 && id < N1) ? x[(size_t)id * ldx + c] : sh;
+        m = any ? fmaxf(m, v) : v;
+        any = true;
+    }
+    out[(size_t)n * ldo + c] = any ? m : sh;
+}
+
+extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
+                                float* out, int ldo, float* col_min_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N1 < 0 || N2 < 0 || C < 1 || ldx < C || ldo < C || K < 0 || ld_idx < K) return D3F_ERR_ARG;
+    if (N2 == 0) return D3F_OK;
+    if (!x || !idx || !out || !col_min_dev) return D3F_ERR_ARG;
+    unsigned* cm = (unsigned*)col_min_dev;
+    colmin_init_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
+    if (N1 > 0) {
+        int rows = d3f_cdiv(N1, 64);
+        if (rows > 512) rows = 512;
+        colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, ldx, C, cm);
+    }
+    colmin_decode_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
+    maxpool_kernel<<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, col_min_dev, out,
+                                                                        ldo);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// closest_pool (models/network_blocks.py:69-83, used by nearest_upsample_block :971-979) fused with the skip
+// concatenation of models/D3Feat.py:63:  out[n] = [ x'[idx[n,0]] , skip[n] ],  x' = x + zero row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restrict__ x, int N1, int ldx, int C1,
+                                                           const int* __restrict__ idx, int N2, int ld_idx,
+                                                           const float* __restrict__ skip, int lds, int C2,
+                                                           float* __restrict__ out, int ldo) {
+    const int Ct = C1 + C2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N2 * Ct) return;
+    const int n = (int)(t / Ct), c = (int)(t % Ct);
+    float v;
+    if (c < C1) {
+        const int id = idx[(size_t)n * ld_idx];
+        v = (id >= 0 && id < N1) ? x[(size_t)id * ldx + c] : 0.f;
+    } else {
+        v = skip[(size_t)n * lds + (c - C1)];
+    }
+    out[(size_t)n * ldo + c] = v;
+}
+
+extern "C" int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, const int* idx, int N2, int ld_idx,
+                                    const float* skip, int lds, int C2, float* out, int ldo, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N1 < 0 || N2 < 0 || C1 < 1 || C2 < 0 || ldx < C1 || ldo < C1 + C2 || ld_idx < 1 || (C2 > 0 && lds < C2))
+        return D3F_ERR_ARG;
+    if (N2 == 0) return D3F_OK;
+    if (!x || !idx || !out || (C2 > 0 && !skip)) return D3F_ERR_ARG;
+    upsample_cat_kernel<<<d3f_cdiv((long long)N2 * (C1 + C2), 256), 256, 0, stream>>>(x, N1, ldx, C1, idx, N2, ld_idx, skip,
+                                                                                      lds, C2, out, ldo);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// D3Feat head -- models/D3Feat.py:65-115.
+//   desc  = x * rsqrt(max(sum x^2, 1e-10))                                                   (:65)
+//   m_b   = max over all entries of cloud b's rows (and 0 if the cloud's in_batches row is padded)   (:84-85)
+//   y     = x / (m_b + 1e-6)                                                                 (:90)
+//   mean  = sum_k y[idx[n,k]] / max(#{k : sum_c y[idx[n,k],c] != 0}, 1)                      (:93-97)
+//   score = max_c softplus(y - mean) * y / (1e-6 + max_c y)                                  (:98-106)
+// Kernel 1: per-cloud maxima (ordered-uint atomicMax).  Kernel 2: one half-wave (32 lanes) per point when
+// C <= 32 (the shipped 32-d descriptor), generally ceil(C/32) channels per lane; each neighbour row is one
+// coalesced 128-byte read; channel reductions are 5-step xor shuffles inside the 32-lane half.
+// ------------------------------------------------------------------------------------------------
+__global__ void head_max_init_kernel(const int* __restrict__ lens, const int* __restrict__ include_zero_dev, int B,
+                                     unsigned* __restrict__ mx, int* __restrict__ offs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int s = 0;
+        for (int b = 0; b < B; ++b) {
+            offs[b] = s;
+            s += lens[b];
+            mx[b] = include_zero_dev[b] ? d3f_f2ord(0.f) : 0u;
+        }
+        offs[B] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) head_max_kernel(const float* __restrict__ x, int N, int ldx, int C,
+                                                       const int* __restrict__ offs, int B, unsigned* __restrict__ mx) {
+    const int b = blockIdx.y;
+    const long long lo = (long long)offs[b] * C, hi = (long long)offs[b + 1] * C;
+    unsigned m = 0u;
+    for (long long t = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < hi; t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t / C;
+        const int c = (int)(t % C);
+        m = max(m, d3f_f2ord(x[(size_t)r * ldx + c]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && lo < hi) atomicMax(&mx[b], m);
+}
+
+template <int CPL>  // channels per lane: C <= 32 * CPL
+__global__ void __launch_bounds__(256)
+head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __restrict__ idx, int ld_idx, int K,
+            const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
+            float* __restrict__ score) {
+    const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
+    const bool active = half < N;
+    const int n = active ? half : 0;
+    const int b = d3f_find_elem(offs, B, n);
+    const float den = d3f_ord2f(mx[b]) + 1e-6f;
+    float xv[CPL], yv[CPL], sum[CPL];
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = l + 32 * j;
+        xv[j] = (c < C) ? x[(size_t)n * ldx + c] : 0.f;
+        yv[j] = xv[j] / den;
+        sum[j] = 0.f;
+        sq += xv[j] * xv[j];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    int cnt = 0;
+    for (int k = 0; k < K; ++k) {
+        const int id = idx[(size_t)n * ld_idx + k];
+        if (id < 0 || id >= N) continue;  // shadow row: zeros
+        const int bn = d3f_find_elem(offs, B, id);
+        const float dn = d3f_ord2f(mx[bn]) + 1e-6f;
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = l + 32 * j;
+            const float v = (c < C) ? x[(size_t)id * ldx + c] / dn : 0.f;
+            sum[j] += v;
+            rs += v;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
+        cnt += (rs != 0.f) ? 1 : 0;
+    }
+    const float fc = (float)max(cnt, 1);
+    float ymax = -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+        if (l + 32 * j < C) ymax = fmaxf(ymax, yv[j]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+    float best = -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (l + 32 * j < C) {
+            const float d = yv[j] - sum[j] / fc;
+            // softplus as TF computes it: log1p(exp(d)) with the large/small-argument shortcuts
+            float sp;
+            if (d > 15.f) sp = d;
+            else if (d < -15.f) sp = expf(d);
+            else sp = log1pf(expf(d));
+            best = fmaxf(best, sp * (yv[j] / (1e-6f + ymax)));
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (active) {
+        const float inv = rsqrtf(fmaxf(sq, 1e-10f));
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            if (l + 32 * j < C) desc[(size_t)n * ldd + l + 32 * j] = xv[j] * inv;
+        if (l == 0) score[n] = best;
+    }
+}
+
+extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
+                               const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
+                               int* scratch_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || C < 1 || C > 128 || ldx < C || ldd < C || K < 0 || ld_idx < K || B < 1 || B > D3F_MAX_BATCH) return D3F_ERR_ARG;
+    if (N == 0) return D3F_OK;
+    if (!x || !idx || !lens_dev || !include_zero_dev || !desc || !score || !scratch_dev) return D3F_ERR_ARG;
+    unsigned* mx = (unsigned*)scratch_dev;  // [B]
+    int* offs = scratch_dev + B;            // [B+1]
+    head_max_init_kernel<<<1, 64, 0, stream>>>(lens_dev, include_zero_dev, B, mx, offs);
+    int chunks = d3f_cdiv((long long)N * C, 256 * 16);
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    head_max_kernel<<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
+    const int blocks = d3f_cdiv((long long)N * 32, 256);
+    if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score);
+    else if (C <= 64) head_kernel<2><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score);
+    else head_kernel<4><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone epilogue: out = act(x * col_scale + col_shift + residual)  (network_blocks.py:149-160, :185-186)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) affine_act_kernel(const float* __restrict__ x, int ldx, int M, int N,
+                                                         const float* __restrict__ cs, const float* __restrict__ ch,
+                                                         const float* __restrict__ res, int ldr, int leaky, float alpha,
+                                                         float* __restrict__ out, int ldo) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)M * N) return;
+    const int m = (int)(t / N), n = (int)(t % N);
+    float v = x[(size_t)m * ldx + n];
+    if (cs) v *= cs[n];
+    if (ch) v += ch[n];
+    if (res) v += res[(size_t)m * ldr + n];
+    if (leaky) v = v > 0.f ? v : v * alpha;
+    out[(size_t)m * ldo + n] = v;
+}
+
+extern "C" int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale, const float* col_shift,
+                              const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || N < 0 || ldx < N || ldo < N || (residual && ldr < N)) return D3F_ERR_ARG;
+    if (M == 0 || N == 0) return D3F_OK;
+    if (!x || !out) return D3F_ERR_ARG;
+    affine_act_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(x, ldx, M, N, col_scale, col_shift, residual, ldr,
+                                                                          leaky, alpha, out, ldo);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+extern "C" int d3f_version(void) { return 100; }

@@ -1,0 +1,159 @@
+// Small shared primitives: exclusive scan (i32), per-element bounding boxes, length -> offset prefix.
+// All HBM-bound streaming kernels; 256-thread blocks, 16 B per lane where the layout allows.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan, three launches: per-block scan (1024 items/block) -> scan of block sums (one block,
+// chunked, carries a running total so any n works) -> add block offsets.
+// ------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 4
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds /* >= 4 ints */, int* total) {
+    // wave inclusive scan via DPP-free shuffles (wave = 64)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) lds[w] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+        int s = lds[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(const int* in, int* out,
+                                                                int n, int* __restrict__ block_sums) {
+    __shared__ int lds[4];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan_256(s, lds, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_sums_kernel(int* __restrict__ block_sums, int nblocks,
+                                                               int* __restrict__ total) {
+    __shared__ int lds[4];
+    int carry = 0;
+    for (int c = 0; c < nblocks; c += SCAN_BLOCK) {
+        int i = c + threadIdx.x;
+        int v = (i < nblocks) ? block_sums[i] : 0;
+        int tot;
+        int ex = block_exclusive_scan_256(v, lds, &tot);
+        if (i < nblocks) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_add_kernel(int* __restrict__ out, int n,
+                                                              const int* __restrict__ block_sums) {
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const int add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) out[base + i] += add;
+}
+
+size_t d3f_scan_tmp_ints(int n) { return (size_t)d3f_cdiv(n > 0 ? n : 1, SCAN_TILE) + 64; }
+
+int d3f_exclusive_scan_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream) {
+    if (n <= 0) {
+        if (total) D3F_HIP_TRY(hipMemsetAsync(total, 0, sizeof(int), stream));
+        return D3F_OK;
+    }
+    const int nb = d3f_cdiv(n, SCAN_TILE);
+    scan_tiles_kernel<<<nb, SCAN_BLOCK, 0, stream>>>(in, out, n, tmp);
+    scan_sums_kernel<<<1, SCAN_BLOCK, 0, stream>>>(tmp, nb, total);
+    if (nb > 1) scan_add_kernel<<<nb, SCAN_BLOCK, 0, stream>>>(out, n, tmp);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// offs[0..B] from lens[0..B)   (B <= 255: one thread is plenty)
+// ------------------------------------------------------------------------------------------------
+__global__ void offsets_kernel(const int* __restrict__ lens, int B, int* __restrict__ offs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int s = 0;
+        for (int b = 0; b < B; ++b) { offs[b] = s; s += lens[b]; }
+        offs[B] = s;
+    }
+}
+
+int d3f_offsets_launch(const int* lens, int B, int* offs, hipStream_t stream) {
+    offsets_kernel<<<1, 64, 0, stream>>>(lens, B, offs);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bounding boxes per batch element: grid (chunks, B).  Min/max are exact and order independent, so the
+// result equals cpp_utils/cloud/cloud.cpp:27-66 (min_point / max_point) bit for bit.
+// bbox must be pre-initialised: min slots 0xFFFFFFFF, max slots 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pts, const int* __restrict__ offs,
+                                                   unsigned* __restrict__ bbox) {
+    const int b = blockIdx.y;
+    const int lo = offs[b], hi = offs[b + 1];
+    unsigned mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+    for (int i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            unsigned u = d3f_f2ord(pts[3 * (size_t)i + d]);
+            mn[d] = min(mn[d], u);
+            mx[d] = max(mx[d], u);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[d] = min(mn[d], (unsigned)__shfl_xor((int)mn[d], o, 64));
+            mx[d] = max(mx[d], (unsigned)__shfl_xor((int)mx[d], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && lo < hi) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&bbox[b * 6 + d], mn[d]);
+            atomicMax(&bbox[b * 6 + 3 + d], mx[d]);
+        }
+    }
+}
+
+__global__ void bbox_init_kernel(unsigned* __restrict__ bbox, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * 6) bbox[i] = ((i % 6) < 3) ? 0xFFFFFFFFu : 0u;
+}
+
+int d3f_bbox_launch(const float* pts, const int* offs, int B, int N, unsigned* bbox, hipStream_t stream) {
+    bbox_init_kernel<<<d3f_cdiv(B * 6, 256), 256, 0, stream>>>(bbox, B);
+    int chunks = d3f_cdiv(N > 0 ? N : 1, 256 * 8);
+    if (chunks > 1024) chunks = 1024;
+    bbox_kernel<<<dim3(chunks, B), 256, 0, stream>>>(pts, offs, bbox);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}

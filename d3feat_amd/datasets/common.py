@@ -1,0 +1,280 @@
+"""Input pipeline of the D3Feat descriptor network on the MI355X: the 5-level pyramid of points / neighbour /
+pooling / upsampling index matrices, neighbour-limit calibration and the test pipeline plumbing.
+
+Mirrors the inference part of the reference's datasets/common.py (class Dataset):
+    tf_batch_subsampling / tf_batch_neighbors          :67-72
+    big_neighborhood_filter                            :399-406
+    tf_get_batch_inds / tf_stack_batch_inds            :408-496
+    calibrate_neighbors                                :572-673
+    init_test_input_pipeline                           :776-857
+    tf_descriptor_input                                :1301-1413
+with torch tensors on the GPU instead of TF graph tensors and eager execution instead of tf.data.  A subclass
+provides `get_batch_gen(split, config)` and `get_tf_mapping(config)` exactly like the reference's datasets
+(demo_registration.py:30-110); generator tuples are
+    (points f32[N,3], anc_keypts, pos_keypts, obj_inds, stack_lengths i32[B], ids, backup_points f32[N,3]).
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from .. import tf_custom_ops
+
+
+def tf_batch_subsampling(points, batches_len, sampleDl):
+    """datasets/common.py:67-68."""
+    return tf_custom_ops.batch_grid_subsampling(points, batches_len, sampleDl)
+
+
+def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius):
+    """datasets/common.py:71-72."""
+    return tf_custom_ops.batch_ordered_neighbors(queries, supports, q_batches, s_batches, radius)
+
+
+def _host_lens(lens):
+    if isinstance(lens, torch.Tensor):
+        return [int(x) for x in lens.tolist()]
+    return [int(x) for x in np.asarray(lens).reshape(-1)]
+
+
+class Dataset:
+    """Base class: holds `neighborhood_limits` and builds the network inputs."""
+
+    def __init__(self, name):
+        self.name = name
+        self.path = ''
+        self.label_to_names = {}
+        self.num_classes = 0
+        self.ignored_labels = np.array([])
+        self.label_names = []
+        self.label_to_idx = {}
+        self.network_model = 'descriptor'
+        self.num_threads = 1
+        self.neighborhood_limits = None
+        self.num_test = 0
+        self.device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.flat_inputs = None
+        self.test_init_op = None
+
+    # ---- utility methods ---------------------------------------------------------------------------------------
+    def big_neighborhood_filter(self, neighbors, layer):
+        """datasets/common.py:399-406: keep the first neighborhood_limits[layer] columns."""
+        return neighbors[:, :int(self.neighborhood_limits[layer])]
+
+    def tf_get_batch_inds(self, stacks_len):
+        """datasets/common.py:408-451: [3, 2, 5] -> [0,0,0,1,1,2,2,2,2,2] (int32, on the device)."""
+        lens = _host_lens(stacks_len)
+        host = np.repeat(np.arange(len(lens), dtype=np.int32), lens)
+        return torch.from_numpy(host).to(self.device)
+
+    def tf_stack_batch_inds(self, stacks_len):
+        """datasets/common.py:453-496: int32[B, max_len(+1)] rows arange padded with the total point count;
+        an extra pad column when all lengths are equal."""
+        lens = _host_lens(stacks_len)
+        n, mx = sum(lens), max(lens)
+        width = mx + (1 if n == mx * len(lens) else 0)
+        host = np.full((len(lens), width), n, dtype=np.int32)
+        p = 0
+        for b, l in enumerate(lens):
+            host[b, :l] = np.arange(p, p + l, dtype=np.int32)
+            p += l
+        return torch.from_numpy(host).to(self.device)
+
+    # ---- the pyramid ------------------------------------------------------------------------------------------------
+    def tf_descriptor_input(self, config, stacked_points, stacked_features, stacked_lengths, batch_inds,
+                            exact_shapes=True, up_first_column_only=False, timings=None):
+        """datasets/common.py:1301-1413.
+
+        exact_shapes=True reproduces the reference's output shapes: every index matrix has
+        min(Kmax, neighborhood_limits[layer]) columns, which costs one host synchronisation per search.
+        exact_shapes=False (the fast path used by the model) always allocates neighborhood_limits[layer] columns
+        and lets the kernel pad with the shadow index -- identical semantics for every consumer
+        (KPConv / max-pool / closest-pool / detection head all treat the shadow index as "no neighbour") -- and
+        defers all status checks to one synchronisation at the end.  up_first_column_only additionally computes
+        only the nearest neighbour for the upsampling matrices (the only column closest_pool reads,
+        models/network_blocks.py:81).
+        """
+        dev = stacked_points.device
+        lens_dev = ops.as_lens(stacked_lengths, dev)
+        stacked_lengths = lens_dev
+        # batch weights (datasets/common.py:1307-1310) -- unused at inference, built lazily on the host
+        host_lens = _host_lens(lens_dev)
+        bw = (np.float32(min(host_lens)) / np.asarray(host_lens, dtype=np.float32)).astype(np.float32)
+        stacked_weights = torch.from_numpy(np.repeat(bw, host_lens)).to(dev)
+
+        r_normal = config.first_subsampling_dl * config.KP_extent * 2.5
+        layer_blocks = []
+        input_points, input_neighbors, input_pools, input_upsamples, input_batches_len = [], [], [], [], []
+        pending = []
+        arch = config.architecture
+
+        def search(q, s, ql, sl, r, layer, first_only=False):
+            lim = int(self.neighborhood_limits[layer])
+            if exact_shapes:
+                full = tf_batch_neighbors(q, s, ql, sl, r)
+                return full[:, :lim]
+            width = 1 if first_only else lim
+            out, status = ops.batch_radius_neighbors(q, s, ql, sl, r, width)
+            pending.append(status)
+            return out
+
+        for block_i, block in enumerate(arch):
+            if 'global' in block or 'upsample' in block:
+                break
+            if not ('pool' in block or 'strided' in block):
+                layer_blocks += [block]
+                if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
+                    continue
+            layer = len(input_points)
+            if layer_blocks:
+                if np.any(['deformable' in blck for blck in layer_blocks[:-1]]):
+                    r = r_normal * config.density_parameter / (config.KP_extent * 2.5)
+                else:
+                    r = r_normal
+                conv_i = search(stacked_points, stacked_points, stacked_lengths, stacked_lengths, r, layer)
+            else:
+                conv_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+            if 'pool' in block or 'strided' in block:
+                dl = 2 * r_normal / (config.KP_extent * 2.5)
+                pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)
+                if 'deformable' in block:
+                    r = r_normal * config.density_parameter / (config.KP_extent * 2.5)
+                else:
+                    r = r_normal
+                pool_i = search(pool_p, stacked_points, pool_b, stacked_lengths, r, layer)
+                up_i = search(stacked_points, pool_p, stacked_lengths, pool_b, 2 * r, layer,
+                              first_only=up_first_column_only)
+            else:
+                pool_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+                pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+                pool_b = torch.zeros((0,), dtype=torch.int32, device=dev)
+                up_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+            input_points += [stacked_points]
+            input_neighbors += [conv_i]
+            input_pools += [pool_i]
+            input_upsamples += [up_i]
+            input_batches_len += [stacked_lengths]
+            stacked_points = pool_p
+            stacked_lengths = pool_b
+            r_normal *= 2
+            layer_blocks = []
+
+        for st in pending:
+            ops.check_status(st, 'tf_descriptor_input/neighbors')
+
+        stacked_batch_inds_0 = self.tf_stack_batch_inds(input_batches_len[0])
+        stacked_batch_inds_1 = self.tf_stack_batch_inds(input_batches_len[-1])
+        li = input_points + input_neighbors + input_pools + input_upsamples
+        li += [stacked_features, stacked_weights, stacked_batch_inds_0, stacked_batch_inds_1]
+        return li
+
+    # ---- neighbour-limit calibration -----------------------------------------------------------------------------------
+    def calibrate_neighbors(self, config, keep_ratio=0.8, samples_threshold=10000, verbose=False):
+        """datasets/common.py:572-673: histogram the number of valid neighbours (index < rows) per layer over at
+        most one epoch of the test split until every layer has >= samples_threshold samples; the limit of a layer
+        is the number of histogram bins whose cumulative count is below keep_ratio of the total."""
+        split = 'train' if len(getattr(self, 'anc_points', {}).get('train', [])) > 0 else 'test'
+        gen_function, _, _ = self.get_batch_gen(split, config)
+        map_func = self.get_tf_mapping(config)
+        hist_n = int(np.ceil(4 / 3 * np.pi * (config.density_parameter + 1) ** 3))
+        neighb_hists = np.zeros((config.num_layers, hist_n), dtype=np.int64)
+        for sample in gen_function():
+            if np.min(np.sum(neighb_hists, axis=1)) >= samples_threshold:
+                break
+            flat = map_func(*self._to_device(sample))
+            neighbors = flat[config.num_layers:2 * config.num_layers]
+            for l, mat in enumerate(neighbors):
+                neighb_hists[l] += self.neighbor_histogram(mat, hist_n)
+        cumsum = np.cumsum(neighb_hists.T, axis=0)
+        percentiles = np.sum(cumsum < (keep_ratio * cumsum[hist_n - 1, :]), axis=0)
+        self.neighborhood_limits = percentiles.astype(np.int32)
+        if verbose:
+            print('neighborhood_limits', self.neighborhood_limits)
+        return neighb_hists
+
+    @staticmethod
+    def neighbor_histogram(neighb_mat, hist_n):
+        """datasets/common.py:645-647 for one matrix.  The matrix is copied to the host for the bincount (it is a
+        start-up calibration pass, not the hot path)."""
+        mat = neighb_mat.cpu().numpy()
+        counts = np.sum(mat < mat.shape[0], axis=1)
+        return np.bincount(counts, minlength=hist_n)[:hist_n].astype(np.int64)
+
+    # ---- test pipeline ------------------------------------------------------------------------------------------------------
+    def _to_device(self, sample):
+        """generator tuple -> map_func arguments: the two point arrays and stack_lengths become device tensors."""
+        pts, anc_k, pos_k, obj, lens, ids, backup = sample
+        return (torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float32)).to(self.device), anc_k, pos_k, obj,
+                torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).to(self.device), ids,
+                torch.from_numpy(np.ascontiguousarray(backup, dtype=np.float32)).to(self.device))
+
+    def init_test_input_pipeline(self, config):
+        """datasets/common.py:776-857: set the limits to the upper bound, calibrate them, then expose the test
+        split as an endless iterator of flat input lists (`self.flat_inputs`; call next() on it, or pass it to
+        KernelPointFCNN which pulls one element per run -- the role of iter.get_next())."""
+        config.num_classes = self.num_classes - len(self.ignored_labels)
+        config.network_model = self.network_model
+        hist_n = int(np.ceil(4 / 3 * np.pi * (config.density_parameter + 1) ** 3))
+        self.neighborhood_limits = np.full(config.num_layers, hist_n, dtype=np.int32)
+        self.calibrate_neighbors(config)
+        print("self.neighborhood:", self.neighborhood_limits)
+        gen_function, _, _ = self.get_batch_gen('test', config)
+        map_func = self.get_tf_mapping(config)
+        dataset = self
+
+        class _Repeat:
+            def __init__(self):
+                self.it = None
+
+            def reset(self):
+                self.it = iter(gen_function())
+
+            def __iter__(self):
+                return self
+
+            def __next__(self):
+                if self.it is None:
+                    self.reset()
+                try:
+                    sample = next(self.it)
+                except StopIteration:  # .repeat()
+                    self.reset()
+                    sample = next(self.it)
+                return map_func(*dataset._to_device(sample))
+
+        self.flat_inputs = _Repeat()
+        self.test_init_op = self.flat_inputs.reset
+
+
+class FragmentDataset(Dataset):
+    """Test-time dataset over a list of point clouds (numpy float32 [N,3], already at the first subsampling
+    resolution).  Like the reference's 3DMatch / ETH / demo test generators (datasets/ThreeDMatch.py:180-192,
+    demo_registration.py:30-95) every fragment is fed stacked with itself: anc == pos."""
+
+    def __init__(self, clouds, ids=None, fast=False):
+        Dataset.__init__(self, 'Fragments')
+        self.anc_points = {'train': [], 'test': [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]}
+        self.ids_list = {'train': [], 'test': list(ids) if ids is not None else ['cloud_%d' % i for i in range(len(clouds))]}
+        self.num_test = len(clouds)
+        self.fast = fast
+
+    def get_batch_gen(self, split, config):
+        def gen():
+            for i, pts in enumerate(self.anc_points[split]):
+                yield (np.concatenate([pts, pts], axis=0), np.array([], dtype=np.int32), np.array([], dtype=np.int32),
+                       np.array([i, i], dtype=np.int32), np.array([pts.shape[0], pts.shape[0]], dtype=np.int32),
+                       np.array([self.ids_list[split][i]] * 2), np.concatenate([pts, pts], axis=0))
+        gen_types = ('float32', 'int32', 'int32', 'int32', 'int32', 'string', 'float32')
+        gen_shapes = ([None, 3], [None], [None], [None], [None], [None], [None, 3])
+        return gen, gen_types, gen_shapes
+
+    def get_tf_mapping(self, config):
+        def tf_map(anc_points, anc_keypts, pos_keypts, obj_inds, stack_lengths, ply_id, backup_points):
+            batch_inds = self.tf_get_batch_inds(stack_lengths)
+            # stacked_features = ones([N, 1])  (demo_registration.py:102): a fill, done once on the host
+            stacked_features = torch.from_numpy(np.ones((anc_points.shape[0], 1), dtype=np.float32)).to(anc_points.device)
+            li = self.tf_descriptor_input(config, anc_points, stacked_features, stack_lengths, batch_inds,
+                                          exact_shapes=not self.fast, up_first_column_only=self.fast)
+            return li + [stack_lengths, anc_keypts, pos_keypts, ply_id, backup_points]
+        return tf_map

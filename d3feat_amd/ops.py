@@ -1,0 +1,268 @@
+"""torch-tensor front end of the C ABI (include/d3feat_amd.h).
+
+PyTorch is used for three things only: device allocations (torch.empty on a CUDA/HIP device), the current
+HIP stream, and torch.distributed.  Every computation below is a call into libd3feat_amd.so; nothing here
+computes with torch ops and nothing falls back to the CPU.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_WS = {}
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch: one growable byte buffer per (device, stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device))
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _req(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor on a GPU (got %s)" % (name, type(t)))
+    if not t.is_cuda:
+        raise _lib.D3FeatLibraryError("%s is on %s: d3feat_amd has no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must be %d-D (got shape %s)" % (name, ndim, tuple(t.shape)))
+    return t
+
+
+def _rows(t, name):
+    """2-D tensor whose rows are contiguous -> (tensor, leading dimension in elements)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("%s must be 2-D with contiguous rows (shape %s strides %s)" % (name, tuple(t.shape), t.stride()))
+    ld = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+    if ld < t.shape[1]:
+        raise ValueError("%s has overlapping rows" % name)
+    return t, int(max(ld, 1))
+
+
+def as_lens(lens, device):
+    if isinstance(lens, torch.Tensor):
+        return lens.to(device=device, dtype=torch.int32).contiguous()
+    return torch.as_tensor(np.asarray(lens, dtype=np.int32), device=device)
+
+
+def check_status(status, what):
+    """status: int32[2] device tensor written by a kernel; raises on any D3F_ST_* flag. Synchronises."""
+    st = status.tolist()
+    flags = st[1]
+    if flags:
+        msgs = []
+        if flags & _lib.ST_EMPTY_ELEMENT:
+            msgs.append("a batch element is empty")
+        if flags & _lib.ST_NEG_CELL:
+            msgs.append("negative voxel index (origin above a point after fp32 rounding)")
+        if flags & _lib.ST_KEY_RANGE:
+            msgs.append("voxel key exceeds 2^56")
+        if flags & _lib.ST_HIT_OVERFLOW:
+            msgs.append("a query has more than %d in-radius supports" % _lib.NEIGHBOR_CAP)
+        raise _lib.D3FeatLibraryError("d3feat_amd.%s: %s" % (what, "; ".join(msgs)))
+    return st[0]
+
+
+# ----------------------------------------------------------------------------------------------------------
+def batch_grid_subsample(points, lens, dl, features=None, classes=None):
+    """-> (sub_points f32[M,3], sub_lens i32[B] (device), sub_features | None, sub_classes | None).
+    One host synchronisation (M is data dependent)."""
+    lib = _lib.load()
+    points = _req(points, torch.float32, "points", 2).contiguous()
+    dev = points.device
+    N = points.shape[0]
+    lens_t = as_lens(lens, dev)
+    B = lens_t.numel()
+    fdim = ldim = 0
+    if features is not None:
+        features = _req(features, torch.float32, "features", 2).contiguous()
+        fdim = features.shape[1]
+    if classes is not None:
+        classes = _req(classes, torch.int32, "classes", 2).contiguous()
+        ldim = classes.shape[1]
+    sub_p = torch.empty((max(N, 1), 3), dtype=torch.float32, device=dev)
+    sub_f = torch.empty((max(N, 1), fdim), dtype=torch.float32, device=dev) if fdim else None
+    sub_c = torch.empty((max(N, 1), ldim), dtype=torch.int32, device=dev) if ldim else None
+    sub_l = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((2,), dtype=torch.int32, device=dev)
+    nbytes = lib.d3f_grid_subsample_workspace_bytes(N, B, fdim, ldim)
+    ws = workspace(nbytes, dev)
+    rc = lib.d3f_batch_grid_subsample(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl),
+                                      features.data_ptr() if fdim else None, fdim,
+                                      classes.data_ptr() if ldim else None, ldim,
+                                      sub_p.data_ptr(), sub_f.data_ptr() if fdim else None,
+                                      sub_c.data_ptr() if ldim else None, sub_l.data_ptr(), status.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _stream(dev))
+    _lib.check(rc, "batch_grid_subsample")
+    M = check_status(status, "batch_grid_subsample")
+    return sub_p[:M], sub_l, (sub_f[:M] if fdim else None), (sub_c[:M] if ldim else None)
+
+
+def batch_radius_neighbors(queries, supports, q_lens, s_lens, radius, width, ld=None, out=None, pad_value=None):
+    """Launch the search; -> (out i32[Nq, ld] with `width` valid columns, status i32[2] device tensor).
+    No synchronisation: status[0] = Kmax, status[1] = flags (see check_status)."""
+    lib = _lib.load()
+    queries = _req(queries, torch.float32, "queries", 2).contiguous()
+    supports = _req(supports, torch.float32, "supports", 2).contiguous()
+    dev = queries.device
+    Nq, Ns = queries.shape[0], supports.shape[0]
+    ql, sl = as_lens(q_lens, dev), as_lens(s_lens, dev)
+    if ql.numel() != sl.numel():
+        raise ValueError("q_batches and s_batches must have the same number of elements")
+    B = ql.numel()
+    ld = int(ld if ld is not None else width)
+    if out is None:
+        out = torch.empty((Nq, ld), dtype=torch.int32, device=dev)
+    status = torch.empty((2,), dtype=torch.int32, device=dev)
+    ws = workspace(lib.d3f_radius_neighbors_workspace_bytes(Nq, Ns, B), dev)
+    rc = lib.d3f_batch_radius_neighbors(queries.data_ptr(), Nq, supports.data_ptr(), Ns, ql.data_ptr(), sl.data_ptr(), B,
+                                        float(radius), out.data_ptr(), ld, int(width),
+                                        int(Ns if pad_value is None else pad_value), status.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream(dev))
+    _lib.check(rc, "batch_radius_neighbors")
+    return out, status
+
+
+_INFLUENCE = {"constant": 0, "linear": 1, "gaussian": 2}
+_AGGREGATION = {"sum": 0, "closest": 1}
+
+
+def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, leaky=False, alpha=0.2, out=None):
+    """out = act((A @ Bm) * row_scale[:,None] * col_scale + col_shift + residual) on the matrix cores."""
+    lib = _lib.load()
+    A, lda = _rows(_req(A, torch.float32, "A"), "A")
+    Bm, ldb = _rows(_req(Bm, torch.float32, "B"), "B")
+    M, K = A.shape
+    if Bm.shape[0] != K:
+        raise ValueError("gemm: A is %s, B is %s" % (tuple(A.shape), tuple(Bm.shape)))
+    N = Bm.shape[1]
+    dev = A.device
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    out, ldc = _rows(out, "out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
+    for v, n, name in ((row_scale, M, "row_scale"), (col_scale, N, "col_scale"), (col_shift, N, "col_shift")):
+        if v is not None:
+            _req(v, torch.float32, name)
+            if v.numel() != n or not v.is_contiguous():
+                raise ValueError("%s must be a contiguous vector of %d" % (name, n))
+    nbytes = lib.d3f_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, dev)
+    rc = lib.d3f_gemm_f32(A.data_ptr(), lda, Bm.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+                          row_scale.data_ptr() if row_scale is not None else None,
+                          col_scale.data_ptr() if col_scale is not None else None,
+                          col_shift.data_ptr() if col_shift is not None else None,
+                          residual.data_ptr() if residual is not None else None, ldr,
+                          1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _stream(dev))
+    _lib.check(rc, "gemm_f32")
+    return out
+
+
+def kpconv_aggregate(query_points, support_points, neighbors_indices, features, K_points, KP_extent,
+                     KP_influence="linear", aggregation_mode="sum"):
+    """-> (wf f32[Nq, num_kp*Cin], inv_cnt f32[Nq])   (phase 1 of KPConv_ops)."""
+    lib = _lib.load()
+    q = _req(query_points, torch.float32, "query_points", 2).contiguous()
+    s = _req(support_points, torch.float32, "support_points", 2).contiguous()
+    idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
+    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    if KP_influence not in _INFLUENCE:
+        raise ValueError("Unknown influence function type (config.KP_influence)")
+    if aggregation_mode not in _AGGREGATION:
+        raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
+    kp = np.ascontiguousarray(K_points.detach().cpu().numpy() if isinstance(K_points, torch.Tensor) else K_points,
+                              dtype=np.float32)
+    num_kp = kp.shape[0]
+    Nq, Ns, K, Cin = q.shape[0], s.shape[0], idx.shape[1], f.shape[1]
+    if idx.shape[0] != Nq or f.shape[0] != Ns:
+        raise ValueError("KPConv: %d queries / %d index rows, %d supports / %d feature rows" %
+                         (Nq, idx.shape[0], Ns, f.shape[0]))
+    dev = q.device
+    wf = torch.empty((Nq, num_kp * Cin), dtype=torch.float32, device=dev)
+    inv_cnt = torch.empty((Nq,), dtype=torch.float32, device=dev)
+    ws = workspace(lib.d3f_kpconv_workspace_bytes(Ns), dev)
+    rc = lib.d3f_kpconv_aggregate(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf, Cin,
+                                  kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
+                                  _AGGREGATION[aggregation_mode], wf.data_ptr(), inv_cnt.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _stream(dev))
+    _lib.check(rc, "kpconv_aggregate")
+    return wf, inv_cnt
+
+
+def ind_max_pool(x, inds):
+    lib = _lib.load()
+    x, ldx = _rows(_req(x, torch.float32, "x"), "x")
+    inds, ldi = _rows(_req(inds, torch.int32, "inds"), "inds")
+    dev = x.device
+    out = torch.empty((inds.shape[0], x.shape[1]), dtype=torch.float32, device=dev)
+    colmin = torch.empty((x.shape[1],), dtype=torch.float32, device=dev)
+    rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
+                              inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _stream(dev))
+    _lib.check(rc, "ind_max_pool")
+    return out
+
+
+def closest_pool_cat(x, inds, skip=None):
+    lib = _lib.load()
+    x, ldx = _rows(_req(x, torch.float32, "x"), "x")
+    inds, ldi = _rows(_req(inds, torch.int32, "inds"), "inds")
+    dev = x.device
+    C1 = x.shape[1]
+    C2 = lds = 0
+    if skip is not None:
+        skip, lds = _rows(_req(skip, torch.float32, "skip"), "skip")
+        C2 = skip.shape[1]
+        if skip.shape[0] != inds.shape[0]:
+            raise ValueError("closest_pool_cat: %d index rows, %d skip rows" % (inds.shape[0], skip.shape[0]))
+    out = torch.empty((inds.shape[0], C1 + C2), dtype=torch.float32, device=dev)
+    rc = lib.d3f_closest_pool_cat(x.data_ptr(), x.shape[0], ldx, C1, inds.data_ptr(), inds.shape[0], ldi,
+                                  skip.data_ptr() if skip is not None else None, lds, C2, out.data_ptr(), C1 + C2,
+                                  _stream(dev))
+    _lib.check(rc, "closest_pool_cat")
+    return out
+
+
+def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev):
+    """-> (desc f32[N,C], score f32[N,1])."""
+    lib = _lib.load()
+    x, ldx = _rows(_req(x, torch.float32, "x"), "x")
+    nb, ldi = _rows(_req(neighbors, torch.int32, "neighbors"), "neighbors")
+    dev = x.device
+    N, Cc = x.shape
+    B = stack_lengths_dev.numel()
+    desc = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+    score = torch.empty((N, 1), dtype=torch.float32, device=dev)
+    scratch = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
+    rc = lib.d3f_detect_head(x.data_ptr(), N, ldx, Cc, nb.data_ptr(), ldi, nb.shape[1],
+                             stack_lengths_dev.data_ptr(), include_zero_dev.data_ptr(), B, desc.data_ptr(), Cc,
+                             score.data_ptr(), scratch.data_ptr(), _stream(dev))
+    _lib.check(rc, "detect_head")
+    return desc, score
+
+
+def affine_act(x, col_scale=None, col_shift=None, residual=None, leaky=False, alpha=0.2):
+    """out = act(x * col_scale + col_shift + residual): the stand-alone form of the GEMM epilogue."""
+    lib = _lib.load()
+    x, ldx = _rows(_req(x, torch.float32, "x"), "x")
+    M, N = x.shape
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    rc = lib.d3f_affine_act(x.data_ptr(), ldx, M, N, col_scale.data_ptr() if col_scale is not None else None,
+                            col_shift.data_ptr() if col_shift is not None else None,
+                            residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0, float(alpha),
+                            out.data_ptr(), N, _stream(x.device))
+    _lib.check(rc, "affine_act")
+    return out

@@ -1,0 +1,150 @@
+/*
+ * d3feat_amd -- C ABI of the MI355X-native D3Feat inference hot path (libd3feat_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / HIP types in the signatures.
+ * Every pointer named *_dev (and every tensor argument) is a DEVICE pointer in HBM unless stated
+ * otherwise; `stream` is a hipStream_t passed as void* (NULL = default stream).  All entry points
+ * are asynchronous on `stream`, allocate nothing (the caller owns outputs and the workspace) and
+ * return D3F_OK or a negative D3F_ERR_* code.  Data-dependent failures that can only be detected
+ * on the device are reported through a caller-provided int status[] in HBM (see each function).
+ *
+ * Each function cites the reference interface (paths relative to the XuyangBai/D3Feat checkout)
+ * it replaces.  INTEGRATION.md shows the binding a maintainer of the reference would add.
+ */
+#ifndef D3FEAT_AMD_H
+#define D3FEAT_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3F_OK 0
+#define D3F_ERR_HIP (-1)        /* a HIP runtime call / kernel launch failed */
+#define D3F_ERR_WORKSPACE (-2)  /* workspace too small (see *_workspace_bytes) */
+#define D3F_ERR_ARG (-3)        /* invalid argument (negative size, B out of range, bad leading dimension ...) */
+
+/* bits of the device-side status word */
+#define D3F_ST_EMPTY_ELEMENT 1   /* a batch element has zero points (UB in the reference, cloud.cpp:30,51)  */
+#define D3F_ST_NEG_CELL 2        /* floor((p-origin)/dl) < 0 (the reference's (size_t) cast would be UB, :52-54) */
+#define D3F_ST_KEY_RANGE 4       /* voxel key >= 2^56 */
+#define D3F_ST_HIT_OVERFLOW 8    /* a query has more in-radius supports than D3F_NEIGHBOR_CAP */
+
+#define D3F_MAX_BATCH 255        /* batch elements per stacked call */
+#define D3F_NEIGHBOR_CAP 1024    /* max in-radius supports per query that can be ordered */
+#define D3F_NUM_KP_MAX 16        /* kernel points per KPConv (reference uses 15) */
+
+int d3f_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Grid subsampling.
+ * Replaces tf_custom_ops/tf_subsampling: BatchGridSubsampling (tf_batch_subsampling.cpp:8-20,
+ * kernel :26-123 -> grid_subsampling/grid_subsampling.cpp:101-149) and GridSubsampling
+ * (tf_subsampling.cpp:8-11 -> grid_subsampling.cpp:5-97) with B = 1; with features/classes it also
+ * replaces the numeric core of cpp_wrappers/cpp_subsampling (wrapper.cpp:58-286 ->
+ * grid_subsampling/grid_subsampling.cpp:5-105).
+ *
+ *   points   f32[N,3]  stacked clouds          lens_dev  i32[B] points per batch element (device)
+ *   features f32[N,fdim] or NULL (fdim 0)      classes   i32[N,ldim] or NULL (ldim 0)
+ *   sub_points f32[N,3] (capacity N rows; the first M are valid)   sub_features f32[N,fdim]  sub_classes i32[N,ldim]
+ *   sub_lens_dev i32[B]  voxels per element
+ *   status_dev i32[2]: [0] = M (total voxels), [1] = OR of D3F_ST_* flags
+ * Output is bit-identical to the reference INCLUDING row order (libstdc++ unordered_map iteration order).
+ * ------------------------------------------------------------------------------------------- */
+size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int ldim);
+int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
+                             const float* features, int fdim, const int* classes, int ldim,
+                             float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
+                             int* status_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Radius neighbours.
+ * Replaces tf_custom_ops/tf_neighbors: BatchOrderedNeighbors (tf_batch_neighbors.cpp:8-30, kernel
+ * :36-120 -> neighbors/neighbors.cpp:211-332 batch_nanoflann_neighbors / :125-208
+ * batch_ordered_neighbors).  Per query: all supports of the same batch element with fp32
+ * d2 = (dx*dx + dy*dy) + dz*dz < radius*radius (strict, no FMA), ordered by (d2, support index)
+ * ascending -- exactly batch_ordered_neighbors, and equal to the active nanoflann path except inside
+ * runs of bit-equal d2 (whose order nanoflann leaves unspecified).
+ *
+ *   queries f32[Nq,3], supports f32[Ns,3], q_lens_dev / s_lens_dev i32[B]
+ *   out i32[Nq, ld]: columns [0,width) are written: the first min(count,width) neighbours then pad_value
+ *       (pass Ns for BatchOrderedNeighbors, neighbors.cpp:324; -1 for OrderedNeighbors, neighbors.cpp:111-119)
+ *   status_dev i32[2]: [0] = max neighbour count over all queries (the reference's output width Kmax),
+ *                      [1] = OR of D3F_ST_* flags
+ * `width` plays the role of datasets/common.py:399-406 (big_neighborhood_filter): pass the layer's
+ * neighborhood limit; pass width = ld >= Kmax to get the untruncated matrix.
+ * ------------------------------------------------------------------------------------------- */
+size_t d3f_radius_neighbors_workspace_bytes(int Nq, int Ns, int B);
+int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* supports, int Ns,
+                               const int* q_lens_dev, const int* s_lens_dev, int B, float radius,
+                               int* out, int ld, int width, int pad_value, int* status_dev,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * KPConv, phase 1: neighbour gather + kernel-point influence + weighted aggregation.
+ * Replaces the first half of kernels/convolution_ops.py:161-255 (KPConv_ops :186-240, :250-252):
+ *   wf[n,p,c]  = sum_k  h(|| (s[idx[n,k]] - q[n]) - KP[p] ||) * f[idx[n,k], c]
+ *   inv_cnt[n] = 1 / max(#{k : sum_c f[idx[n,k],c] > 0}, 1)
+ * influence: 0 constant, 1 linear  h = max(1 - sqrt(d2+1e-10)/(2*KP_extent), 0), 2 gaussian (sigma = 0.3*KP_extent);
+ * aggregation: 0 sum, 1 closest.  Shadow neighbours (idx >= Ns) contribute nothing.
+ *   q f32[Nq,3]  s f32[Ns,3]  idx i32[Nq,ld_idx] (K columns used)  f f32[Ns,ldf] (Cin columns used)
+ *   kp_host f32[num_kp,3] (HOST pointer: 45 floats passed by value to the kernel)  wf f32[Nq, num_kp*Cin]  inv_cnt f32[Nq]
+ * Phase 2 is d3f_gemm_f32(wf, K_values reshaped [num_kp*Cin, Cout]) with row_scale = inv_cnt.
+ * ------------------------------------------------------------------------------------------- */
+size_t d3f_kpconv_workspace_bytes(int Ns);
+int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                         const float* f, int ldf, int Cin, const float* kp_host, int num_kp, float KP_extent,
+                         int influence, int aggregation, float* wf, float* inv_cnt,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
+ * Replaces kernels/convolution_ops.py:90-99 (unary_convolution = tf.matmul) and :243-253 (the
+ * kernel-weight contraction + neighbour-count normalisation), with the inference epilogue of
+ * models/network_blocks.py:149-160,185-186 fused:
+ *   C[m,n] = act( (sum_k A[m,k] B[k,n]) * row_scale[m] * col_scale[n] + col_shift[n] + residual[m,n] )
+ * row_scale / col_scale / col_shift / residual may be NULL (identity); act = LeakyReLU(alpha) when
+ * leaky != 0.  A f32[M,K] (lda), B f32[K,N] (ldb), C f32[M,N] (ldc), residual f32[M,N] (ldr).
+ * workspace is used only when the call decides to split K (skinny shapes).
+ * ------------------------------------------------------------------------------------------- */
+size_t d3f_gemm_workspace_bytes(int M, int N, int K);
+int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                 const float* row_scale, const float* col_scale, const float* col_shift,
+                 const float* residual, int ldr, int leaky, float alpha,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pooling / upsampling gathers.
+ *   d3f_ind_max_pool      models/network_blocks.py:51-66  out[n,c] = max_k x'[idx[n,k],c], x' = x + row of column minima
+ *   d3f_closest_pool_cat  models/network_blocks.py:69-83 + models/D3Feat.py:63
+ *                         out[n, 0:C1] = x'[idx[n,0]] (x' = x + zero row), out[n, C1:C1+C2] = skip[n]  (skip may be NULL, C2 0)
+ *   col_min_dev: f32[C] scratch written by d3f_ind_max_pool.
+ * ------------------------------------------------------------------------------------------- */
+int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
+                     float* out, int ldo, float* col_min_dev, void* stream);
+int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, const int* idx, int N2, int ld_idx,
+                         const float* skip, int lds, int C2, float* out, int ldo, void* stream);
+
+/* Stand-alone form of the GEMM epilogue (models/network_blocks.py:149-160 batch_norm in inference mode folded to
+ * scale/shift, :185-186 leaky_relu, residual add):  out = act(x * col_scale + col_shift + residual). */
+int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale, const float* col_shift,
+                   const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * D3Feat head: descriptors + detection scores.  Replaces models/D3Feat.py:65-115.
+ *   x f32[N,C] (ldx)  un-normalised output of last_unary;  idx i32[N,ld_idx] level-0 neighbours (K columns)
+ *   lens_dev i32[B] points per stacked cloud (B = 2 in the reference, any B >= 1 here)
+ *   include_zero_dev i32[B] (device): 1 if the cloud's row of in_batches contains the shadow index (so that
+ *       the per-cloud maximum of :84-85 includes the zero row) -- datasets/common.py:453-496
+ *   desc f32[N,C] = l2_normalize(x, eps 1e-10);  score f32[N]
+ *   scratch_dev: >= 2*B+2 ints of device scratch.  C <= 128.
+ * ------------------------------------------------------------------------------------------- */
+int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
+                    const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
+                    int* scratch_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3FEAT_AMD_H */

@@ -1,0 +1,241 @@
+"""GPU parity of the network kernels against the torch-CPU restatement of the reference graph
+(oracle/network_np.py).  Floating point: max |diff| <= 1e-4 (BASELINE.json north_star), on activations whose
+scale is O(1); looser relative bound where the magnitude grows."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import surface_cloud
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(got, want, tol=TOL):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(got - want).max()
+    assert err <= tol * scale, "max abs err %.3e (scale %.3g)" % (err, scale)
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 32), (777, 15, 64), (4097, 128, 256), (390, 7680, 512), (200, 1024, 2048),
+                                   (64, 3072, 512), (5, 3, 7)])
+def test_gemm_epilogues(device, M, K, N):
+    from d3feat_amd import ops
+    rng = np.random.default_rng(M + K + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    rs = rng.random(M).astype(np.float32) + 0.5
+    cs = rng.random(N).astype(np.float32) + 0.5
+    ch = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    got = ops.gemm(_t(A, device), _t(B, device)).cpu().numpy()
+    _close(got, ref, 2e-5)
+    full = ref * rs[:, None] * cs + ch + res
+    full = np.where(full > 0, full, 0.2 * full)
+    got = ops.gemm(_t(A, device), _t(B, device), _t(rs, device), _t(cs, device), _t(ch, device), _t(res, device), True, 0.2)
+    _close(got.cpu().numpy(), full, 2e-5)
+
+
+def test_gemm_strided_views(device):
+    from d3feat_amd import ops
+    rng = np.random.default_rng(0)
+    big = rng.standard_normal((300, 96)).astype(np.float32)
+    B = rng.standard_normal((40, 24)).astype(np.float32)
+    tb = _t(big, device)
+    got = ops.gemm(tb[:, 8:48], _t(B, device)).cpu().numpy()      # lda = 96, base not 16B-multiple of row
+    _close(got, big[:, 8:48].astype(np.float64) @ B, 2e-5)
+
+
+def _layer_case(seed, cin, cout, strided, layer=0):
+    from d3feat_amd.utils.config import threedmatch_config
+    cfg = threedmatch_config()
+    s0 = surface_cloud(seed, n_raw=40000)
+    rng = np.random.default_rng(seed)
+    return cfg, s0, rng
+
+
+@pytest.mark.parametrize("cin,cout", [(1, 64), (32, 32), (64, 64), (128, 128), (256, 256), (512, 512), (6, 10)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_kpconv_vs_oracle(device, coracle, cin, cout, strided):
+    from d3feat_amd.kernels import convolution_ops as conv_ops
+    from d3feat_amd.kernels.kernel_points import create_kernel_points
+    from oracle import network_np as onp
+    if cin >= 256 and strided:
+        pytest.skip("covered by the non-strided case (same kernels)")
+    s0 = surface_cloud(cin + cout, n_raw=30000 if cin < 256 else 12000)
+    rng = np.random.default_rng(cin * 7 + cout)
+    lens = np.asarray([len(s0)], np.int32)
+    if strided:
+        q = coracle.grid_subsampling(s0, 0.06)
+        nb = coracle.batch_neighbors(q, s0, np.asarray([len(q)], np.int32), lens, np.float32(0.075))
+    else:
+        q = s0
+        nb = coracle.batch_neighbors(s0, s0, lens, lens, np.float32(0.075))
+    nb = nb[:, :37]
+    f = rng.standard_normal((len(s0), cin)).astype(np.float32)
+    if cin == 1:
+        f = np.ones_like(f)
+    W = (rng.standard_normal((15, cin, cout)) * np.sqrt(2.0 / cout)).astype(np.float32)
+    KP = create_kernel_points(1.5 * 0.03, 15, 1, 3, 'center', rng=np.random.default_rng(1)).reshape(15, 3).astype(np.float32)
+    want = onp.KPConv_ops(q, s0, nb, f, KP, W, 0.03, 'linear', 'sum').numpy()
+    got = conv_ops.KPConv_ops(_t(q, device), _t(s0, device), _t(nb.astype(np.int32), device), _t(f, device), KP,
+                              _t(W, device), 0.03, 'linear', 'sum').cpu().numpy()
+    _close(got, want)
+
+
+@pytest.mark.parametrize("influence,mode", [("constant", "sum"), ("gaussian", "sum"), ("linear", "closest")])
+def test_kpconv_modes(device, coracle, influence, mode):
+    from d3feat_amd.kernels import convolution_ops as conv_ops
+    from d3feat_amd.kernels.kernel_points import create_kernel_points
+    from oracle import network_np as onp
+    s0 = surface_cloud(9, n_raw=15000)
+    rng = np.random.default_rng(3)
+    lens = np.asarray([len(s0)], np.int32)
+    nb = coracle.batch_neighbors(s0, s0, lens, lens, np.float32(0.075))[:, :30]
+    f = rng.standard_normal((len(s0), 16)).astype(np.float32)
+    W = (rng.standard_normal((15, 16, 8)) * 0.3).astype(np.float32)
+    KP = create_kernel_points(0.045, 15, 1, 3, 'center', rng=np.random.default_rng(1)).reshape(15, 3).astype(np.float32)
+    want = onp.KPConv_ops(s0, s0, nb, f, KP, W, 0.03, influence, mode).numpy()
+    got = conv_ops.KPConv_ops(_t(s0, device), _t(s0, device), _t(nb.astype(np.int32), device), _t(f, device), KP,
+                              _t(W, device), 0.03, influence, mode).cpu().numpy()
+    _close(got, want)
+
+
+def test_pools_vs_oracle(device, coracle):
+    from d3feat_amd import ops
+    from oracle import network_np as onp
+    s0 = surface_cloud(11, n_raw=20000)
+    sub = coracle.grid_subsampling(s0, 0.06)
+    l0, l1 = np.asarray([len(s0)], np.int32), np.asarray([len(sub)], np.int32)
+    pool_i = coracle.batch_neighbors(sub, s0, l1, l0, np.float32(0.05))[:, :20]    # small radius -> some all-shadow rows
+    up_i = coracle.batch_neighbors(s0, sub, l0, l1, np.float32(0.07))[:, :20]
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((len(s0), 128)).astype(np.float32)
+    y = rng.standard_normal((len(sub), 256)).astype(np.float32)
+    want = onp.ind_max_pool(torch.from_numpy(x), pool_i).numpy()
+    got = ops.ind_max_pool(_t(x, device), _t(pool_i.astype(np.int32), device)).cpu().numpy()
+    assert np.array_equal(got, want)
+    want = torch.cat([onp.closest_pool(torch.from_numpy(y), up_i), torch.from_numpy(x)], 1).numpy()
+    got = ops.closest_pool_cat(_t(y, device), _t(up_i.astype(np.int32), device), _t(x, device)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("lens", [(0.5, 0.5), (0.7, 0.3)])
+def test_detection_head_vs_oracle(device, coracle, lens):
+    from d3feat_amd import ops
+    from d3feat_amd.models.D3Feat import detection_head
+    from oracle import network_np as onp
+    s0 = surface_cloud(13, n_raw=20000)
+    n = len(s0)
+    n0 = int(n * lens[0])
+    L = np.asarray([n0, n - n0], np.int32)
+    nb = coracle.batch_neighbors(s0, s0, L, L, np.float32(0.075))[:, :35]
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((n, 32)) * 2).astype(np.float32)
+    in_b = onp.stack_batch_inds(L)
+    want_s = onp.detection_head(torch.from_numpy(x), nb, in_b, L).numpy()
+    xt = torch.from_numpy(x)
+    want_d = (xt * torch.rsqrt(torch.clamp((xt ** 2).sum(1, keepdim=True), min=1e-10))).numpy()
+    inputs = dict(neighbors=[_t(nb.astype(np.int32), device)], stack_lengths=_t(L, device))
+    desc, score = detection_head(_t(x, device), inputs)
+    _close(desc.cpu().numpy(), want_d, 1e-5)
+    _close(score.cpu().numpy(), want_s)
+
+
+def _pair_inputs(coracle, cfg, cloud, limits):
+    from oracle import network_np as onp
+    pts = np.concatenate([cloud, cloud])
+    lens = np.asarray([len(cloud)] * 2, np.int32)
+    return onp.descriptor_input(cfg, pts, np.ones((len(pts), 1), np.float32), lens, limits,
+                                lambda q, s, ql, sl, r: coracle.batch_neighbors(q, s, ql, sl, r),
+                                lambda p, l, dl: coracle.batch_grid_subsampling(p, l, dl))
+
+
+def test_pyramid_vs_oracle(device, coracle):
+    """tf_descriptor_input on the GPU == the oracle pyramid, matrix by matrix, bit for bit (exact shapes);
+    the fast (padded) variant equals it on the valid columns and holds the shadow index elsewhere."""
+    from d3feat_amd.datasets.common import FragmentDataset
+    from d3feat_amd.utils.config import threedmatch_config
+    cfg = threedmatch_config()
+    cloud = surface_cloud(21, n_raw=60000)
+    limits = np.asarray([37, 35, 36, 38, 38], np.int32)
+    want = _pair_inputs(coracle, cfg, cloud, limits)
+    for fast in (False, True):
+        ds = FragmentDataset([cloud], fast=fast)
+        ds.neighborhood_limits = limits
+        gen, _, _ = ds.get_batch_gen('test', cfg)
+        flat = ds.get_tf_mapping(cfg)(*ds._to_device(next(iter(gen()))))
+        L = cfg.num_layers
+        for l in range(L):
+            assert np.array_equal(flat[l].cpu().numpy().view(np.uint32), want['points'][l].view(np.uint32))
+            for name, off in (('neighbors', L), ('pools', 2 * L), ('upsamples', 3 * L)):
+                g, w = flat[off + l].cpu().numpy(), want[name][l]
+                if w.shape[0] == 0:
+                    assert g.shape[0] == 0
+                    continue
+                if not fast:
+                    assert np.array_equal(g, w), (name, l)
+                elif name == 'upsamples':
+                    assert np.array_equal(g[:, 0], w[:, 0])
+                else:
+                    pad = want['points'][l].shape[0]     # shadow index = number of supports (the layer's points)
+                    assert g.shape[1] == limits[l]
+                    assert np.array_equal(g[:, :w.shape[1]], w), (name, l)
+                    assert np.all(g[:, w.shape[1]:] == pad)
+        assert np.array_equal(flat[4 * L + 2].cpu().numpy(), want['in_batches'])
+        assert np.array_equal(flat[4 * L + 3].cpu().numpy(), want['out_batches'])
+
+
+def test_calibrate_neighbors_vs_oracle(device, coracle):
+    from d3feat_amd.datasets.common import FragmentDataset
+    from d3feat_amd.utils.config import threedmatch_config
+    from oracle import network_np as onp
+    cfg = threedmatch_config()
+    clouds = [surface_cloud(31, n_raw=60000), surface_cloud(32, n_raw=50000)]
+    ds = FragmentDataset(clouds)
+    hist_n = onp.hist_size(cfg)
+    ds.neighborhood_limits = np.full(cfg.num_layers, hist_n, np.int32)
+    ds.calibrate_neighbors(cfg, samples_threshold=10 ** 9)
+    hists = np.zeros((cfg.num_layers, hist_n), np.int64)
+    for c in clouds:
+        inp = _pair_inputs(coracle, cfg, c, np.full(cfg.num_layers, hist_n, np.int32))
+        hists += onp.neighbor_histograms(inp['neighbors'], hist_n)
+    assert np.array_equal(ds.neighborhood_limits, onp.limits_from_histograms(hists))
+
+
+def test_full_forward_vs_oracle(device, coracle):
+    """Whole KPFCNN forward (pyramid from the oracle so that only the network is under test, then end to end)."""
+    from d3feat_amd.datasets.common import FragmentDataset
+    from d3feat_amd.models.KPFCNN_model import KernelPointFCNN
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    from oracle import network_np as onp
+    cfg = threedmatch_config()
+    cloud = surface_cloud(41, n_raw=50000)
+    limits = np.asarray([37, 35, 36, 38, 38], np.int32)
+    W = build_variables(cfg, seed=42, randomize_bn=True).values
+    inp = _pair_inputs(coracle, cfg, cloud, limits)
+    want_d, want_s = onp.forward(cfg, W, inp)
+    ds = FragmentDataset([cloud], fast=True)
+    ds.neighborhood_limits = limits
+    gen, _, _ = ds.get_batch_gen('test', cfg)
+    flat = ds.get_tf_mapping(cfg)(*ds._to_device(next(iter(gen()))))
+    model = KernelPointFCNN(flat, cfg, weights=W)
+    d, s = model.out_features.cpu().numpy(), model.out_scores.cpu().numpy()
+    assert d.shape == want_d.shape == (2 * len(cloud), 32) and s.shape == want_s.shape
+    assert np.isfinite(d).all() and np.isfinite(s).all()
+    _close(d, want_d)
+    _close(s, want_s)
+    # exact-shape inputs give the same result as the padded fast path
+    ds2 = FragmentDataset([cloud], fast=False)
+    ds2.neighborhood_limits = limits
+    flat2 = ds2.get_tf_mapping(cfg)(*ds2._to_device(next(iter(gen()))))
+    m2 = KernelPointFCNN(flat2, cfg, weights=W)
+    assert torch.equal(m2.out_features, model.out_features) and torch.equal(m2.out_scores, model.out_scores)
