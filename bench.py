@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""D3Feat hot-path benchmark (BASELINE.json: fragments/sec on 30k-pt clouds + ms/KPConv-layer).
+
+One "step" = one synthetic 3DMatch-shaped fragment end to end on the GPU, exactly the work the reference does per
+sess.run plus the stage-0 voxelisation:
+    raw cloud (300k pts, resident in HBM) -> grid subsample @0.03 m (~30k pts) -> stacked with itself (the
+    reference's test generators feed every fragment as a self-pair, datasets/ThreeDMatch.py:190-192) ->
+    5-level pyramid (13 radius searches + 4 grid subsamplings) -> KPFCNN forward (10 KPConv + 28 unary) ->
+    32-d descriptors + detection scores in HBM.
+Multi-GPU: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...; fragments are sharded across
+ranks (weak scaling: K fragments per rank) and the last fragment's (xyz, desc, score) of every rank is
+all-gathered over RCCL once at the end of the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      the dominant kernel (largest share of GPU time among the timed launches), HIP-event timed on the
+                launch stream in a separate instrumented pass over the same fragments;
+  kpconv_layers ms per KPConv layer (aggregation + contraction kernels);
+  cpu_baseline  the same step on the host: reference C++ (oracle/_ref, 1 thread) when available, else the C
+                restatement, for the geometry; torch-CPU restatement of the TF graph for the network (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-fragments", type=int, default=2)
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
+    return ap.parse_args()
+
+
+class Step:
+    """The hot path for one fragment."""
+
+    def __init__(self, cfg, model, limits, device):
+        from d3feat_amd.datasets.common import FragmentDataset
+        self.cfg, self.model, self.device = cfg, model, device
+        self.ds = FragmentDataset([], fast=True)
+        self.ds.neighborhood_limits = limits
+        self.map = self.ds.get_tf_mapping(cfg)
+
+    def __call__(self, raw_dev):
+        import torch
+        from d3feat_amd import tf_custom_ops as tfo
+        sub = tfo.grid_subsampling(raw_dev, self.cfg.first_subsampling_dl)          # stage 0
+        n = sub.shape[0]
+        pts = torch.cat([sub, sub], 0)                                               # self-pair (device copy)
+        lens = torch.tensor([n, n], dtype=torch.int32, device=self.device)
+        flat = self.map(pts, None, None, None, lens, ("a", "a"), pts)
+        desc, score = self.model.run(flat)
+        return pts, desc, score
+
+
+def kpconv_alg_bytes(Nq, Ns, K, Cin, Cout):
+    """algorithmic bytes of one KPConv layer."""
+    return 4 * (3 * Nq + 3 * Ns + Nq * K + Ns * Cin + 45 + 15 * Cin * Cout + Nq * Cout)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from d3feat_amd import ops, parallel
+    from d3feat_amd.datasets.common import FragmentDataset
+    from d3feat_amd.models.KPFCNN_model import KernelPointFCNN
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    from d3feat_amd.utils.synthetic import room_fragment
+    from d3feat_amd import tf_custom_ops as tfo
+
+    cfg = threedmatch_config()
+    W = build_variables(cfg, seed=42).values
+    # synthetic fragments of this rank, raw points resident in HBM before timing starts
+    seeds = [rank * 1000 + i for i in range(args.pool)]
+    raws_host = [room_fragment(s) for s in seeds]
+    raws = [torch.from_numpy(r).to(device) for r in raws_host]
+
+    # neighbourhood limits: calibrated like init_test_input_pipeline on this rank's pool, histograms summed over ranks
+    subs = [tfo.grid_subsampling(r, cfg.first_subsampling_dl).cpu().numpy() for r in raws]
+    cal = FragmentDataset(subs)
+    hist_n = int(np.ceil(4 / 3 * np.pi * (cfg.density_parameter + 1) ** 3))
+    cal.neighborhood_limits = np.full(cfg.num_layers, hist_n, np.int32)
+    hists = cal.calibrate_neighbors(cfg, samples_threshold=10 ** 9)
+    hists = parallel.allreduce_histograms(hists, device)
+    cumsum = np.cumsum(hists.T, axis=0)
+    limits = np.sum(cumsum < (0.8 * cumsum[hist_n - 1, :]), axis=0).astype(np.int32)
+
+    model = KernelPointFCNN(None, cfg, weights=W, device=device)
+    step = Step(cfg, model, limits, device)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    out = None
+    for i in range(args.warmup):
+        out = step(raws[i % len(raws)])
+    if world > 1:
+        parallel.gather_descriptors(*out) if out is not None else None
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(raws[i % len(raws)])
+    gathered = parallel.gather_descriptors(*out)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    npts = int(out[0].shape[0] // 2)
+
+    # ---- instrumented pass (untimed): per-launch HIP events for the KPConv kernels -----------------------------
+    layers, roof = None, None
+    if rank == 0:
+        ops.PROFILE = []
+        for i in range(max(3, min(args.steps, 8))):
+            step(raws[i % len(raws)])
+        torch.cuda.synchronize(device)
+        recs, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for name, info, s, e in recs:
+            key = (name, tuple(sorted(info.items())))
+            a = agg.setdefault(key, [0.0, 0])
+            a[0] += s.elapsed_time(e)
+            a[1] += 1
+        per = {k: v[0] / v[1] for k, v in agg.items()}
+        # kernel totals by kernel name (all shapes): share of time + launches per step
+        nsteps = max(3, min(args.steps, 8))
+        tot = {}
+        for (name, info), ms in per.items():
+            d = dict(info)
+            fam = name + ("<Cin=%d>" % d["Cin"] if name == "kpconv_aggregate" else "")
+            t = tot.setdefault(fam, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+            cnt = agg[(name, info)][1] / nsteps
+            t["ms"] += ms * cnt
+            t["launches"] += cnt
+            if name == "kpconv_aggregate":
+                t["bytes"] += cnt * kpconv_alg_bytes(d["Nq"], d["Ns"], d["K"], d["Cin"], d["Cin"] if d["Cin"] > 1 else 64)
+            else:
+                t["flops"] += cnt * 2.0 * d["M"] * d["N"] * d["K"]
+                t["bytes"] += cnt * 4.0 * (d["M"] * d["K"] + d["K"] * d["N"] + d["M"] * d["N"])
+        agg_fams = {k: v for k, v in tot.items() if k.startswith("kpconv_aggregate")}
+        dom_name = max(tot, key=lambda k: tot[k]["ms"])
+        dom = tot[dom_name]
+        avg_ms = dom["ms"] / dom["launches"]
+        if dom_name.startswith("kpconv_aggregate"):
+            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            roof = dict(kernel="kpconv_agg_vec4/scalar " + dom_name, bound="hbm", achieved=round(ach, 2),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                        avg_launch_us=round(avg_ms * 1e3, 2), launches_per_step=dom["launches"],
+                        alg_bytes_per_launch=int(dom["bytes"] / dom["launches"]))
+        else:
+            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+            roof = dict(kernel="gemm_f32_kernel (all shapes of one step)", bound="mfma", achieved=round(ach, 3),
+                        peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 5), traffic=None,
+                        avg_launch_us=round(avg_ms * 1e3, 2), launches_per_step=dom["launches"],
+                        alg_flops_per_launch=int(dom["flops"] / dom["launches"]))
+        roof["time_share_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(tot.items())}
+        tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get(roof["kernel"].split()[0])
+            except Exception:
+                pass
+        # ms per KPConv layer: aggregation + its contraction (the gemm whose K = 15*Cin and M = Nq)
+        layers = []
+        for (name, info), ms in sorted(per.items(), key=lambda kv: -dict(kv[0][1]).get("Nq", 0)):
+            if name != "kpconv_aggregate":
+                continue
+            d = dict(info)
+            g = [m for (n2, i2), m in per.items() if n2 == "gemm_f32" and dict(i2)["M"] == d["Nq"] and dict(i2)["K"] == 15 * d["Cin"]]
+            layers.append(dict(Nq=d["Nq"], Ns=d["Ns"], K=d["K"], Cin=d["Cin"], agg_ms=round(ms, 4),
+                               gemm_ms=round(min(g), 4) if g else None))
+
+    # ---- CPU baseline (rank 0, N=1) -------------------------------------------------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, W, limits, raws_host[: max(1, args.cpu_fragments)])
+
+    if rank == 0:
+        res = {
+            "metric": "fragments/sec (30k-pt clouds)", "value": round(world * args.steps / dt, 3), "unit": "fragments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SURVEY §8d config #2: synthetic 3DMatch room fragment, 300k raw pts -> grid subsample "
+                                   "0.03 m (~%dk pts) -> self-pair -> 5-level pyramid -> full KPFCNN forward (random-init "
+                                   "weights, 14.1M params) -> 32-d descriptors + scores" % round(npts / 1000),
+                       "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
+                       "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
+                       "final_gather_ranks": len(gathered)},
+            "roofline": roof, "kpconv_layers_ms": layers, "cpu_baseline": cpu,
+        }
+        if cpu:
+            res["vs_cpu_baseline"] = round(res["value"] / cpu["value"], 2)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, W, limits, raws_host):
+    """The same step on the host cores of this box (reported baseline, not the target)."""
+    import torch
+    from oracle import clib, network_np as onp
+    use_ref = clib.ref_available()
+    co = clib.COracle()
+    rl = clib.RefLib() if use_ref else None
+    nthreads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(nthreads)
+
+    def nbr(q, s, ql, sl, r):
+        return rl.batch_nanoflann_neighbors(q, s, ql, sl, r) if use_ref else co.batch_neighbors(q, s, ql, sl, r)
+
+    def sub(p, l, dl):
+        return rl.batch_grid_subsampling(p, l, dl) if use_ref else co.batch_grid_subsampling(p, l, dl)
+
+    def one(raw):
+        t = [time.perf_counter()]
+        s0 = rl.grid_subsampling(raw, cfg.first_subsampling_dl) if use_ref else co.grid_subsampling(raw, cfg.first_subsampling_dl)
+        pts = np.concatenate([s0, s0])
+        lens = np.asarray([len(s0)] * 2, np.int32)
+        inp = onp.descriptor_input(cfg, pts, np.ones((len(pts), 1), np.float32), lens, limits, nbr, sub)
+        t.append(time.perf_counter())
+        onp.forward(cfg, W, inp)
+        t.append(time.perf_counter())
+        return t[1] - t[0], t[2] - t[1]
+
+    one(raws_host[0])  # warm-up (page-in, thread pools)
+    pre, net = [], []
+    for r in raws_host:
+        a, b = one(r)
+        pre.append(a)
+        net.append(b)
+    tot = float(np.sum(pre) + np.sum(net))
+    return {"value": round(len(raws_host) / tot, 4), "unit": "fragments/s", "cores": nthreads,
+            "kind": "reference" if use_ref else "port",
+            "sample": "%d fragment(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
+                      "thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads: %.3f s/fragment"
+                      % (len(raws_host), "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
+                         float(np.mean(pre)), nthreads, float(np.mean(net))),
+            "geometry_s": round(float(np.mean(pre)), 4), "network_s": round(float(np.mean(net)), 4)}
+
+
+if __name__ == "__main__":
+    main()

@@ -172,26 +172,30 @@ kpconv_agg_scalar(const float* __restrict__ q, int Nq, const float* __restrict__
     if (c == 0) inv_cnt[qg] = 1.0f / fmaxf((float)cnt, 1.0f);
 }
 
-extern "C" size_t d3f_kpconv_workspace_bytes(int Ns) { return d3f_align((size_t)(Ns > 0 ? Ns : 1)) + 256; }
+// ---- C ABI ---------------------------------------------------------------------------------------
+extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Ns < 0 || Cin < 1 || ldf < Cin) return D3F_ERR_ARG;
+    if (Ns == 0) return D3F_OK;
+    if (!f || !row_pos) return D3F_ERR_ARG;
+    kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, ldf, Cin, row_pos);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
 
 extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                                    const float* f, int ldf, int Cin, const float* kp_host, int num_kp, float KP_extent,
-                                    int influence, int aggregation, float* wf, float* inv_cnt,
-                                    void* workspace, size_t workspace_bytes, void* stream_) {
+                                    const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host,
+                                    int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
+                                    void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || Cin < 1 || ldf < Cin || num_kp < 1 || num_kp > KP_MAXP - 1 ||
         influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f))
         return D3F_ERR_ARG;
     if (Nq == 0) return D3F_OK;
-    if (!q || !s || !idx || !f || !kp_host || !wf || !inv_cnt) return D3F_ERR_ARG;
+    if (!q || !s || !idx || !f || !rowpos || !kp_host || !wf || !inv_cnt) return D3F_ERR_ARG;
     KpParams P;
     for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
     P.num_kp = num_kp; P.extent = KP_extent; P.influence = influence; P.aggregation = aggregation;
-    // per-support "row sum > 0" flags
-    D3fArena ar(workspace, workspace_bytes);
-    unsigned char* rowpos = ar.take<unsigned char>((size_t)(Ns > 0 ? Ns : 1));
-    if (!ar.ok) return D3F_ERR_WORKSPACE;
-    if (Ns > 0) kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, ldf, Cin, rowpos);
     const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0);
 #define D3F_AGG(LQ_)                                                                                          \
     kpconv_agg_vec4<LQ_><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, \

@@ -11,6 +11,29 @@ from . import _lib
 
 _WS = {}
 
+# Optional per-call HIP-event timing (bench.py): set PROFILE to a list to collect (name, info, start, end) records
+# for the kpconv_aggregate / gemm_f32 launches issued on the current stream.
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, name, info, device):
+        self.on = PROFILE is not None
+        self.name, self.info, self.device = name, info, device
+
+    def __enter__(self):
+        if self.on:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.end.record(torch.cuda.current_stream(self.device))
+            PROFILE.append((self.name, self.info, self.start, self.end))
+        return False
+
 
 def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
@@ -159,12 +182,13 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
                 raise ValueError("%s must be a contiguous vector of %d" % (name, n))
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, K)
     ws = workspace(nbytes, dev)
-    rc = lib.d3f_gemm_f32(A.data_ptr(), lda, Bm.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
-                          row_scale.data_ptr() if row_scale is not None else None,
-                          col_scale.data_ptr() if col_scale is not None else None,
-                          col_shift.data_ptr() if col_shift is not None else None,
-                          residual.data_ptr() if residual is not None else None, ldr,
-                          1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _stream(dev))
+    with _timed("gemm_f32", dict(M=M, N=N, K=K), dev):
+        rc = lib.d3f_gemm_f32(A.data_ptr(), lda, Bm.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+                              row_scale.data_ptr() if row_scale is not None else None,
+                              col_scale.data_ptr() if col_scale is not None else None,
+                              col_shift.data_ptr() if col_shift is not None else None,
+                              residual.data_ptr() if residual is not None else None, ldr,
+                              1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _stream(dev))
     _lib.check(rc, "gemm_f32")
     return out
 
@@ -191,11 +215,14 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
     dev = q.device
     wf = torch.empty((Nq, num_kp * Cin), dtype=torch.float32, device=dev)
     inv_cnt = torch.empty((Nq,), dtype=torch.float32, device=dev)
-    ws = workspace(lib.d3f_kpconv_workspace_bytes(Ns), dev)
-    rc = lib.d3f_kpconv_aggregate(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf, Cin,
-                                  kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
-                                  _AGGREGATION[aggregation_mode], wf.data_ptr(), inv_cnt.data_ptr(),
-                                  ws.data_ptr(), ws.numel(), _stream(dev))
+    row_pos = torch.empty((max(Ns, 1),), dtype=torch.uint8, device=dev)
+    st = _stream(dev)
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, Cin, row_pos.data_ptr(), st), "row_positive")
+    with _timed("kpconv_aggregate", dict(Nq=Nq, Ns=Ns, K=K, Cin=Cin), dev):
+        rc = lib.d3f_kpconv_aggregate(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
+                                      Cin, row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent),
+                                      _INFLUENCE[KP_influence], _AGGREGATION[aggregation_mode], wf.data_ptr(),
+                                      inv_cnt.data_ptr(), st)
     _lib.check(rc, "kpconv_aggregate")
     return wf, inv_cnt
 

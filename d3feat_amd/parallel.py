@@ -1,0 +1,73 @@
+"""Fragment-level data parallelism: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+The reference has no multi-GPU path; its unit of work -- one fragment = one sess.run
+(utils/tester.py:196-199) -- is independent of every other, so the path shards with NO data-path collective:
+  * `shard_fragments`     static partition of the fragment list (round-robin, or greedy by point count);
+  * `allreduce_histograms` start-up only: neighbour-count histograms are summed so that every rank derives the same
+                           neighborhood_limits as a single process would (datasets/common.py:629-670 is a pure sum);
+  * `gather_descriptors`  the only exchange, once at the end: variable-length all_gather of
+                           (xyz f32[N,3], desc f32[N,32], score f32[N,1]) = 144 B/point.  On a fully connected
+                           8-GPU xGMI node this is one small message per peer (latency bound), so a single padded
+                           all_gather is used rather than a ring of per-tensor collectives.
+Works unchanged with backend "gloo" on CPU tensors (tests/test_parallel_gloo.py, world_size 2).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_fragments(n_items, rank, world_size, sizes=None):
+    """Indices of the fragments this rank processes.  sizes=None: round-robin.  With per-fragment point counts:
+    greedy longest-processing-time assignment (deterministic, identical on every rank)."""
+    if sizes is None:
+        return list(range(rank, n_items, world_size))
+    order = sorted(range(n_items), key=lambda i: (-int(sizes[i]), i))
+    load = [0] * world_size
+    mine = []
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        load[r] += int(sizes[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def allreduce_histograms(hists, device=None):
+    """Sum int64 histograms [layers, bins] over ranks (no-op for a single process)."""
+    rank, ws = world()
+    if ws == 1:
+        return hists
+    t = torch.as_tensor(np.ascontiguousarray(hists), dtype=torch.int64)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def gather_descriptors(xyz, desc, score):
+    """All ranks receive every rank's (xyz, desc, score).  Inputs: f32[N,3], f32[N,C], f32[N,1] on this rank's
+    device (N may differ per rank).  Returns a list (one entry per rank) of (xyz, desc, score) tensors."""
+    rank, ws = world()
+    if ws == 1:
+        return [(xyz, desc, score)]
+    dev = xyz.device
+    C = desc.shape[1]
+    n = torch.tensor([xyz.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(sizes)
+    width = 3 + C + 1
+    payload = torch.zeros((nmax, width), dtype=torch.float32, device=dev)
+    payload[: xyz.shape[0], 0:3] = xyz
+    payload[: xyz.shape[0], 3:3 + C] = desc
+    payload[: xyz.shape[0], 3 + C:] = score.reshape(-1, 1)
+    out = [torch.empty_like(payload) for _ in range(ws)]
+    dist.all_gather(out, payload)
+    return [(o[:s, 0:3], o[:s, 3:3 + C], o[:s, 3 + C:]) for o, s in zip(out, sizes)]

@@ -8,7 +8,7 @@
 import numpy as np
 
 
-def room_fragment(seed=0, n_raw=300000, edge=1.62, jitter=0.002):
+def room_fragment(seed=0, n_raw=300000, edge=1.68, jitter=0.002):
     rng = np.random.Generator(np.random.PCG64(seed))
     ex, ey, ez = edge * (1.0 + 0.05 * rng.random()), edge * (1.0 + 0.05 * rng.random()), edge * 0.8
     n_box = int(n_raw * 0.88)

@@ -85,18 +85,20 @@ int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* suppor
  * KPConv, phase 1: neighbour gather + kernel-point influence + weighted aggregation.
  * Replaces the first half of kernels/convolution_ops.py:161-255 (KPConv_ops :186-240, :250-252):
  *   wf[n,p,c]  = sum_k  h(|| (s[idx[n,k]] - q[n]) - KP[p] ||) * f[idx[n,k], c]
- *   inv_cnt[n] = 1 / max(#{k : sum_c f[idx[n,k],c] > 0}, 1)
+ *   inv_cnt[n] = 1 / max(#{k : row_pos[idx[n,k]]}, 1),  row_pos from d3f_row_positive(f)
  * influence: 0 constant, 1 linear  h = max(1 - sqrt(d2+1e-10)/(2*KP_extent), 0), 2 gaussian (sigma = 0.3*KP_extent);
  * aggregation: 0 sum, 1 closest.  Shadow neighbours (idx >= Ns) contribute nothing.
  *   q f32[Nq,3]  s f32[Ns,3]  idx i32[Nq,ld_idx] (K columns used)  f f32[Ns,ldf] (Cin columns used)
  *   kp_host f32[num_kp,3] (HOST pointer: 45 floats passed by value to the kernel)  wf f32[Nq, num_kp*Cin]  inv_cnt f32[Nq]
  * Phase 2 is d3f_gemm_f32(wf, K_values reshaped [num_kp*Cin, Cout]) with row_scale = inv_cnt.
  * ------------------------------------------------------------------------------------------- */
-size_t d3f_kpconv_workspace_bytes(int Ns);
+/* row_pos[s] = (sum_c f[s,c] > 0): the per-support test behind the neighbour count (:250-251), evaluated once
+ * per support row.  row_pos u8[Ns]. */
+int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, void* stream);
 int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                         const float* f, int ldf, int Cin, const float* kp_host, int num_kp, float KP_extent,
-                         int influence, int aggregation, float* wf, float* inv_cnt,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         const float* f, int ldf, int Cin, const unsigned char* row_pos, const float* kp_host,
+                         int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
