@@ -58,10 +58,11 @@ class Step:
     def __call__(self, raw_dev):
         import torch
         from d3feat_amd import tf_custom_ops as tfo
+        from d3feat_amd.ops import as_lens as ops_as_lens
         sub = tfo.grid_subsampling(raw_dev, self.cfg.first_subsampling_dl)          # stage 0
         n = sub.shape[0]
         pts = torch.cat([sub, sub], 0)                                               # self-pair (device copy)
-        lens = torch.tensor([n, n], dtype=torch.int32, device=self.device)
+        lens = ops_as_lens([n, n], self.device)
         flat = self.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
         return pts, desc, score
@@ -140,68 +141,81 @@ def main():
     dt = float(tmax.item())
     npts = int(out[0].shape[0] // 2)
 
-    # ---- instrumented pass (untimed): per-launch HIP events for the KPConv kernels -----------------------------
+    # ---- instrumented pass (untimed): per-launch HIP events on the launch stream --------------------------------
     layers, roof = None, None
     if rank == 0:
+        nprof = max(3, min(args.steps, 8))
         ops.PROFILE = []
-        for i in range(max(3, min(args.steps, 8))):
+        for i in range(nprof):
+            ops.PROFILE.append(("step", {}, None, None))
             step(raws[i % len(raws)])
         torch.cuda.synchronize(device)
         recs, ops.PROFILE = ops.PROFILE, None
-        agg = {}
+        fam = {}      # kernel family -> totals over the instrumented pass
+        per_step_agg, per_step_gemm = [], []
         for name, info, s, e in recs:
-            key = (name, tuple(sorted(info.items())))
-            a = agg.setdefault(key, [0.0, 0])
-            a[0] += s.elapsed_time(e)
-            a[1] += 1
-        per = {k: v[0] / v[1] for k, v in agg.items()}
-        # kernel totals by kernel name (all shapes): share of time + launches per step
-        nsteps = max(3, min(args.steps, 8))
-        tot = {}
-        for (name, info), ms in per.items():
-            d = dict(info)
-            fam = name + ("<Cin=%d>" % d["Cin"] if name == "kpconv_aggregate" else "")
-            t = tot.setdefault(fam, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
-            cnt = agg[(name, info)][1] / nsteps
-            t["ms"] += ms * cnt
-            t["launches"] += cnt
+            if name == "step":
+                per_step_agg.append([])
+                per_step_gemm.append([])
+                continue
+            ms = s.elapsed_time(e)
             if name == "kpconv_aggregate":
-                t["bytes"] += cnt * kpconv_alg_bytes(d["Nq"], d["Ns"], d["K"], d["Cin"], d["Cin"] if d["Cin"] > 1 else 64)
-            else:
-                t["flops"] += cnt * 2.0 * d["M"] * d["N"] * d["K"]
-                t["bytes"] += cnt * 4.0 * (d["M"] * d["K"] + d["K"] * d["N"] + d["M"] * d["N"])
-        agg_fams = {k: v for k, v in tot.items() if k.startswith("kpconv_aggregate")}
-        dom_name = max(tot, key=lambda k: tot[k]["ms"])
-        dom = tot[dom_name]
+                key = "kpconv_agg_vec4<Cin=%d>" % info["Cin"] if info["Cin"] % 4 == 0 else "kpconv_agg_scalar<Cin=%d>" % info["Cin"]
+                # every KPConv of the shipped architecture has Cout == Cin except the first (1 -> 64)
+                cout = info["Cin"] if info["Cin"] > 1 else cfg.first_features_dim
+                nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], info["Cin"], cout), 0.0
+                per_step_agg[-1].append((info, ms))
+            elif name == "gemm_f32":
+                key = "gemm_f32_kernel"
+                nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
+                flops = 2.0 * info["M"] * info["N"] * info["K"]
+                per_step_gemm[-1].append((info, ms))
+            else:  # nb_search: SURVEY §8(d) bytes_alg = 12*(Nq+Ns) + 4*Nq*K_out
+                key = "nb_search_kernel<first_only=%d>" % info["first_only"]
+                nbytes, flops = 12.0 * (info["Nq"] + info["Ns"]) + 4.0 * info["Nq"] * (1 if info["first_only"] else info["width"]), 0.0
+            f = fam.setdefault(key, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+            f["ms"] += ms
+            f["launches"] += 1
+            f["bytes"] += nbytes
+            f["flops"] += flops
+        dom_name = max(fam, key=lambda k: fam[k]["ms"])
+        dom = fam[dom_name]
         avg_ms = dom["ms"] / dom["launches"]
-        if dom_name.startswith("kpconv_aggregate"):
-            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            roof = dict(kernel="kpconv_agg_vec4/scalar " + dom_name, bound="hbm", achieved=round(ach, 2),
-                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                        avg_launch_us=round(avg_ms * 1e3, 2), launches_per_step=dom["launches"],
-                        alg_bytes_per_launch=int(dom["bytes"] / dom["launches"]))
-        else:
+        if dom_name.startswith("gemm"):
             ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            roof = dict(kernel="gemm_f32_kernel (all shapes of one step)", bound="mfma", achieved=round(ach, 3),
-                        peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 5), traffic=None,
-                        avg_launch_us=round(avg_ms * 1e3, 2), launches_per_step=dom["launches"],
+            roof = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=round(ach / MFMA_F32_PEAK_TF, 5), traffic=None,
                         alg_flops_per_launch=int(dom["flops"] / dom["launches"]))
-        roof["time_share_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(tot.items())}
+        else:
+            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            roof = dict(kernel=dom_name, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                        alg_bytes_per_launch=int(dom["bytes"] / dom["launches"]))
+        roof["avg_launch_us"] = round(avg_ms * 1e3, 2)
+        roof["launches_per_step"] = round(dom["launches"] / nprof, 2)
+        roof["timed_kernels_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in sorted(fam.items())}
         tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tr):
             try:
-                roof["traffic"] = json.load(open(tr)).get(roof["kernel"].split()[0])
+                roof["traffic"] = json.load(open(tr)).get(dom_name.split("<")[0])
             except Exception:
                 pass
-        # ms per KPConv layer: aggregation + its contraction (the gemm whose K = 15*Cin and M = Nq)
+        # ms per KPConv layer (call order inside a step = network order): aggregation + its contraction
+        nl = len(per_step_agg[0])
         layers = []
-        for (name, info), ms in sorted(per.items(), key=lambda kv: -dict(kv[0][1]).get("Nq", 0)):
-            if name != "kpconv_aggregate":
-                continue
-            d = dict(info)
-            g = [m for (n2, i2), m in per.items() if n2 == "gemm_f32" and dict(i2)["M"] == d["Nq"] and dict(i2)["K"] == 15 * d["Cin"]]
-            layers.append(dict(Nq=d["Nq"], Ns=d["Ns"], K=d["K"], Cin=d["Cin"], agg_ms=round(ms, 4),
-                               gemm_ms=round(min(g), 4) if g else None))
+        for li in range(nl):
+            infos = [st[li][0] for st in per_step_agg]
+            agg_ms = float(np.mean([st[li][1] for st in per_step_agg]))
+            gem = []
+            for st_a, st_g in zip(per_step_agg, per_step_gemm):
+                d = st_a[li][0]
+                cand = [m for (g, m) in st_g if g["M"] == d["Nq"] and g["K"] == cfg.num_kernel_points * d["Cin"]]
+                if cand:
+                    gem.append(cand[0] if len(cand) == 1 or li % 2 == 0 or True else cand[-1])
+            layers.append(dict(layer=li, Nq=int(np.mean([d["Nq"] for d in infos])), Ns=int(np.mean([d["Ns"] for d in infos])),
+                               K=infos[0]["K"], Cin=infos[0]["Cin"], agg_ms=round(agg_ms, 4),
+                               gemm_ms=round(float(np.mean(gem)), 4) if gem else None,
+                               total_ms=round(agg_ms + (float(np.mean(gem)) if gem else 0.0), 4)))
 
     # ---- CPU baseline (rank 0, N=1) -------------------------------------------------------------------------------
     cpu = None

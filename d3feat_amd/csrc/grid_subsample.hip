@@ -173,50 +173,82 @@ __device__ __forceinline__ int gs_ld(const int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void __launch_bounds__(1024) gs_order_kernel(const unsigned long long* __restrict__ vkey,
-                                                        const int* __restrict__ moffs, const int* __restrict__ offs,
-                                                        const GsElem* __restrict__ el, int* L0, int* L1, int* nx,
-                                                        int* cd, int* bf, int* bc, int* bh, int* __restrict__ vpos) {
+// key % nb for key < 2^56, nb < 2^31 without the 64-bit software division: double-precision quotient estimate
+// (off by at most 1 or 2) and a branch-free correction.
+__device__ __forceinline__ int gs_mod(unsigned long long key, unsigned nb, double inv_nb) {
+    const unsigned long long q = (unsigned long long)((double)key * inv_nb);
+    long long r = (long long)(key - q * (unsigned long long)nb);
+    r += (r < 0) ? (long long)nb : 0;
+    r += (r < 0) ? (long long)nb : 0;
+    r -= (r >= (long long)nb) ? (long long)nb : 0;
+    r -= (r >= (long long)nb) ? (long long)nb : 0;
+    return (int)r;
+}
+
+// Round j reads the insertion sequence from list buffer P[j&1] and writes the new list order to P[(j+1)&1]; its
+// bucket arrays are the parity-(j&1) set.  Rounds 0..GS_SMALL_LAST (bucket counts 13..1109) are tiny and run inside
+// ONE single-workgroup launch (gs_order_small_kernel); a single CU however sustains only ~1 divergent L2 access per
+// clock, so the large rounds (the last 2-5 for 10^4..10^5 voxels) are spread over the whole chip as four small
+// grid-wide launches each (insert / tile scan / tile-sum scan / place).
+#define GS_SMALL_LAST 6
+#define GS_TILE 1024
+
+struct GsOrderArgs {
+    const unsigned long long* vkey;
+    const int* moffs;
+    const int* offs;
+    const GsElem* el;
+    int* P[2];      // list buffers, element b at + offs[b]
+    int* nx;        // chain links, per position
+    int* cd;        // reverse-scan values, per position
+    int* bkt;       // bucket of the element at a position
+    int* bf[2];     // per bucket: first insertion position   (parity sets, element b at + el[b].bbase)
+    int* bc[2];     // per bucket: size
+    int* bh[2];     // per bucket: chain head (last insertion)
+    int* tsum;      // tile sums of the reverse scan, element b at + offs[b]/GS_TILE + b
+    int* vpos;      // OUT: final position of each voxel inside its element
+};
+
+__global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A) {
     __shared__ int wsum[16];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int M = moffs[b + 1] - moffs[b];
+    const int M = A.moffs[b + 1] - A.moffs[b];
     if (M <= 0) return;
-    const unsigned long long* key = vkey + moffs[b];
-    int* La = L0 + offs[b];
-    int* Lb = L1 + offs[b];
-    int* NXT = nx + offs[b];
-    int* CD = cd + offs[b];
-    int* BF = bf + el[b].bbase;
-    int* BC = bc + el[b].bbase;
-    int* BH = bh + el[b].bbase;
-    int* VP = vpos + moffs[b];
+    const unsigned long long* key = A.vkey + A.moffs[b];
+    int* NXT = A.nx + A.offs[b];
+    int* CD = A.cd + A.offs[b];
+    int* VP = A.vpos + A.moffs[b];
+    const long long bbase = A.el[b].bbase;
     int lo = 0;
-    for (int j = 0; j < D3F_NCHAIN; ++j) {
-        const unsigned long long nbl = D3F_CHAIN_DEV[j];  // bucket count of this round (N <= 2^30 keeps it < 2^31)
-        const int nb = (int)nbl;
+    bool done = false;
+    for (int j = 0; j <= GS_SMALL_LAST; ++j) {
+        const int nb = (int)D3F_CHAIN_DEV[j];
+        const double inv_nb = 1.0 / (double)nb;
         const bool last = M <= nb;
-        const int hi = last ? M : nb;  // elements in the table at the end of this round
+        const int hi = last ? M : nb;
+        int* La = A.P[j & 1] + A.offs[b];
+        int* Lb = A.P[(j + 1) & 1] + A.offs[b];
+        int* BF = A.bf[j & 1] + bbase;
+        int* BC = A.bc[j & 1] + bbase;
+        int* BH = A.bh[j & 1] + bbase;
         for (int t = tid; t < nb; t += 1024) { BF[t] = 0x7fffffff; BC[t] = 0; BH[t] = -1; }
         __syncthreads();
-        // insertion sequence of this round: the previous round's list order (rehash), then the new keys
         for (int t = tid; t < hi; t += 1024) {
             const int id = (t < lo) ? gs_ld(&La[t]) : t;
-            const int bk = (int)(key[id] % nbl);
+            const int bk = gs_mod(key[id], (unsigned)nb, inv_nb);
             atomicMin(&BF[bk], t);
             atomicAdd(&BC[bk], 1);
             NXT[t] = atomicExch(&BH[bk], t);
+            A.bkt[A.offs[b] + t] = bk;
         }
         __syncthreads();
-        // CD[t] = sum over t' > t of c[t'],  c[t] = (t is the first insertion of its bucket) ? bucket size : 0
         int carry = 0;
         for (int c0 = 0; c0 < hi; c0 += 1024) {
-            const int u = c0 + tid;
-            const int t = hi - 1 - u;
+            const int u = c0 + tid, t = hi - 1 - u;
             int c = 0;
             if (u < hi) {
-                const int id = (t < lo) ? gs_ld(&La[t]) : t;
-                const int bk = (int)(key[id] % nbl);
+                const int bk = gs_ld(&A.bkt[A.offs[b] + t]);
                 c = (gs_ld(&BF[bk]) == t) ? gs_ld(&BC[bk]) : 0;
             }
             int x = c;
@@ -227,22 +259,21 @@ __global__ void __launch_bounds__(1024) gs_order_kernel(const unsigned long long
             }
             if (lane == 63) wsum[w] = x;
             __syncthreads();
-            int base = 0, tot = 0;
+            int wbase = 0, tot = 0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                int s = wsum[q];
-                if (q < w) base += s;
-                tot += s;
+                int v = wsum[q];
+                if (q < w) wbase += v;
+                tot += v;
             }
             __syncthreads();
-            if (u < hi) CD[t] = carry + base + x - c;
+            if (u < hi) CD[t] = carry + wbase + x - c;
             carry += tot;
         }
         __syncthreads();
-        // list position = (elements of buckets first-inserted later) + (later insertions into the same bucket)
         for (int t = tid; t < hi; t += 1024) {
             const int id = (t < lo) ? gs_ld(&La[t]) : t;
-            const int bk = (int)(key[id] % nbl);
+            const int bk = gs_ld(&A.bkt[A.offs[b] + t]);
             int r = 0;
             for (int q = gs_ld(&BH[bk]); q >= 0; q = gs_ld(&NXT[q])) r += (q > t) ? 1 : 0;
             const int dest = gs_ld(&CD[gs_ld(&BF[bk])]) + r;
@@ -250,9 +281,157 @@ __global__ void __launch_bounds__(1024) gs_order_kernel(const unsigned long long
             if (last) VP[id] = dest;
         }
         __syncthreads();
-        if (last) break;
-        int* tmp = La; La = Lb; Lb = tmp;
+        if (last) { done = true; break; }
         lo = hi;
+    }
+    if (!done) {
+        // prepare the bucket arrays of the first grid-wide round
+        const int j = GS_SMALL_LAST + 1;
+        const int nb = (int)D3F_CHAIN_DEV[j];
+        int* BF = A.bf[j & 1] + bbase;
+        int* BC = A.bc[j & 1] + bbase;
+        int* BH = A.bh[j & 1] + bbase;
+        for (int t = tid; t < nb; t += 1024) { BF[t] = 0x7fffffff; BC[t] = 0; BH[t] = -1; }
+    }
+}
+
+// geometry of grid-wide round j for element b; false when the element finished in an earlier round
+__device__ __forceinline__ bool gs_round(const GsOrderArgs& A, int b, int j, int& M, int& lo, int& hi, int& nb, bool& last) {
+    M = A.moffs[b + 1] - A.moffs[b];
+    lo = (int)D3F_CHAIN_DEV[j - 1];
+    if (M <= lo) return false;
+    nb = (int)D3F_CHAIN_DEV[j];
+    last = M <= nb;
+    hi = last ? M : nb;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) gs_order_insert_kernel(GsOrderArgs A, int j) {
+    const int b = blockIdx.y;
+    int M, lo, hi, nb;
+    bool last;
+    if (!gs_round(A, b, j, M, lo, hi, nb, last)) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= hi) return;
+    const int o = A.offs[b];
+    const long long bbase = A.el[b].bbase;
+    const int id = (t < lo) ? A.P[j & 1][o + t] : t;
+    const int bk = gs_mod(A.vkey[A.moffs[b] + id], (unsigned)nb, 1.0 / (double)nb);
+    atomicMin(&A.bf[j & 1][bbase + bk], t);
+    atomicAdd(&A.bc[j & 1][bbase + bk], 1);
+    A.nx[o + t] = atomicExch(&A.bh[j & 1][bbase + bk], t);
+    A.bkt[o + t] = bk;
+}
+
+// tile-local reverse exclusive scan of c[t] = (t first of its bucket) ? bucket size : 0, over u = hi-1-t
+__global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A, int j) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y;
+    int M, lo, hi, nb;
+    bool last;
+    if (!gs_round(A, b, j, M, lo, hi, nb, last)) return;
+    const int tile = blockIdx.x;
+    if (tile * GS_TILE >= hi) return;
+    const int o = A.offs[b];
+    const long long bbase = A.el[b].bbase;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int c[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = tile * GS_TILE + tid * 4 + k, t = hi - 1 - u;
+        c[k] = 0;
+        if (u < hi) {
+            const int bk = A.bkt[o + t];
+            c[k] = (A.bf[j & 1][bbase + bk] == t) ? A.bc[j & 1][bbase + bk] : 0;
+        }
+        s += c[k];
+    }
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int v = wsum[q];
+        if (q < w) wbase += v;
+        tot += v;
+    }
+    int run = wbase + x - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = tile * GS_TILE + tid * 4 + k;
+        if (u < hi) A.cd[o + hi - 1 - u] = run;
+        run += c[k];
+    }
+    if (tid == 0) A.tsum[o / GS_TILE + b + tile] = tot;
+}
+
+__global__ void __launch_bounds__(256) gs_order_scan_sums_kernel(GsOrderArgs A, int j) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.x;
+    int M, lo, hi, nb;
+    bool last;
+    if (!gs_round(A, b, j, M, lo, hi, nb, last)) return;
+    int* ts = A.tsum + A.offs[b] / GS_TILE + b;
+    const int ntiles = (hi + GS_TILE - 1) / GS_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int carry = 0;
+    for (int c0 = 0; c0 < ntiles; c0 += 256) {
+        const int i = c0 + tid;
+        const int v = (i < ntiles) ? ts[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int s = wsum[q];
+            if (q < w) wbase += s;
+            tot += s;
+        }
+        __syncthreads();
+        if (i < ntiles) ts[i] = carry + wbase + x - v;
+        carry += tot;
+    }
+}
+
+__global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int j) {
+    const int b = blockIdx.y;
+    int M, lo, hi, nb;
+    bool last;
+    if (!gs_round(A, b, j, M, lo, hi, nb, last)) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int o = A.offs[b];
+    const long long bbase = A.el[b].bbase;
+    if (t < hi) {
+        const int id = (t < lo) ? A.P[j & 1][o + t] : t;
+        const int bk = A.bkt[o + t];
+        int r = 0;
+        for (int q = A.bh[j & 1][bbase + bk]; q >= 0; q = A.nx[o + q]) r += (q > t) ? 1 : 0;
+        const int f = A.bf[j & 1][bbase + bk];
+        const int dest = A.cd[o + f] + A.tsum[o / GS_TILE + b + (hi - 1 - f) / GS_TILE] + r;
+        A.P[(j + 1) & 1][o + dest] = id;
+        if (last) A.vpos[A.moffs[b] + id] = dest;
+    }
+    if (!last && j + 1 < D3F_NCHAIN) {
+        // clear the other parity's bucket arrays for the next round (nb_next < 2.24 * hi)
+        const int nbn = (int)D3F_CHAIN_DEV[j + 1];
+        const int stride = gridDim.x * 256;
+        for (int i = t; i < nbn; i += stride) {
+            A.bf[(j + 1) & 1][bbase + i] = 0x7fffffff;
+            A.bc[(j + 1) & 1][bbase + i] = 0;
+            A.bh[(j + 1) & 1][bbase + i] = -1;
+        }
     }
 }
 
@@ -326,15 +505,15 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     GsLayout L = gs_layout(N, B);
     size_t n = (size_t)(N > 0 ? N : 1);
     size_t bytes = 0;
-    bytes += d3f_align((B + 1) * sizeof(int)) * 2;          // offs, moffs
+    bytes += d3f_align((B + 1) * sizeof(int)) * 2 + d3f_align((B + 2) * sizeof(int));   // offs, moffs, meta
     bytes += d3f_align(B * 6 * sizeof(unsigned));           // bbox
     bytes += d3f_align(B * sizeof(GsElem));
     bytes += d3f_align(L.cap * sizeof(unsigned long long)); // tkey
     bytes += d3f_align(L.cap * sizeof(int));                // tfirst
     bytes += d3f_align(n * sizeof(unsigned long long));     // vkey
-    bytes += 12 * d3f_align(n * sizeof(int));               // slot isfirst/vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx cd (13, one shared)
-    bytes += 2 * d3f_align(n * sizeof(int));
-    bytes += 3 * d3f_align((size_t)L.bucket_total * sizeof(int));
+    bytes += 14 * d3f_align(n * sizeof(int));               // slot vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx cd bkt
+    bytes += 6 * d3f_align((size_t)L.bucket_total * sizeof(int));
+    bytes += d3f_align((n / GS_TILE + B + 8) * sizeof(int));
     bytes += d3f_align(d3f_scan_tmp_ints(N) * sizeof(int));
     return bytes + 4096;
 }
@@ -342,12 +521,12 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
 extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
                                         const float* features, int fdim, const int* classes, int ldim,
                                         float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
-                                        int* status_dev, void* workspace, size_t workspace_bytes, void* stream_) {
+                                        int* status_host, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || N > (1 << 30) || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f) || fdim < 0 || ldim < 0) return D3F_ERR_ARG;
-    if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
+    if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_host) return D3F_ERR_ARG;
     if ((fdim > 0 && (!features || !sub_features)) || (ldim > 0 && (!classes || !sub_classes))) return D3F_ERR_ARG;
-    D3F_HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int), stream));
+    for (int i = 0; i < B + 2; ++i) status_host[i] = 0;
     if (N == 0) {
         D3F_HIP_TRY(hipMemsetAsync(sub_lens_dev, 0, B * sizeof(int), stream));
         return D3F_OK;
@@ -357,6 +536,7 @@ extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* l
     const size_t n = (size_t)N;
     int* offs = ar.take<int>(B + 1);
     int* moffs = ar.take<int>(B + 1);
+    int* meta = ar.take<int>(B + 2);   // [M, flags, sub_lens...]
     unsigned* bbox = ar.take<unsigned>(B * 6);
     GsElem* el = ar.take<GsElem>(B);
     unsigned long long* tkey = ar.take<unsigned long long>(L.cap);
@@ -370,43 +550,71 @@ extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* l
     int* pnext = ar.take<int>(n);
     int* vstart = ar.take<int>(n);
     int* sorted = ar.take<int>(n);
-    int* vpos = ar.take<int>(n);
-    int* L0 = ar.take<int>(n);
-    int* L1 = ar.take<int>(n);
-    int* nx = ar.take<int>(n);
-    int* cd = ar.take<int>(n);
-    int* bf = ar.take<int>((size_t)L.bucket_total);
-    int* bc = ar.take<int>((size_t)L.bucket_total);
-    int* bh = ar.take<int>((size_t)L.bucket_total);
+    GsOrderArgs A;
+    A.vpos = ar.take<int>(n);
+    A.P[0] = ar.take<int>(n);
+    A.P[1] = ar.take<int>(n);
+    A.nx = ar.take<int>(n);
+    A.cd = ar.take<int>(n);
+    A.bkt = ar.take<int>(n);
+    for (int k = 0; k < 2; ++k) {
+        A.bf[k] = ar.take<int>((size_t)L.bucket_total);
+        A.bc[k] = ar.take<int>((size_t)L.bucket_total);
+        A.bh[k] = ar.take<int>((size_t)L.bucket_total);
+    }
+    A.tsum = ar.take<int>(n / GS_TILE + B + 8);
     int* stmp = ar.take<int>(d3f_scan_tmp_ints(N));
     if (!ar.ok) return D3F_ERR_WORKSPACE;
+    A.vkey = vkey; A.moffs = moffs; A.offs = offs; A.el = el;
 
     int rc;
+    D3F_HIP_TRY(hipMemsetAsync(meta, 0, (B + 2) * sizeof(int), stream));
     if ((rc = d3f_offsets_launch(lens_dev, B, offs, stream)) != D3F_OK) return rc;
     if ((rc = d3f_bbox_launch(points, offs, B, N, bbox, stream)) != D3F_OK) return rc;
-    gs_prep_kernel<<<d3f_cdiv(B, 64), 64, 0, stream>>>(bbox, offs, B, dl, el, status_dev);
+    gs_prep_kernel<<<d3f_cdiv(B, 64), 64, 0, stream>>>(bbox, offs, B, dl, el, meta);
     D3F_HIP_TRY(hipMemsetAsync(tkey, 0xFF, L.cap * sizeof(unsigned long long), stream));
     D3F_HIP_TRY(hipMemsetAsync(tfirst, 0x7F, L.cap * sizeof(int), stream));  // 0x7F7F7F7F > any index
     const int nblk = d3f_cdiv(N, 256);
     gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
-                                               slot, status_dev);
+                                               slot, meta);
     gs_mark_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, vscan);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_exclusive_scan_i32(vscan, vscan, N, stmp, &status_dev[0], stream)) != D3F_OK) return rc;
-    D3F_HIP_TRY(hipMemsetAsync(vhead, 0xFF, n * sizeof(int), stream));
-    D3F_HIP_TRY(hipMemsetAsync(vcnt, 0, n * sizeof(int), stream));
+    if ((rc = d3f_exclusive_scan_i32(vscan, vscan, N, stmp, &meta[0], stream)) != D3F_OK) return rc;
+    gs_moffs_kernel<<<d3f_cdiv(B + 1, 64), 64, 0, stream>>>(offs, B, vscan, meta, moffs, meta + 2);
+    D3F_HIP_TRY(hipMemcpyAsync(sub_lens_dev, meta + 2, B * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    // The output size is data dependent (as for the reference op, whose output tensor is allocated after the
+    // computation): ONE host synchronisation here brings back M, the flags and the per-element counts; everything
+    // after it is sized by M instead of N.
+    D3F_HIP_TRY(hipMemcpyAsync(status_host, meta, (B + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    D3F_HIP_TRY(hipStreamSynchronize(stream));
+    const int M = status_host[0];
+    if (status_host[1] != 0 || M <= 0) return D3F_OK;  // flags are reported to the caller; nothing more to compute
+    int maxM = 0;
+    for (int b = 0; b < B; ++b) maxM = status_host[2 + b] > maxM ? status_host[2 + b] : maxM;
+
+    D3F_HIP_TRY(hipMemsetAsync(vhead, 0xFF, (size_t)M * sizeof(int), stream));
+    D3F_HIP_TRY(hipMemsetAsync(vcnt, 0, (size_t)M * sizeof(int), stream));
     gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, pvid, vkey, vhead, vcnt, pnext);
-    gs_moffs_kernel<<<d3f_cdiv(B + 1, 64), 64, 0, stream>>>(offs, B, vscan, status_dev, moffs, sub_lens_dev);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_exclusive_scan_i32(vcnt, vstart, N, stmp, nullptr, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_exclusive_scan_i32(vcnt, vstart, M, stmp, nullptr, stream)) != D3F_OK) return rc;
     gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, pvid, vhead, pnext, vstart, sorted);
-    gs_order_kernel<<<B, 1024, 0, stream>>>(vkey, moffs, offs, el, L0, L1, nx, cd, bf, bc, bh, vpos);
-    gs_accum_kernel<<<nblk, 256, 0, stream>>>(points, features, fdim, status_dev, moffs, B, vstart, vcnt, sorted, vpos,
-                                              sub_points, sub_features);
+    // ---- libstdc++ iteration order ----
+    gs_order_small_kernel<<<B, 1024, 0, stream>>>(A);
+    for (int j = GS_SMALL_LAST + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
+        const long long nbj = (long long)D3F_CHAIN_HOST[j];
+        const int hi = (int)((long long)maxM < nbj ? (long long)maxM : nbj);
+        dim3 g(d3f_cdiv(hi, 256), B), gt(d3f_cdiv(hi, GS_TILE), B);
+        gs_order_insert_kernel<<<g, 256, 0, stream>>>(A, j);
+        gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j);
+        gs_order_scan_sums_kernel<<<B, 256, 0, stream>>>(A, j);
+        gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
+    }
+    gs_accum_kernel<<<d3f_cdiv(M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, vcnt, sorted, A.vpos,
+                                                         sub_points, sub_features);
     if (ldim > 0) {
-        const size_t tot = n * (size_t)ldim;
+        const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);
-        gs_labels_kernel<<<nblk, 256, 0, stream>>>(N, ldim, classes, pvid, moffs, B, vpos, sub_classes);
+        gs_labels_kernel<<<nblk, 256, 0, stream>>>(N, ldim, classes, pvid, moffs, B, A.vpos, sub_classes);
     }
     D3F_LAUNCH_CHECK();
     return D3F_OK;

@@ -27,22 +27,45 @@ __global__ void __launch_bounds__(256) colmin_decode_kernel(unsigned* __restrict
     if (c < C) ((float*)cm)[c] = d3f_ord2f(cm[c]);
 }
 
+template <int VEC>  // channels per thread (4: 16-byte loads; 1: generic)
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
                                                       const float* __restrict__ colmin, float* __restrict__ out, int ldo) {
+    const int CV = C / VEC;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)N2 * C) return;
-    const int n = (int)(t / C), c = (int)(t % C);
-    const float sh = colmin[c];
-    float m = -3.402823466e38f;
-    bool any = false;
-    for (int k = 0; k < K; ++k) {
-        const int id = idx[(size_t)n * ld_idx + k];
-        const float v = (id >= 0 && id < N1) ? x[(size_t)id * ldx + c] : sh;
-        m = any ? fmaxf(m, v) : v;
-        any = true;
+    if (t >= (long long)N2 * CV) return;
+    const int n = (int)(t / CV), c = (int)(t % CV) * VEC;
+    float sh[VEC], m[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { sh[v] = colmin[c + v]; m[v] = -3.402823466e38f; }
+    const int* row = idx + (size_t)n * ld_idx;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        int id[4];
+        float val[4][VEC];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) id[j] = (k0 + j < K) ? row[k0 + j] : -2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (id[j] >= 0 && id[j] < N1) {
+                if (VEC == 4) {
+                    const float4 f = *(const float4*)&x[(size_t)id[j] * ldx + c];
+                    val[j][0] = f.x; val[j][1 % VEC] = f.y; val[j][2 % VEC] = f.z; val[j][3 % VEC] = f.w;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) val[j][v] = x[(size_t)id[j] * ldx + c + v];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) val[j][v] = (id[j] == -2) ? -3.402823466e38f : sh[v];  // shadow -> column min
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], val[j][v]);
     }
-    out[(size_t)n * ldo + c] = any ? m : sh;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) out[(size_t)n * ldo + c + v] = (K > 0) ? m[v] : sh[v];
 }
 
 extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
@@ -55,12 +78,16 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
     colmin_init_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
     if (N1 > 0) {
         int rows = d3f_cdiv(N1, 64);
-        if (rows > 512) rows = 512;
+        if (rows > 128) rows = 128;
         colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, ldx, C, cm);
     }
     colmin_decode_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
-    maxpool_kernel<<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, col_min_dev, out,
-                                                                        ldo);
+    if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
+        maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
+                                                                                      col_min_dev, out, ldo);
+    else
+        maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, col_min_dev,
+                                                                               out, ldo);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -136,7 +163,10 @@ __global__ void __launch_bounds__(256) head_max_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && lo < hi) atomicMax(&mx[b], m);
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && lo < hi) atomicMax(&mx[b], max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
 template <int CPL>  // channels per lane: C <= 32 * CPL
@@ -162,22 +192,45 @@ head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __res
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
     int cnt = 0;
-    for (int k = 0; k < K; ++k) {
-        const int id = idx[(size_t)n * ld_idx + k];
-        if (id < 0 || id >= N) continue;  // shadow row: zeros
-        const int bn = d3f_find_elem(offs, B, id);
-        const float dn = d3f_ord2f(mx[bn]) + 1e-6f;
-        float rs = 0.f;
+    // the point's index row is fetched 32 entries at a time by the half-wave (coalesced), then broadcast entry by
+    // entry; 4 neighbour rows are kept in flight
+    const int hbase = threadIdx.x & 32;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;
+        const int kn = min(32, K - k0);
+        for (int kk = 0; kk < kn; kk += 4) {
+            int id[4];
+            float dn[4];
+            float v[4][CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            const int c = l + 32 * j;
-            const float v = (c < C) ? x[(size_t)id * ldx + c] / dn : 0.f;
-            sum[j] += v;
-            rs += v;
+            for (int j = 0; j < 4; ++j) {
+                id[j] = __shfl(mine, hbase + min(kk + j, 31), 64);
+                if (kk + j >= kn || id[j] < 0 || id[j] >= N) id[j] = -1;   // shadow row: zeros
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dn[j] = 1.f;
+                if (id[j] >= 0) dn[j] = d3f_ord2f(mx[d3f_find_elem(offs, B, id[j])]) + 1e-6f;
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) {
+                    const int c = l + 32 * jj;
+                    v[j][jj] = (id[j] >= 0 && c < C) ? x[(size_t)id[j] * ldx + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float rs = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) {
+                    const float y = v[j][jj] / dn[j];
+                    sum[jj] += y;
+                    rs += y;
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
+                cnt += (id[j] >= 0 && rs != 0.f) ? 1 : 0;
+            }
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
-        cnt += (rs != 0.f) ? 1 : 0;
     }
     const float fc = (float)max(cnt, 1);
     float ymax = -3.402823466e38f;
@@ -221,7 +274,7 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     int* offs = scratch_dev + B;            // [B+1]
     head_max_init_kernel<<<1, 64, 0, stream>>>(lens_dev, include_zero_dev, B, mx, offs);
     int chunks = d3f_cdiv((long long)N * C, 256 * 16);
-    if (chunks > 1024) chunks = 1024;
+    if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
     head_max_kernel<<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
     const int blocks = d3f_cdiv((long long)N * 32, 256);

@@ -97,25 +97,33 @@ __global__ void __launch_bounds__(256) nb_count_kernel(const float* __restrict__
 
 __global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict__ s, int Ns, const int* __restrict__ cell_of,
                                                          const int* __restrict__ cell_start, int* __restrict__ cell_cur,
-                                                         float4* __restrict__ sorted) {
+                                                         float4* __restrict__ sorted, int* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ns) return;
     const int c = cell_of[i];
     const int pos = cell_start[c] + atomicAdd(&cell_cur[c], 1);
     sorted[pos] = make_float4(s[3 * (size_t)i], s[3 * (size_t)i + 1], s[3 * (size_t)i + 2], __int_as_float(i));
+    order[pos] = i;
 }
 
 // ---- search: one wavefront per query -----------------------------------------------------------------
+// Latency is the enemy here (each query touches ~100 candidates in 9 runs): the 18 run bounds are fetched by 18
+// lanes in ONE round trip, the 9 runs are then walked as a single virtual list (lane -> run by comparing against
+// the wave-uniform run prefix), so a typical query needs two 64-wide candidate loads instead of 9+ dependent steps.
+template <bool FIRST_ONLY>
 __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
 nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qoffs, int B,
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
-                 float r2, int pad, int* __restrict__ out, int ld, int width, int cap, int* __restrict__ status) {
+                 const int* __restrict__ qorder, float r2, int pad, int* __restrict__ out, int ld, int width, int cap,
+                 int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* hd2 = (float*)smem + (size_t)wave * 2 * cap;
     int* hidx = (int*)hd2 + cap;
-    const int qi = blockIdx.x * NB_WAVES_PER_BLOCK + wave;
-    if (qi >= Nq) return;
+    const int wq = blockIdx.x * NB_WAVES_PER_BLOCK + wave;
+    if (wq >= Nq) return;
+    // queries that ARE the supports are visited in cell order: neighbouring waves then share their candidate runs in L2
+    const int qi = qorder ? qorder[wq] : wq;
     const int b = d3f_find_elem(qoffs, B, qi);
     const NbElem e = el[b];
     const float qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
@@ -124,46 +132,80 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qo
     cx = min(max(cx, -2), e.dims[0] + 1);
     cy = min(max(cy, -2), e.dims[1] + 1);
     cz = min(max(cz, -2), e.dims[2] + 1);
-    int n = 0;  // wave-uniform hit count
-    const unsigned long long lt = d3f_lanemask_lt();
-    // a query outside the supports' box by more than one cell cannot have neighbours: the clamped loops are empty
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, e.dims[0] - 1);
-    if (x0 <= x1) {
-        for (int z = max(cz - 1, 0); z <= min(cz + 1, e.dims[2] - 1); ++z) {
-            for (int y = max(cy - 1, 0); y <= min(cy + 1, e.dims[1] - 1); ++y) {
-                const int rowbase = e.cbase + e.dims[0] * (y + e.dims[1] * z);
-                const int lo = cell_start[rowbase + x0], hi = cell_start[rowbase + x1 + 1];
-                for (int t0 = lo; t0 < hi; t0 += 64) {
-                    const int t = t0 + lane;
-                    bool hit = false;
-                    float d2 = 0.f;
-                    int si = 0;
-                    if (t < hi) {
-                        const float4 sp = sorted[t];
-                        const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
-                        d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                        si = __float_as_int(sp.w);
-                        hit = d2 < r2;
-                    }
-                    const unsigned long long m = __ballot(hit);
-                    if (hit) {
-                        const int pos = n + __popcll(m & lt);
-                        if (pos < cap) { hd2[pos] = d2; hidx[pos] = si; }
-                    }
-                    n += __popcll(m);
-                }
-            }
+    // lanes 0..8: run start, lanes 9..17: run end, of the 9 (y,z) rows of the stencil
+    int bound = 0;
+    if (lane < 18) {
+        const int j = lane < 9 ? lane : lane - 9;
+        const int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
+        if (x0 <= x1 && y >= 0 && y < e.dims[1] && z >= 0 && z < e.dims[2]) {
+            const int rowbase = e.cbase + e.dims[0] * (y + e.dims[1] * z);
+            bound = cell_start[rowbase + (lane < 9 ? x0 : x1 + 1)];
         }
     }
+    const int hi_l = __shfl_down(bound, 9, 64);
+    const int len_l = (lane < 9) ? hi_l - bound : 0;
+    // wave-uniform run offsets: off[j] = lo[j] - prefix[j]; prefix kept for the lane -> run test
+    int pre[10], off[9];
+    pre[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int lo_j = __shfl(bound, j, 64);
+        const int ln_j = __shfl(len_l, j, 64);
+        off[j] = lo_j - pre[j];
+        pre[j + 1] = pre[j] + ln_j;
+    }
+    const int T = pre[9];
+    int n = 0;  // wave-uniform hit count
+    const unsigned long long lt = d3f_lanemask_lt();
+    float bd2 = 3.4e38f;
+    int bidx = 0x7fffffff;
+    for (int v0 = 0; v0 < T; v0 += 64) {
+        const int v = v0 + lane;
+        bool hit = false;
+        float d2 = 0.f;
+        int si = 0;
+        if (v < T) {
+            int t = v + off[0];
+#pragma unroll
+            for (int j = 1; j < 9; ++j) t = (v >= pre[j]) ? v + off[j] : t;
+            const float4 sp = sorted[t];
+            const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
+            d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            si = __float_as_int(sp.w);
+            hit = d2 < r2;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (FIRST_ONLY) {
+            if (hit && (d2 < bd2 || (d2 == bd2 && si < bidx))) { bd2 = d2; bidx = si; }
+        } else if (hit) {
+            const int pos = n + __popcll(m & lt);
+            if (pos < cap) { hd2[pos] = d2; hidx[pos] = si; }
+        }
+        n += __popcll(m);
+    }
     if (lane == 0) {
-        atomicMax(&status[0], n);
-        if (n > cap) atomicOr(&status[1], D3F_ST_HIT_OVERFLOW);
+        // one shared word: an unconditional atomic per query serialises at ~12 ns each in L2 (60k queries = 0.7 ms);
+        // read first, update only when this query raises the maximum (a handful of times per launch)
+        if (n > __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[0], n);
+        if (!FIRST_ONLY && n > cap) atomicOr(&status[1], D3F_ST_HIT_OVERFLOW);
+    }
+    int* row = out + (size_t)qi * ld;
+    if (FIRST_ONLY) {
+        // lexicographic (d2, index) minimum over the wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(bd2, o, 64);
+            const int oi = __shfl_xor(bidx, o, 64);
+            if (od < bd2 || (od == bd2 && oi < bidx)) { bd2 = od; bidx = oi; }
+        }
+        if (lane == 0 && width > 0) row[0] = (n > 0) ? bidx : pad;
+        for (int j = 1 + lane; j < width; j += 64) row[j] = pad;
+        return;
     }
     const int m = min(n, cap);
-    // the wave's own LDS writes are visible to its own later reads once lgkmcnt drains; no other wave touches them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int* row = out + (size_t)qi * ld;
     for (int e0 = 0; e0 < m; e0 += 64) {
         const int ei = e0 + lane;
         if (ei < m) {
@@ -189,73 +231,124 @@ static long long nb_cell_budget(int Ns) {
     return b;
 }
 
+// The grid object is a plain arena inside caller-owned memory; build and search carve it identically.
+struct NbGrid {
+    int* soffs; unsigned* bbox; NbElem* el; int* ncells; int* cell_cnt; int* cell_cur; int* cell_start; int* cell_of;
+    float4* sorted; int* order; int* stmp;
+    long long cells;
+    bool ok;
+};
+static NbGrid nb_carve(void* ws, size_t bytes, int Ns, int B) {
+    NbGrid g;
+    g.cells = nb_cell_budget(Ns) + 8;
+    D3fArena ar(ws, bytes);
+    const size_t ns = (size_t)(Ns > 0 ? Ns : 1);
+    g.soffs = ar.take<int>(B + 1);
+    g.bbox = ar.take<unsigned>(B * 6);
+    g.el = ar.take<NbElem>(B);
+    g.ncells = ar.take<int>(16);
+    g.cell_cnt = ar.take<int>((size_t)g.cells * 2);   // [counts | cursors]: one memset
+    g.cell_cur = g.cell_cnt ? g.cell_cnt + g.cells : nullptr;
+    g.cell_start = ar.take<int>((size_t)g.cells);
+    g.cell_of = ar.take<int>(ns);
+    g.sorted = ar.take<float4>(ns);
+    g.order = ar.take<int>(ns);
+    g.stmp = ar.take<int>(d3f_scan_tmp_ints((int)g.cells));
+    g.ok = ar.ok;
+    return g;
+}
+
+extern "C" size_t d3f_neighbor_grid_bytes(int Ns, int B) {
+    if (Ns < 0 || B < 1) return 0;
+    const long long cells = nb_cell_budget(Ns) + 8;
+    const size_t ns = (size_t)(Ns > 0 ? Ns : 1);
+    size_t bytes = 0;
+    bytes += d3f_align((B + 1) * sizeof(int)) + d3f_align(B * 6 * sizeof(unsigned)) + d3f_align(B * sizeof(NbElem)) + d3f_align(64);
+    bytes += d3f_align((size_t)cells * 2 * sizeof(int)) + d3f_align((size_t)cells * sizeof(int));
+    bytes += 2 * d3f_align(ns * sizeof(int)) + d3f_align(ns * sizeof(float4));
+    bytes += d3f_align(d3f_scan_tmp_ints((int)cells) * sizeof(int));
+    return bytes + 1024;
+}
+
+extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev, int B, float radius,
+                                       void* grid, size_t grid_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Ns < 0 || B < 1 || B > D3F_MAX_BATCH || !(radius >= 0.f) || !s_lens_dev || (Ns > 0 && !supports) || !grid)
+        return D3F_ERR_ARG;
+    NbGrid g = nb_carve(grid, grid_bytes, Ns, B);
+    if (!g.ok) return D3F_ERR_WORKSPACE;
+    int rc;
+    if ((rc = d3f_offsets_launch(s_lens_dev, B, g.soffs, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_bbox_launch(supports, g.soffs, B, Ns, g.bbox, stream)) != D3F_OK) return rc;
+    nb_prep_kernel<<<1, 64, 0, stream>>>(g.bbox, g.soffs, B, radius, nb_cell_budget(Ns), g.el, g.ncells);
+    // The cell arrays are sized for the whole budget; scanning all of it keeps the launch shapes static
+    // (no host read-back of the real cell count).  cell_start[c] for c >= ncells is the total count.
+    D3F_HIP_TRY(hipMemsetAsync(g.cell_cnt, 0, (size_t)g.cells * 2 * sizeof(int), stream));
+    if (Ns > 0) {
+        nb_count_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs, B, g.el, g.cell_of, g.cell_cnt);
+        D3F_LAUNCH_CHECK();
+    }
+    if ((rc = d3f_exclusive_scan_i32(g.cell_cnt, g.cell_start, (int)g.cells, g.stmp, nullptr, stream)) != D3F_OK) return rc;
+    if (Ns > 0) {
+        nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.cell_of, g.cell_start, g.cell_cur, g.sorted,
+                                                                 g.order);
+        D3F_LAUNCH_CHECK();
+    }
+    return D3F_OK;
+}
+
+extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                                        const int* q_lens_dev, int B, float radius, int queries_are_supports,
+                                        int* out, int ld, int width, int pad_value, int cap, int first_only,
+                                        int* status_dev, int* scratch_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
+    if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
+    if (!grid || !status_dev || !scratch_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
+    if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
+    D3F_HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int), stream));
+    if (Nq == 0) return D3F_OK;
+    NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
+    if (!g.ok) return D3F_ERR_WORKSPACE;
+    int rc;
+    int* qoffs = scratch_dev;  // B + 1 ints
+    if ((rc = d3f_offsets_launch(q_lens_dev, B, qoffs, stream)) != D3F_OK) return rc;
+    const float r2 = radius * radius;
+    const int blocks = d3f_cdiv(Nq, NB_WAVES_PER_BLOCK);
+    const int* qorder = queries_are_supports ? g.order : nullptr;
+    if (first_only) {
+        nb_search_kernel<true><<<blocks, 64 * NB_WAVES_PER_BLOCK, 0, stream>>>(
+            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, out, ld, width, 1, status_dev);
+    } else {
+        const size_t lds = (size_t)NB_WAVES_PER_BLOCK * cap * 2 * sizeof(float);
+        nb_search_kernel<false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(
+            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, out, ld, width, cap, status_dev);
+    }
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
 extern "C" size_t d3f_radius_neighbors_workspace_bytes(int Nq, int Ns, int B) {
     (void)Nq;
     if (Ns < 0 || B < 1) return 0;
-    const long long cells = nb_cell_budget(Ns) + 8;
-    size_t ns = (size_t)(Ns > 0 ? Ns : 1);
-    size_t bytes = 0;
-    bytes += 2 * d3f_align((B + 1) * sizeof(int));
-    bytes += d3f_align(B * 6 * sizeof(unsigned));
-    bytes += d3f_align(B * sizeof(NbElem));
-    bytes += d3f_align(64);
-    bytes += 3 * d3f_align((size_t)cells * sizeof(int));
-    bytes += d3f_align(ns * sizeof(int));
-    bytes += d3f_align(ns * sizeof(float4));
-    bytes += d3f_align(d3f_scan_tmp_ints((int)cells) * sizeof(int));
-    return bytes + 4096;
+    return d3f_neighbor_grid_bytes(Ns, B) + d3f_align((B + 1) * sizeof(int)) + 256;
 }
 
+// One-shot form (build + search), the direct replacement of the BatchOrderedNeighbors op.
 extern "C" int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* supports, int Ns,
                                           const int* q_lens_dev, const int* s_lens_dev, int B, float radius,
                                           int* out, int ld, int width, int pad_value, int* status_dev,
                                           void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
     if (!status_dev || !q_lens_dev || !s_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out))) || (Ns > 0 && !supports))
         return D3F_ERR_ARG;
-    D3F_HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int), stream));
-    if (Nq == 0) return D3F_OK;
-    const long long budget = nb_cell_budget(Ns);
-    const long long cells = budget + 8;
-    D3fArena ar(workspace, workspace_bytes);
-    const size_t ns = (size_t)(Ns > 0 ? Ns : 1);
-    int* qoffs = ar.take<int>(B + 1);
-    int* soffs = ar.take<int>(B + 1);
-    unsigned* bbox = ar.take<unsigned>(B * 6);
-    NbElem* el = ar.take<NbElem>(B);
-    int* ncells = ar.take<int>(16);
-    int* cell_cnt = ar.take<int>((size_t)cells);
-    int* cell_start = ar.take<int>((size_t)cells);
-    int* cell_cur = ar.take<int>((size_t)cells);
-    int* cell_of = ar.take<int>(ns);
-    float4* sorted = ar.take<float4>(ns);
-    int* stmp = ar.take<int>(d3f_scan_tmp_ints((int)cells));
-    if (!ar.ok) return D3F_ERR_WORKSPACE;
-
-    int rc;
-    if ((rc = d3f_offsets_launch(q_lens_dev, B, qoffs, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_offsets_launch(s_lens_dev, B, soffs, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_bbox_launch(supports, soffs, B, Ns, bbox, stream)) != D3F_OK) return rc;
-    nb_prep_kernel<<<1, 64, 0, stream>>>(bbox, soffs, B, radius, budget, el, ncells);
-    // The cell arrays are sized for the whole budget; scanning all of it keeps the launch shapes static
-    // (no host read-back of the real cell count).  cell_start[c] for c >= ncells is the total count.
-    D3F_HIP_TRY(hipMemsetAsync(cell_cnt, 0, (size_t)cells * sizeof(int), stream));
-    D3F_HIP_TRY(hipMemsetAsync(cell_cur, 0, (size_t)cells * sizeof(int), stream));
-    if (Ns > 0) {
-        nb_count_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, soffs, B, el, cell_of, cell_cnt);
-        D3F_LAUNCH_CHECK();
-    }
-    if ((rc = d3f_exclusive_scan_i32(cell_cnt, cell_start, (int)cells, stmp, nullptr, stream)) != D3F_OK) return rc;
-    if (Ns > 0) {
-        nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, cell_of, cell_start, cell_cur, sorted);
-        D3F_LAUNCH_CHECK();
-    }
-    const int cap = D3F_NEIGHBOR_CAP;
-    const size_t lds = (size_t)NB_WAVES_PER_BLOCK * cap * 2 * sizeof(float);
-    const float r2 = radius * radius;
-    nb_search_kernel<<<d3f_cdiv(Nq, NB_WAVES_PER_BLOCK), 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(
-        queries, Nq, qoffs, B, el, cell_start, sorted, r2, pad_value, out, ld, width, cap, status_dev);
-    D3F_LAUNCH_CHECK();
-    return D3F_OK;
+    const size_t gb = d3f_neighbor_grid_bytes(Ns, B);
+    const size_t sb = d3f_align((B + 1) * sizeof(int));
+    if (!workspace || workspace_bytes < gb + sb) return D3F_ERR_WORKSPACE;
+    int* scratch = (int*)((char*)workspace + d3f_align(gb));
+    if (d3f_align(gb) + sb > workspace_bytes) return D3F_ERR_WORKSPACE;
+    int rc = d3f_neighbor_grid_build(supports, Ns, s_lens_dev, B, radius, workspace, gb, stream_);
+    if (rc != D3F_OK) return rc;
+    return d3f_neighbor_grid_search(workspace, gb, Ns, queries, Nq, q_lens_dev, B, radius, 0, out, ld, width, pad_value,
+                                    D3F_NEIGHBOR_CAP, 0, status_dev, scratch, stream_);
 }

@@ -135,12 +135,19 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pts
             mx[d] = max(mx[d], (unsigned)__shfl_xor((int)mx[d], o, 64));
         }
     }
-    if ((threadIdx.x & 63) == 0 && lo < hi) {
+    // one atomic per block and slot (same-address atomics serialise in L2 at ~12 ns each)
+    __shared__ unsigned red[4][6];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(&bbox[b * 6 + d], mn[d]);
-            atomicMax(&bbox[b * 6 + 3 + d], mx[d]);
-        }
+        for (int d = 0; d < 3; ++d) { red[wv][d] = mn[d]; red[wv][3 + d] = mx[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && lo < hi) {
+        unsigned v = red[0][threadIdx.x];
+        for (int k = 1; k < 4; ++k) v = (threadIdx.x < 3) ? min(v, red[k][threadIdx.x]) : max(v, red[k][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bbox[b * 6 + threadIdx.x], v);
+        else atomicMax(&bbox[b * 6 + threadIdx.x], v);
     }
 }
 
@@ -151,8 +158,8 @@ __global__ void bbox_init_kernel(unsigned* __restrict__ bbox, int B) {
 
 int d3f_bbox_launch(const float* pts, const int* offs, int B, int N, unsigned* bbox, hipStream_t stream) {
     bbox_init_kernel<<<d3f_cdiv(B * 6, 256), 256, 0, stream>>>(bbox, B);
-    int chunks = d3f_cdiv(N > 0 ? N : 1, 256 * 8);
-    if (chunks > 1024) chunks = 1024;
+    int chunks = d3f_cdiv(N > 0 ? N : 1, 256 * 4);
+    if (chunks > 128) chunks = 128;
     bbox_kernel<<<dim3(chunks, B), 256, 0, stream>>>(pts, offs, bbox);
     D3F_LAUNCH_CHECK();
     return D3F_OK;

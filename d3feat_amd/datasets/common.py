@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from .. import tf_custom_ops
 
 
@@ -33,9 +33,7 @@ def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius):
 
 
 def _host_lens(lens):
-    if isinstance(lens, torch.Tensor):
-        return [int(x) for x in lens.tolist()]
-    return [int(x) for x in np.asarray(lens).reshape(-1)]
+    return ops.host_lens(lens)
 
 
 class Dataset:
@@ -96,9 +94,10 @@ class Dataset:
         models/network_blocks.py:81).
         """
         dev = stacked_points.device
+        first_points, first_lengths = stacked_points, stacked_lengths
         lens_dev = ops.as_lens(stacked_lengths, dev)
         stacked_lengths = lens_dev
-        # batch weights (datasets/common.py:1307-1310) -- unused at inference, built lazily on the host
+        # batch weights (datasets/common.py:1307-1310) -- unused at inference, built on the host
         host_lens = _host_lens(lens_dev)
         bw = (np.float32(min(host_lens)) / np.asarray(host_lens, dtype=np.float32)).astype(np.float32)
         stacked_weights = torch.from_numpy(np.repeat(bw, host_lens)).to(dev)
@@ -108,14 +107,20 @@ class Dataset:
         input_points, input_neighbors, input_pools, input_upsamples, input_batches_len = [], [], [], [], []
         pending = []
         arch = config.architecture
+        cap = getattr(self, '_neighbor_cap', 192)
+        grids = {}
 
         def search(q, s, ql, sl, r, layer, first_only=False):
             lim = int(self.neighborhood_limits[layer])
             if exact_shapes:
                 full = tf_batch_neighbors(q, s, ql, sl, r)
                 return full[:, :lim]
-            width = 1 if first_only else lim
-            out, status = ops.batch_radius_neighbors(q, s, ql, sl, r, width)
+            # conv_i and pool_i of a layer query the same supports with the same radius: one grid serves both
+            key = (s.data_ptr(), float(r))
+            grid = grids.get(key)
+            if grid is None:
+                grid = grids[key] = ops.NeighborGrid(s, sl, r)
+            out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only)
             pending.append(status)
             return out
 
@@ -160,8 +165,18 @@ class Dataset:
             r_normal *= 2
             layer_blocks = []
 
+        overflow = False
         for st in pending:
-            ops.check_status(st, 'tf_descriptor_input/neighbors')
+            kmax, flags = st.tolist()
+            if flags & _lib.ST_HIT_OVERFLOW and cap < _lib.NEIGHBOR_CAP:
+                overflow = True
+            else:
+                ops.check_status(st, 'tf_descriptor_input/neighbors')
+        if overflow:
+            # some query has more in-radius supports than the fast LDS budget: redo with the full budget (sticky)
+            self._neighbor_cap = _lib.NEIGHBOR_CAP
+            return self.tf_descriptor_input(config, first_points, stacked_features, first_lengths, batch_inds,
+                                            exact_shapes=exact_shapes, up_first_column_only=up_first_column_only)
 
         stacked_batch_inds_0 = self.tf_stack_batch_inds(input_batches_len[0])
         stacked_batch_inds_1 = self.tf_stack_batch_inds(input_batches_len[-1])

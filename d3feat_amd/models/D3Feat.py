@@ -53,7 +53,7 @@ def detection_head(features, inputs):
     if include_zero is None:
         # datasets/common.py:453-496: a row of in_batches holds the shadow index iff the cloud is shorter than the
         # longest one, or all clouds have the same length (extra pad column)
-        host = lens_dev.tolist() if not isinstance(lens, (list, tuple, np.ndarray)) else [int(x) for x in lens]
+        host = ops.host_lens(lens_dev if isinstance(lens, torch.Tensor) else lens)
         mx = max(host)
         all_eq = all(h == mx for h in host)
         include_zero = ops.as_lens([1 if (h < mx or all_eq) else 0 for h in host], dev)

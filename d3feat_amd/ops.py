@@ -4,6 +4,8 @@ PyTorch is used for three things only: device allocations (torch.empty on a CUDA
 HIP stream, and torch.distributed.  Every computation below is a call into libd3feat_amd.so; nothing here
 computes with torch ops and nothing falls back to the CPU.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -72,15 +74,28 @@ def _rows(t, name):
 
 
 def as_lens(lens, device):
+    """Batch lengths as a device int32 tensor.  When the values are known on the host they ride along as the
+    attribute `host_lens` (saves a device read-back wherever host logic needs them)."""
     if isinstance(lens, torch.Tensor):
-        return lens.to(device=device, dtype=torch.int32).contiguous()
-    return torch.as_tensor(np.asarray(lens, dtype=np.int32), device=device)
+        out = lens.to(device=device, dtype=torch.int32).contiguous()
+        if out is not lens and hasattr(lens, "host_lens"):
+            out.host_lens = lens.host_lens
+        return out
+    host = np.asarray(lens, dtype=np.int32).reshape(-1)
+    out = torch.as_tensor(host, device=device)
+    out.host_lens = [int(x) for x in host]
+    return out
 
 
-def check_status(status, what):
-    """status: int32[2] device tensor written by a kernel; raises on any D3F_ST_* flag. Synchronises."""
-    st = status.tolist()
-    flags = st[1]
+def host_lens(lens):
+    """Python list of the batch lengths (reads the device tensor back only when no host copy rides along)."""
+    if isinstance(lens, torch.Tensor):
+        h = getattr(lens, "host_lens", None)
+        return list(h) if h is not None else [int(x) for x in lens.tolist()]
+    return [int(x) for x in np.asarray(lens).reshape(-1)]
+
+
+def _raise_flags(flags, what):
     if flags:
         msgs = []
         if flags & _lib.ST_EMPTY_ELEMENT:
@@ -92,6 +107,13 @@ def check_status(status, what):
         if flags & _lib.ST_HIT_OVERFLOW:
             msgs.append("a query has more than %d in-radius supports" % _lib.NEIGHBOR_CAP)
         raise _lib.D3FeatLibraryError("d3feat_amd.%s: %s" % (what, "; ".join(msgs)))
+    return 0
+
+
+def check_status(status, what):
+    """status: int32[2] device tensor written by a kernel; raises on any D3F_ST_* flag. Synchronises."""
+    st = status.tolist()
+    _raise_flags(st[1], what)
     return st[0]
 
 
@@ -116,43 +138,68 @@ def batch_grid_subsample(points, lens, dl, features=None, classes=None):
     sub_f = torch.empty((max(N, 1), fdim), dtype=torch.float32, device=dev) if fdim else None
     sub_c = torch.empty((max(N, 1), ldim), dtype=torch.int32, device=dev) if ldim else None
     sub_l = torch.empty((B,), dtype=torch.int32, device=dev)
-    status = torch.empty((2,), dtype=torch.int32, device=dev)
+    status = (ctypes.c_int * (B + 2))()
     nbytes = lib.d3f_grid_subsample_workspace_bytes(N, B, fdim, ldim)
     ws = workspace(nbytes, dev)
     rc = lib.d3f_batch_grid_subsample(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl),
                                       features.data_ptr() if fdim else None, fdim,
                                       classes.data_ptr() if ldim else None, ldim,
                                       sub_p.data_ptr(), sub_f.data_ptr() if fdim else None,
-                                      sub_c.data_ptr() if ldim else None, sub_l.data_ptr(), status.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), _stream(dev))
+                                      sub_c.data_ptr() if ldim else None, sub_l.data_ptr(),
+                                      ctypes.addressof(status), ws.data_ptr(), ws.numel(), _stream(dev))
     _lib.check(rc, "batch_grid_subsample")
-    M = check_status(status, "batch_grid_subsample")
+    M = _raise_flags(status[1], "batch_grid_subsample") or status[0]
+    sub_l.host_lens = [int(status[2 + b]) for b in range(B)]
     return sub_p[:M], sub_l, (sub_f[:M] if fdim else None), (sub_c[:M] if ldim else None)
 
 
-def batch_radius_neighbors(queries, supports, q_lens, s_lens, radius, width, ld=None, out=None, pad_value=None):
-    """Launch the search; -> (out i32[Nq, ld] with `width` valid columns, status i32[2] device tensor).
+class NeighborGrid:
+    """Cell grid over a stacked support cloud (see d3f_neighbor_grid_build); owns its device memory."""
+
+    def __init__(self, supports, s_lens, radius):
+        lib = _lib.load()
+        self.supports = _req(supports, torch.float32, "supports", 2).contiguous()
+        dev = self.supports.device
+        self.Ns = self.supports.shape[0]
+        self.s_lens = as_lens(s_lens, dev)
+        self.B = self.s_lens.numel()
+        self.radius = float(radius)
+        self.nbytes = lib.d3f_neighbor_grid_bytes(self.Ns, self.B)
+        self.mem = torch.empty((self.nbytes,), dtype=torch.uint8, device=dev)
+        rc = lib.d3f_neighbor_grid_build(self.supports.data_ptr(), self.Ns, self.s_lens.data_ptr(), self.B, self.radius,
+                                         self.mem.data_ptr(), self.nbytes, _stream(dev))
+        _lib.check(rc, "neighbor_grid_build")
+
+    def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None):
+        """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation."""
+        lib = _lib.load()
+        queries = _req(queries, torch.float32, "queries", 2).contiguous()
+        dev = queries.device
+        Nq = queries.shape[0]
+        ql = as_lens(q_lens, dev)
+        if ql.numel() != self.B:
+            raise ValueError("q_batches and s_batches must have the same number of elements")
+        ld = int(ld if ld is not None else width)
+        if out is None:
+            out = torch.empty((Nq, ld), dtype=torch.int32, device=dev)
+        status = torch.empty((2,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((self.B + 1,), dtype=torch.int32, device=dev)
+        same = 1 if (queries.data_ptr() == self.supports.data_ptr() and Nq == self.Ns) else 0
+        with _timed("nb_search", dict(Nq=Nq, Ns=self.Ns, width=int(width), first_only=int(bool(first_only))), dev):
+            rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
+                                              ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),
+                                              int(self.Ns if pad_value is None else pad_value), int(cap),
+                                              1 if first_only else 0, status.data_ptr(), scratch.data_ptr(), _stream(dev))
+        _lib.check(rc, "neighbor_grid_search")
+        return out, status
+
+
+def batch_radius_neighbors(queries, supports, q_lens, s_lens, radius, width, ld=None, out=None, pad_value=None, cap=192,
+                           first_only=False):
+    """Build + search; -> (out i32[Nq, ld] with `width` valid columns, status i32[2] device tensor).
     No synchronisation: status[0] = Kmax, status[1] = flags (see check_status)."""
-    lib = _lib.load()
-    queries = _req(queries, torch.float32, "queries", 2).contiguous()
-    supports = _req(supports, torch.float32, "supports", 2).contiguous()
-    dev = queries.device
-    Nq, Ns = queries.shape[0], supports.shape[0]
-    ql, sl = as_lens(q_lens, dev), as_lens(s_lens, dev)
-    if ql.numel() != sl.numel():
-        raise ValueError("q_batches and s_batches must have the same number of elements")
-    B = ql.numel()
-    ld = int(ld if ld is not None else width)
-    if out is None:
-        out = torch.empty((Nq, ld), dtype=torch.int32, device=dev)
-    status = torch.empty((2,), dtype=torch.int32, device=dev)
-    ws = workspace(lib.d3f_radius_neighbors_workspace_bytes(Nq, Ns, B), dev)
-    rc = lib.d3f_batch_radius_neighbors(queries.data_ptr(), Nq, supports.data_ptr(), Ns, ql.data_ptr(), sl.data_ptr(), B,
-                                        float(radius), out.data_ptr(), ld, int(width),
-                                        int(Ns if pad_value is None else pad_value), status.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), _stream(dev))
-    _lib.check(rc, "batch_radius_neighbors")
-    return out, status
+    grid = NeighborGrid(supports, s_lens, radius)
+    return grid.search(queries, q_lens, width, ld=ld, pad_value=pad_value, cap=cap, first_only=first_only, out=out)
 
 
 _INFLUENCE = {"constant": 0, "linear": 1, "gaussian": 2}

@@ -17,12 +17,17 @@ def _neighbors(queries, supports, q_batches, s_batches, radius, pad_value, first
     Nq = queries.shape[0]
     if Nq == 0:
         return torch.zeros((0, 0), dtype=torch.int32, device=queries.device)
-    width = first_width
+    grid = ops.NeighborGrid(supports, s_batches, radius)
+    width, cap = first_width, 192
     while True:
-        out, status = ops.batch_radius_neighbors(queries, supports, q_batches, s_batches, radius, width, pad_value=pad_value)
-        kmax = ops.check_status(status, "batch_ordered_neighbors") if width >= _lib.NEIGHBOR_CAP else status.tolist()[0]
+        out, status = grid.search(queries, q_batches, width, pad_value=pad_value, cap=cap)
+        kmax, flags = status.tolist()
+        if flags & _lib.ST_HIT_OVERFLOW and cap < _lib.NEIGHBOR_CAP:
+            cap = _lib.NEIGHBOR_CAP          # more in-radius supports than the fast LDS budget: order them with the full one
+            width = max(width, min(kmax, _lib.NEIGHBOR_CAP))
+            continue
+        ops.check_status(status, "batch_ordered_neighbors")
         if kmax <= width:
-            ops.check_status(status, "batch_ordered_neighbors")
             return out[:, :kmax]
         width = kmax
 

@@ -48,15 +48,18 @@ int d3f_version(void);
  *   points   f32[N,3]  stacked clouds          lens_dev  i32[B] points per batch element (device)
  *   features f32[N,fdim] or NULL (fdim 0)      classes   i32[N,ldim] or NULL (ldim 0)
  *   sub_points f32[N,3] (capacity N rows; the first M are valid)   sub_features f32[N,fdim]  sub_classes i32[N,ldim]
- *   sub_lens_dev i32[B]  voxels per element
- *   status_dev i32[2]: [0] = M (total voxels), [1] = OR of D3F_ST_* flags
+ *   sub_lens_dev i32[B]  voxels per element (device copy, feeds the next pyramid level)
+ *   status_host i32[B+2] (HOST memory): [0] = M (total voxels), [1] = OR of D3F_ST_* flags, [2..] = voxels per element
  * Output is bit-identical to the reference INCLUDING row order (libstdc++ unordered_map iteration order).
+ * The output size is data dependent, so this entry point synchronises `stream` ONCE internally (after the voxel
+ * count is known) -- the reference op likewise allocates its output after computing it (tf_batch_subsampling.cpp:96-105).
+ * When a flag is raised the outputs are not computed.
  * ------------------------------------------------------------------------------------------- */
 size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int ldim);
 int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
                              const float* features, int fdim, const int* classes, int ldim,
                              float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
-                             int* status_dev, void* workspace, size_t workspace_bytes, void* stream);
+                             int* status_host, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Radius neighbours.
@@ -80,6 +83,28 @@ int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* suppor
                                const int* q_lens_dev, const int* s_lens_dev, int B, float radius,
                                int* out, int ld, int width, int pad_value, int* status_dev,
                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Two-step form of the same op.  datasets/common.py:1344,1367 search the SAME supports with the SAME radius twice
+ * per pyramid level (conv_i and pool_i), so the cell grid is an object the caller keeps:
+ *   d3f_neighbor_grid_build   supports -> cell grid (counting sort by cell) inside caller memory `grid`
+ *                             (>= d3f_neighbor_grid_bytes(Ns, B) bytes, must stay untouched until the last search)
+ *   d3f_neighbor_grid_search  queries against a built grid.
+ *       queries_are_supports  1 when `queries` is the very array the grid was built from: queries are then visited in
+ *                             cell order (L2 locality); results are identical either way
+ *       cap                   in-radius supports per query that can be ordered (LDS budget; <= D3F_NEIGHBOR_CAP);
+ *                             a query with more sets D3F_ST_HIT_OVERFLOW -> search again with a larger cap
+ *       first_only            1: only column 0 (the nearest support, ties by index) is computed -- all that
+ *                             closest_pool reads of the upsampling matrices (models/network_blocks.py:81);
+ *                             columns 1..width-1 are filled with pad_value
+ *       scratch_dev           >= B+1 ints
+ */
+size_t d3f_neighbor_grid_bytes(int Ns, int B);
+int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev, int B, float radius,
+                            void* grid, size_t grid_bytes, void* stream);
+int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                             const int* q_lens_dev, int B, float radius, int queries_are_supports,
+                             int* out, int ld, int width, int pad_value, int cap, int first_only,
+                             int* status_dev, int* scratch_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * KPConv, phase 1: neighbour gather + kernel-point influence + weighted aggregation.
