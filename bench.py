@@ -165,6 +165,10 @@ def main():
                 cout = info["Cin"] if info["Cin"] > 1 else cfg.first_features_dim
                 nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], info["Cin"], cout), 0.0
                 per_step_agg[-1].append((info, ms))
+            elif name == "kpconv_fused_c1":
+                key = "kpconv_c1_fused_kernel"
+                nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], 1, info["Cout"]), 0.0
+                per_step_agg[-1].append((info, ms))
             elif name == "gemm_f32":
                 key = "gemm_f32_kernel"
                 nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])

@@ -47,8 +47,8 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
     constexpr int A_F4 = BM * GM_BK / 4 / 256;  // float4 loads per thread for the A tile
     constexpr int B_F4 = GM_BK * BN / 4 / 256;  // ... for the B tile (>= 1)
     static_assert(B_F4 >= 1, "tile too small");
-    __shared__ float As[BM * GM_SA];
-    __shared__ __attribute__((aligned(16))) float Bs[GM_BK * BN];
+    __shared__ float As[2][BM * GM_SA];                                 // double buffered: one barrier per k-tile
+    __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -98,19 +98,19 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
             rb[i] = v;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
             const int r = e >> 3, k = (e & 7) << 2;
-            float* d = &As[r * GM_SA + k];
+            float* d = &As[buf][r * GM_SA + k];
             d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
             const int r = e / (BN / 4), n = (e % (BN / 4)) << 2;
-            *(float4*)&Bs[r * BN + n] = rb[i];
+            *(float4*)&Bs[buf][r * BN + n] = rb[i];
         }
     };
 
@@ -120,22 +120,23 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
 
     if (t_begin < t_end) {
         load_tile(t_begin);
-        store_tile();
+        store_tile(0);
     }
     __syncthreads();
     const int arow = (wm * 32 + (lane & 31)) * GM_SA + (lane >> 5);
     const int bcol = (lane >> 5) * BN + wn * 32 + (lane & 31);
+    int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
-        if (t + 1 < t_end) load_tile(t + 1);
+        if (t + 1 < t_end) load_tile(t + 1);   // global -> registers, in flight while this tile is multiplied
 #pragma unroll
         for (int kk = 0; kk < GM_BK / 2; ++kk) {
-            const float a = As[arow + kk * 2];
-            const float b = Bs[bcol + kk * 2 * BN];
+            const float a = As[cur][arow + kk * 2];
+            const float b = Bs[cur][bcol + kk * 2 * BN];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+        if (t + 1 < t_end) store_tile(cur ^ 1);
         __syncthreads();
-        if (t + 1 < t_end) store_tile();
-        __syncthreads();
+        cur ^= 1;
     }
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -164,12 +165,14 @@ static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
     if (N <= 32) { bm = 128; bn = 32; } else { bm = 64; bn = 64; }
     const long long blocks = (long long)d3f_cdiv(M, bm) * d3f_cdiv(N, bn);
     const int nt = d3f_cdiv(K, GM_BK);
+    // Skinny problems are latency bound per k-tile (global -> LDS -> MFMA): give every CU ~4 co-resident workgroups by
+    // splitting K, as long as each split keeps >= 4 k-tiles.
     S = 1;
-    if (blocks < 192 && nt >= 16) {
-        long long want = (512 + blocks - 1) / blocks;
-        long long maxs = nt / 8;  // >= 8 k-tiles (256 k) per split
+    if (blocks < 768 && nt >= 8) {
+        long long want = (1024 + blocks - 1) / blocks;
+        long long maxs = nt / 4;
         S = (int)(want < maxs ? want : maxs);
-        if (S > 32) S = 32;
+        if (S > 64) S = 64;
         if (S < 1) S = 1;
     }
     tps = d3f_cdiv(nt, S);

@@ -172,6 +172,100 @@ kpconv_agg_scalar(const float* __restrict__ q, int Nq, const float* __restrict__
     if (c == 0) inv_cnt[qg] = 1.0f / fmaxf((float)cnt, 1.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Input layer (Cin = 1, models/network_blocks.py:222-244 `simple_block` on the all-ones features): whole KPConv_ops
+// in ONE kernel.  One wavefront per query, lanes = neighbour slots: every lane computes the 15 influences of its
+// neighbour, the wave all-reduces the 15 weighted sums (xor butterflies), then lanes switch roles to output channels:
+// lane o does the 15-term contraction with K_values[:,0,o] (held in registers across the wave's queries), the
+// neighbour-count division and the fused batch-norm / LeakyReLU epilogue, and the 64 lanes store one coalesced row.
+// Nothing but the [Nq, Cout] result touches HBM.
+// ------------------------------------------------------------------------------------------------
+struct KpEpi {
+    const float* col_scale;
+    const float* col_shift;
+    const float* residual;
+    int ldr;
+    int leaky;
+    float alpha;
+};
+
+#define C1_QPW 8  // queries per wavefront (amortises the K_values registers)
+
+__global__ void __launch_bounds__(256)
+kpconv_c1_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                       int ld_idx, int K, const float* __restrict__ f, int ldf, KpParams P, const float* __restrict__ W,
+                       int Cout, KpEpi E, float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int q0 = wave * C1_QPW;
+    if (q0 >= Nq) return;
+    for (int o0 = 0; o0 < Cout; o0 += 64) {
+        const int o = o0 + lane;
+        float wreg[KP_MAXP - 1];
+#pragma unroll
+        for (int p = 0; p < KP_MAXP - 1; ++p) wreg[p] = (p < P.num_kp && o < Cout) ? W[(size_t)p * Cout + o] : 0.f;
+        const float cs = (E.col_scale && o < Cout) ? E.col_scale[o] : 1.f;
+        const float ch = (E.col_shift && o < Cout) ? E.col_shift[o] : 0.f;
+        for (int qi = q0; qi < min(q0 + C1_QPW, Nq); ++qi) {
+            const float qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
+            float acc[KP_MAXP - 1];
+#pragma unroll
+            for (int p = 0; p < KP_MAXP - 1; ++p) acc[p] = 0.f;
+            float cnt = 0.f;
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                const int k = k0 + lane;
+                const int id = (k < K) ? idx[(size_t)qi * ld_idx + k] : -1;
+                if (id >= 0 && id < Ns) {
+                    float w[KP_MAXP];
+                    kp_influences(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
+                    const float fv = f[(size_t)id * ldf];
+                    cnt += (fv > 0.f) ? 1.f : 0.f;
+#pragma unroll
+                    for (int p = 0; p < KP_MAXP - 1; ++p) acc[p] = fmaf(w[p], fv, acc[p]);
+                }
+            }
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) {
+                cnt += __shfl_xor(cnt, sh, 64);
+#pragma unroll
+                for (int p = 0; p < KP_MAXP - 1; ++p) acc[p] += __shfl_xor(acc[p], sh, 64);
+            }
+            float v = 0.f;
+#pragma unroll
+            for (int p = 0; p < KP_MAXP - 1; ++p) v = fmaf(acc[p], wreg[p], v);
+            v = v * (1.0f / fmaxf(cnt, 1.0f)) * cs + ch;
+            if (o < Cout) {
+                if (E.residual) v += E.residual[(size_t)qi * E.ldr + o];
+                if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+                out[(size_t)qi * ldo + o] = v;
+            }
+        }
+    }
+}
+
+extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                                   const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
+                                   int aggregation, const float* W, int Cout, const float* col_scale,
+                                   const float* col_shift, const float* residual, int ldr, int leaky, float alpha,
+                                   float* out, int ldo, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 1 || num_kp < 1 || num_kp > KP_MAXP - 1 || influence < 0 ||
+        influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || Cout < 1 || ldo < Cout ||
+        (residual && ldr < Cout))
+        return D3F_ERR_ARG;
+    if (Nq == 0) return D3F_OK;
+    if (!q || !s || !idx || !f || !kp_host || !W || !out) return D3F_ERR_ARG;
+    KpParams P;
+    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
+    P.num_kp = num_kp; P.extent = KP_extent; P.influence = influence; P.aggregation = aggregation;
+    KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
+    const long long waves = d3f_cdiv(Nq, C1_QPW);
+    kpconv_c1_fused_kernel<<<d3f_cdiv(waves * 64, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E,
+                                                                         out, ldo);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
 // ---- C ABI ---------------------------------------------------------------------------------------
 extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

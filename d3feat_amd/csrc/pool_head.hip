@@ -77,8 +77,8 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
     unsigned* cm = (unsigned*)col_min_dev;
     colmin_init_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
     if (N1 > 0) {
-        int rows = d3f_cdiv(N1, 64);
-        if (rows > 128) rows = 128;
+        int rows = d3f_cdiv(N1, 32);
+        if (rows > 1024) rows = 1024;
         colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, ldx, C, cm);
     }
     colmin_decode_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);

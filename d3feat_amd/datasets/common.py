@@ -99,13 +99,17 @@ class Dataset:
         stacked_lengths = lens_dev
         # batch weights (datasets/common.py:1307-1310) -- unused at inference, built on the host
         host_lens = _host_lens(lens_dev)
-        bw = (np.float32(min(host_lens)) / np.asarray(host_lens, dtype=np.float32)).astype(np.float32)
-        stacked_weights = torch.from_numpy(np.repeat(bw, host_lens)).to(dev)
+        if exact_shapes:
+            bw = (np.float32(min(host_lens)) / np.asarray(host_lens, dtype=np.float32)).astype(np.float32)
+            stacked_weights = torch.from_numpy(np.repeat(bw, host_lens)).to(dev)
+        else:
+            stacked_weights = None   # only the training losses read it
 
         r_normal = config.first_subsampling_dl * config.KP_extent * 2.5
         layer_blocks = []
         input_points, input_neighbors, input_pools, input_upsamples, input_batches_len = [], [], [], [], []
         pending = []
+        status_all = torch.empty((64, 2), dtype=torch.int32, device=dev)
         arch = config.architecture
         cap = getattr(self, '_neighbor_cap', 192)
         grids = {}
@@ -120,7 +124,7 @@ class Dataset:
             grid = grids.get(key)
             if grid is None:
                 grid = grids[key] = ops.NeighborGrid(s, sl, r)
-            out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only)
+            out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)])
             pending.append(status)
             return out
 
@@ -166,20 +170,25 @@ class Dataset:
             layer_blocks = []
 
         overflow = False
-        for st in pending:
-            kmax, flags = st.tolist()
-            if flags & _lib.ST_HIT_OVERFLOW and cap < _lib.NEIGHBOR_CAP:
-                overflow = True
-            else:
-                ops.check_status(st, 'tf_descriptor_input/neighbors')
+        if pending:
+            # one read-back for all searches of the pyramid
+            for kmax, flags in status_all[:len(pending)].tolist():
+                if flags & _lib.ST_HIT_OVERFLOW and cap < _lib.NEIGHBOR_CAP:
+                    overflow = True
+                else:
+                    ops._raise_flags(flags, 'tf_descriptor_input/neighbors')
         if overflow:
             # some query has more in-radius supports than the fast LDS budget: redo with the full budget (sticky)
             self._neighbor_cap = _lib.NEIGHBOR_CAP
             return self.tf_descriptor_input(config, first_points, stacked_features, first_lengths, batch_inds,
                                             exact_shapes=exact_shapes, up_first_column_only=up_first_column_only)
 
-        stacked_batch_inds_0 = self.tf_stack_batch_inds(input_batches_len[0])
-        stacked_batch_inds_1 = self.tf_stack_batch_inds(input_batches_len[-1])
+        if exact_shapes:
+            stacked_batch_inds_0 = self.tf_stack_batch_inds(input_batches_len[0])
+            stacked_batch_inds_1 = self.tf_stack_batch_inds(input_batches_len[-1])
+        else:
+            # the head kernel works from stack_lengths; the index matrices are only an output of the reference API
+            stacked_batch_inds_0 = stacked_batch_inds_1 = None
         li = input_points + input_neighbors + input_pools + input_upsamples
         li += [stacked_features, stacked_weights, stacked_batch_inds_0, stacked_batch_inds_1]
         return li
@@ -286,9 +295,9 @@ class FragmentDataset(Dataset):
 
     def get_tf_mapping(self, config):
         def tf_map(anc_points, anc_keypts, pos_keypts, obj_inds, stack_lengths, ply_id, backup_points):
-            batch_inds = self.tf_get_batch_inds(stack_lengths)
-            # stacked_features = ones([N, 1])  (demo_registration.py:102): a fill, done once on the host
-            stacked_features = torch.from_numpy(np.ones((anc_points.shape[0], 1), dtype=np.float32)).to(anc_points.device)
+            batch_inds = None if self.fast else self.tf_get_batch_inds(stack_lengths)
+            # stacked_features = ones([N, 1])  (demo_registration.py:102): a device-side fill
+            stacked_features = torch.ones((anc_points.shape[0], 1), dtype=torch.float32, device=anc_points.device)
             li = self.tf_descriptor_input(config, anc_points, stacked_features, stack_lengths, batch_inds,
                                           exact_shapes=not self.fast, up_first_column_only=self.fast)
             return li + [stack_lengths, anc_keypts, pos_keypts, ply_id, backup_points]

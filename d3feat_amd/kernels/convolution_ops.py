@@ -51,6 +51,10 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
     num_kp, cin, cout = K_values.shape
     if features.shape[1] != cin:
         raise ValueError('KPConv: features have %d channels, K_values expects %d' % (features.shape[1], cin))
+    if cin == 1 and cout <= 256:
+        # input layer: one fused kernel (gather + influences + 15-term contraction + epilogue)
+        return ops.kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values,
+                                   KP_extent, KP_influence, aggregation_mode, **(epilogue or {}))
     wf, inv_cnt = ops.kpconv_aggregate(query_points, support_points, neighbors_indices, features, K_points, KP_extent,
                                        KP_influence, aggregation_mode)
     return ops.gemm(wf, K_values.reshape(num_kp * cin, cout), row_scale=inv_cnt, **(epilogue or {}))

@@ -170,7 +170,7 @@ class NeighborGrid:
                                          self.mem.data_ptr(), self.nbytes, _stream(dev))
         _lib.check(rc, "neighbor_grid_build")
 
-    def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None):
+    def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None):
         """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation."""
         lib = _lib.load()
         queries = _req(queries, torch.float32, "queries", 2).contiguous()
@@ -182,7 +182,8 @@ class NeighborGrid:
         ld = int(ld if ld is not None else width)
         if out is None:
             out = torch.empty((Nq, ld), dtype=torch.int32, device=dev)
-        status = torch.empty((2,), dtype=torch.int32, device=dev)
+        if status is None:
+            status = torch.empty((2,), dtype=torch.int32, device=dev)
         scratch = torch.empty((self.B + 1,), dtype=torch.int32, device=dev)
         same = 1 if (queries.data_ptr() == self.supports.data_ptr() and Nq == self.Ns) else 0
         with _timed("nb_search", dict(Nq=Nq, Ns=self.Ns, width=int(width), first_only=int(bool(first_only))), dev):
@@ -272,6 +273,39 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
                                       inv_cnt.data_ptr(), st)
     _lib.check(rc, "kpconv_aggregate")
     return wf, inv_cnt
+
+
+def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
+                    KP_influence="linear", aggregation_mode="sum", col_scale=None, col_shift=None, residual=None,
+                    leaky=False, alpha=0.2):
+    """Whole KPConv (+ epilogue) for Cin = 1 in one kernel.  K_values f32[num_kp, 1, Cout]."""
+    lib = _lib.load()
+    q = _req(query_points, torch.float32, "query_points", 2).contiguous()
+    s = _req(support_points, torch.float32, "support_points", 2).contiguous()
+    idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
+    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    kp = np.ascontiguousarray(K_points.detach().cpu().numpy() if isinstance(K_points, torch.Tensor) else K_points,
+                              dtype=np.float32)
+    num_kp, cin, cout = K_values.shape
+    if cin != 1 or f.shape[1] != 1:
+        raise ValueError("kpconv_fused_c1 needs Cin == 1")
+    W = _req(K_values, torch.float32, "K_values").reshape(num_kp, cout).contiguous()
+    Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
+    dev = q.device
+    out = torch.empty((Nq, cout), dtype=torch.float32, device=dev)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
+    with _timed("kpconv_fused_c1", dict(Nq=Nq, Ns=Ns, K=K, Cin=1, Cout=cout), dev):
+        rc = lib.d3f_kpconv_fused_c1(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
+                                     kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
+                                     _AGGREGATION[aggregation_mode], W.data_ptr(), cout,
+                                     col_scale.data_ptr() if col_scale is not None else None,
+                                     col_shift.data_ptr() if col_shift is not None else None,
+                                     residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
+                                     float(alpha), out.data_ptr(), cout, _stream(dev))
+    _lib.check(rc, "kpconv_fused_c1")
+    return out
 
 
 def ind_max_pool(x, inds):

@@ -125,6 +125,15 @@ int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const i
                          int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
                          void* stream);
 
+/* Whole KPConv_ops (kernels/convolution_ops.py:161-255) + the fused inference epilogue for Cin = 1 -- the input
+ * layer of every shipped model (`simple` block on the all-ones features, models/network_blocks.py:222-244):
+ *   out[n,o] = act( (sum_p wf[n,p] * W[p,o]) / max(#{k : f[idx[n,k]] > 0}, 1) * col_scale[o] + col_shift[o] + residual[n,o] )
+ * f f32[Ns,1] (ldf), W f32[num_kp, Cout] (= K_values[:,0,:]); one kernel, only `out` is written to HBM. */
+int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                        const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
+                        int aggregation, const float* W, int Cout, const float* col_scale, const float* col_shift,
+                        const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
  * Replaces kernels/convolution_ops.py:90-99 (unary_convolution = tf.matmul) and :243-253 (the
