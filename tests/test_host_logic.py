@@ -1,0 +1,174 @@
+"""Host-side logic that needs no GPU: Config (parameters.txt compatibility), variable naming against the reference's
+checkpoint index, the checkpoint bundle reader, PLY I/O, kernel-point dispositions, fragment sharding."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def test_config_load_matches_shipped_parameters(tmp_path):
+    from d3feat_amd.utils.config import Config, kitti_config, threedmatch_config
+    for fname, builtin in (("parameters_3dmatch.txt", threedmatch_config()), ("parameters_kitti.txt", kitti_config())):
+        d = tmp_path / fname.split(".")[0]
+        d.mkdir()
+        shutil.copyfile(os.path.join(GOLDEN, fname), d / "parameters.txt")
+        c = Config()
+        c.load(str(d))
+        assert c.architecture == builtin.architecture
+        assert c.num_layers == 5 and c.num_kernel_points == 15 and c.first_features_dim == 64
+        for k in ("first_subsampling_dl", "density_parameter", "KP_extent", "KP_influence", "convolution_mode",
+                  "fixed_kernel_points", "use_batch_norm", "in_features_dim", "dataset"):
+            assert getattr(c, k) == getattr(builtin, k), k
+        # save -> load round trip keeps every field the inference path reads
+        out = tmp_path / (fname + ".rt")
+        out.mkdir()
+        c.save(str(out))
+        c2 = Config()
+        c2.load(str(out))
+        for k in ("architecture", "num_layers", "first_features_dim", "first_subsampling_dl", "density_parameter",
+                  "KP_extent", "KP_influence", "convolution_mode", "num_kernel_points", "use_batch_norm"):
+            assert getattr(c2, k) == getattr(c, k), k
+
+
+def test_variable_names_and_shapes_match_reference_checkpoint():
+    """build_variables creates exactly the inference variables of results/Log_contraloss/snapshots/snap-54.index."""
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    from d3feat_amd.utils.tf_checkpoint import ROOT_SCOPE, is_model_variable
+    idx = json.load(open(os.path.join(GOLDEN, "checkpoint_index.json")))
+    want = {k[len(ROOT_SCOPE):]: tuple(v["shape"]) for k, v in idx.items() if is_model_variable(k)}
+    vs = build_variables(threedmatch_config(), seed=0)
+    got = {k: tuple(v.shape) for k, v in vs.values.items()}
+    assert set(got) == set(want), (sorted(set(got) - set(want))[:5], sorted(set(want) - set(got))[:5])
+    assert got == want
+    assert sum(int(np.prod(s)) for s in got.values()) == 14103938            # = payload of the data shard / 4
+    n_bn = sum(1 for k in got if k.endswith("gamma"))
+    assert n_bn == 37
+
+
+def test_checkpoint_bundle_reader_roundtrip(tmp_path):
+    """Write a tiny bundle in the TF layout by hand, read it back (index parsing, offsets, crc, name filtering)."""
+    import struct
+    from d3feat_amd.utils import tf_checkpoint as tc
+
+    def varint(x):
+        out = b""
+        while True:
+            b = x & 0x7F
+            x >>= 7
+            out += bytes([b | (0x80 if x else 0)])
+            if not x:
+                return out
+
+    rng = np.random.default_rng(0)
+    tensors = {"KernelPointNetwork/layer_0/simple_0/weights": rng.standard_normal((15, 1, 4)).astype(np.float32),
+               "KernelPointNetwork/layer_0/simple_0/weights/Momentum": np.zeros((15, 1, 4), np.float32),
+               "KernelPointNetwork/uplayer_0/last_unary_1/weights": rng.standard_normal((4, 2)).astype(np.float32),
+               "global_step": np.asarray(7, np.int64)}
+    data, entries, off = b"", [], 0
+    for name in sorted(tensors):
+        raw = tensors[name].tobytes()
+        shape = b"".join(b"\x12" + varint(len(b"\x08" + varint(d))) + b"\x08" + varint(d) for d in tensors[name].shape)
+        dt = 1 if tensors[name].dtype == np.float32 else 9
+        val = b"\x08" + varint(dt) + b"\x12" + varint(len(shape)) + shape + b"\x20" + varint(off) + b"\x28" + varint(len(raw))
+        val += b"\x35" + struct.pack("<I", tc.masked_crc32c(raw))
+        entries.append((name.encode(), val))
+        data += raw
+        off += len(raw)
+
+    def block(kvs):
+        body = b""
+        for k, v in kvs:                       # no prefix sharing, one restart at 0 (valid per the format)
+            body += varint(0) + varint(len(k)) + varint(len(v)) + k + v
+        return body + struct.pack("<I", 0) + struct.pack("<I", 1)
+
+    blk = block([(b"", b"\x08\x01")] + entries)
+    file = blk + b"\x00" + b"\x00" * 4
+    handle = varint(0) + varint(len(blk))
+    iblk = block([(b"~", handle)])
+    ioff = len(file)
+    file += iblk + b"\x00" + b"\x00" * 4
+    moff = len(file)
+    mblk = block([])
+    file += mblk + b"\x00" + b"\x00" * 4
+    footer = varint(moff) + varint(len(mblk)) + varint(ioff) + varint(len(iblk))
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xdb4775248b80fb57)
+    prefix = str(tmp_path / "snap-1")
+    open(prefix + ".index", "wb").write(file + footer)
+    idx = tc.read_index(prefix + ".index")
+    assert list(idx) == sorted(tensors)
+    assert idx["KernelPointNetwork/layer_0/simple_0/weights"].shape == (15, 1, 4)
+    with pytest.raises(FileNotFoundError):
+        tc.load_checkpoint(prefix)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    w = tc.load_checkpoint(prefix, verify_crc=True)
+    assert set(w) == {"layer_0/simple_0/weights", "uplayer_0/last_unary_1/weights"}
+    assert np.array_equal(w["layer_0/simple_0/weights"], tensors["KernelPointNetwork/layer_0/simple_0/weights"])
+
+
+def test_checkpoint_index_golden_layout():
+    idx = json.load(open(os.path.join(GOLDEN, "checkpoint_index.json")))
+    keys = list(idx)
+    assert keys == sorted(keys) and len(keys) == 196
+    last = idx["KernelPointNetwork/uplayer_3/unary_0/weights"]
+    assert last["shape"] == [3072, 512] and last["offset"] == 50124296 and last["offset"] + last["size"] == 56415752
+    # data is packed back to back in key order
+    off = 0
+    for k in keys:
+        assert idx[k]["offset"] == off
+        off += idx[k]["size"]
+
+
+def test_ply_roundtrip(tmp_path):
+    from d3feat_amd.utils.ply import read_ply, read_ply_xyz, write_ply
+    rng = np.random.default_rng(1)
+    pts = rng.standard_normal((50, 3)).astype(np.float32)
+    lab = rng.integers(0, 9, 50).astype(np.int32)
+    fn = str(tmp_path / "c.ply")
+    assert write_ply(fn, [pts, lab], ["x", "y", "z", "label"])
+    d = read_ply(fn)
+    assert d.dtype.names == ("x", "y", "z", "label")
+    assert np.array_equal(read_ply_xyz(fn), pts) and np.array_equal(d["label"], lab)
+    assert not write_ply(fn, [pts, lab[:10]], ["x", "y", "z", "label"])
+    assert not write_ply(fn, [pts], ["x", "y"])
+
+
+def test_kernel_points_disposition():
+    """kernels/kernel_points.py: 15 points, one at the centre, inside the sphere of the requested radius; the
+    trained KITTI dispositions (tests/golden/kitti_kernel_points.npz) have the same structure."""
+    from d3feat_amd.kernels.kernel_points import create_kernel_points
+    kp = create_kernel_points(0.045, 15, 1, 3, "center", rng=np.random.default_rng(3)).reshape(15, 3)
+    assert kp.shape == (15, 3)
+    r = np.linalg.norm(kp, axis=1)
+    assert r.min() < 0.1 * 0.045 and r.max() <= 0.045 * 1.05
+    d = np.linalg.norm(kp[:, None] - kp[None], axis=-1) + np.eye(15)
+    assert d.min() > 0.3 * 0.045                                       # well spread
+    g = np.load(os.path.join(GOLDEN, "kitti_kernel_points.npz"))
+    assert len(g.files) == 10
+    for k in g.files:
+        assert g[k].shape == (15, 3)
+
+
+def test_shard_fragments_partitions():
+    from d3feat_amd.parallel import shard_fragments
+    for ws in (1, 2, 3, 8):
+        parts = [shard_fragments(37, r, ws) for r in range(ws)]
+        assert sorted(sum(parts, [])) == list(range(37))
+        sizes = np.random.default_rng(ws).integers(15000, 45000, 37)
+        parts = [shard_fragments(37, r, ws, sizes=sizes) for r in range(ws)]
+        assert sorted(sum(parts, [])) == list(range(37))
+        loads = [int(sizes[p].sum()) for p in parts]
+        assert max(loads) - min(loads) <= sizes.max()                 # LPT bound
+
+
+def test_stack_batch_inds_host_logic():
+    """datasets/common.py:453-496 quirk: an extra pad column iff all lengths are equal."""
+    from oracle import network_np as onp
+    a = onp.stack_batch_inds([3, 3])
+    assert a.shape == (2, 4) and a[0, -1] == 6 and a[1, 0] == 3
+    b = onp.stack_batch_inds([4, 2])
+    assert b.shape == (2, 4) and list(b[1]) == [4, 5, 6, 6]

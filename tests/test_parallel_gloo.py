@@ -1,0 +1,94 @@
+"""The N>1 path on CPU: two processes over the gloo backend exercise d3feat_amd/parallel.py exactly as bench.py /
+a test driver use it on N GPUs over RCCL (same calls, CPU tensors): fragment sharding, the start-up histogram
+all-reduce that makes every rank derive identical neighborhood_limits, and the final variable-length gather of
+(xyz, descriptors, scores)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3feat_amd import parallel
+    from oracle import network_np as onp
+    try:
+        assert parallel.world() == (rank, world)
+        # ---- sharding: every fragment exactly once, same answer on every rank
+        n_frag = 11
+        sizes = np.random.default_rng(5).integers(15000, 45000, n_frag)
+        mine = parallel.shard_fragments(n_frag, rank, world, sizes=sizes)
+        t = torch.zeros(n_frag, dtype=torch.int64)
+        t[mine] = 1
+        dist.all_reduce(t)
+        assert torch.all(t == 1)
+        # ---- calibration: per-rank histograms summed == histogram of the union -> identical limits on all ranks
+        hist_n = 905
+
+        def rank_hist(r):
+            rg = np.random.default_rng(100 + r)
+            return np.stack([np.bincount(rg.integers(5, 60, 4000), minlength=hist_n)[:hist_n] for _ in range(5)]).astype(np.int64)
+        summed = parallel.allreduce_histograms(rank_hist(rank))
+        both = sum(rank_hist(r) for r in range(world))
+        assert np.array_equal(summed, both)
+        limits = onp.limits_from_histograms(summed)
+        lt = torch.from_numpy(limits.astype(np.int64))
+        gathered = [torch.zeros_like(lt) for _ in range(world)]
+        dist.all_gather(gathered, lt)
+        assert all(torch.equal(g, lt) for g in gathered)
+        # ---- final gather: variable N per rank, payload intact and in rank order
+        n = 1000 + 37 * rank
+        g = torch.Generator().manual_seed(rank)
+        xyz, desc, score = torch.rand(n, 3, generator=g), torch.rand(n, 32, generator=g), torch.rand(n, 1, generator=g)
+        res = parallel.gather_descriptors(xyz, desc, score)
+        assert len(res) == world
+        for r, (x, d, s) in enumerate(res):
+            gr = torch.Generator().manual_seed(r)
+            nr = 1000 + 37 * r
+            assert x.shape == (nr, 3) and d.shape == (nr, 32) and s.shape == (nr, 1)
+            assert torch.equal(x, torch.rand(nr, 3, generator=gr))
+            assert torch.equal(d, torch.rand(nr, 32, generator=gr))
+            assert torch.equal(s, torch.rand(nr, 1, generator=gr))
+        # ---- empty shard on one rank (fewer fragments than ranks) still gathers
+        e = 0 if rank == 1 else 5
+        res = parallel.gather_descriptors(torch.ones(e, 3), torch.ones(e, 32), torch.ones(e, 1))
+        assert [r[0].shape[0] for r in res] == [5 if r != 1 else 0 for r in range(world)]
+        open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok_%d" % r)) for r in range(world))
+
+
+def test_single_process_degenerates_to_identity():
+    from d3feat_amd import parallel
+    assert parallel.world() == (0, 1)
+    h = np.arange(10, dtype=np.int64).reshape(2, 5)
+    assert parallel.allreduce_histograms(h) is h
+    x = torch.rand(4, 3)
+    res = parallel.gather_descriptors(x, torch.rand(4, 32), torch.rand(4, 1))
+    assert len(res) == 1 and res[0][0] is x
