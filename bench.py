@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-fragments", type=int, default=2)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
+    ap.add_argument("--slots", type=int, default=3, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
+    ap.add_argument("--eager", action="store_true", help="op-by-op eager path instead of the graph engine")
     return ap.parse_args()
 
 
@@ -115,7 +117,7 @@ def main():
     limits = np.sum(cumsum < (0.8 * cumsum[hist_n - 1, :]), axis=0).astype(np.int32)
 
     model = KernelPointFCNN(None, cfg, weights=W, device=device)
-    step = Step(cfg, model, limits, device)
+    step = Step(cfg, model, limits, device)          # eager op-by-op path (instrumented pass, --eager)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -123,15 +125,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    out = None
-    for i in range(args.warmup):
-        out = step(raws[i % len(raws)])
-    if world > 1:
-        parallel.gather_descriptors(*out) if out is not None else None
+    engine = None
+    if not args.eager:
+        # the fragment engine: whole fragment = one replayed HIP graph with device-resident sizes, `slots` in flight
+        from d3feat_amd.engine import FragmentEngine
+        raw_cap = int(max(r.shape[0] for r in raws) * 1.05) + 1024
+        n0_cap = (int(max(len(x) for x in subs) * 1.3) + 1023) // 1024 * 1024
+        engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, slots=args.slots, device=device)
+
+    def run(nsteps):
+        """nsteps fragments through the hot path; returns the last fragment's (pts, desc, score)."""
+        out = None
+        if engine is None:
+            for i in range(nsteps):
+                out = step(raws[i % len(raws)])
+            return out
+        S = len(engine.slots)
+        busy = [False] * S
+        for i in range(nsteps):
+            sl = i % S
+            if busy[sl]:
+                out = engine.fetch(sl)
+            engine.submit(sl, raws[i % len(raws)])
+            busy[sl] = True
+        for k in range(nsteps, nsteps + S):      # drain in submission order
+            sl = k % S
+            if busy[sl]:
+                out = engine.fetch(sl)
+                busy[sl] = False
+        return out
+
+    out = run(args.warmup)
+    if world > 1 and out is not None:
+        parallel.gather_descriptors(*out)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(raws[i % len(raws)])
+    out = run(args.steps)
     gathered = parallel.gather_descriptors(*out)
     sync()
     dt = time.perf_counter() - t0
@@ -236,7 +265,10 @@ def main():
                                    "weights, 14.1M params) -> 32-d descriptors + scores" % round(npts / 1000),
                        "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
                        "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
-                       "final_gather_ranks": len(gathered)},
+                       "final_gather_ranks": len(gathered),
+                       "execution": ("eager op-by-op launches" if engine is None else
+                                     "HIP-graph replay per fragment, device-resident sizes, %d fragments in flight" % len(engine.slots)),
+                       "engine_fallbacks": (engine.fallbacks if engine is not None else None)},
             "roofline": roof, "kpconv_layers_ms": layers, "cpu_baseline": cpu,
         }
         if cpu:

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libd3feat_amd.so")
 
 D3F_OK = 0
 ERRORS = {-1: "HIP runtime / kernel launch failure", -2: "workspace too small", -3: "invalid argument"}
-ST_EMPTY_ELEMENT, ST_NEG_CELL, ST_KEY_RANGE, ST_HIT_OVERFLOW = 1, 2, 4, 8
+ST_EMPTY_ELEMENT, ST_NEG_CELL, ST_KEY_RANGE, ST_HIT_OVERFLOW, ST_OUT_OVERFLOW = 1, 2, 4, 8, 16
+PAD_NUM_SUPPORTS = -2147483648
 NEIGHBOR_CAP = 1024
 MAX_BATCH = 255
 
@@ -22,20 +23,23 @@ SIGNATURES = {
     "d3f_version": (_i, []),
     "d3f_grid_subsample_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_batch_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_batch_grid_subsample_async": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_stack_self_pair": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "d3f_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
     "d3f_batch_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "d3f_neighbor_grid_bytes": (_sz, [_i, _i]),
     "d3f_neighbor_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp]),
     "d3f_neighbor_grid_search": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "d3f_row_positive": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp]),
+    "d3f_row_positive": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp,
+                                  _vp]),
     "d3f_kpconv_fused_c1": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
-                                 _f, _vp, _i, _vp]),
+                                 _f, _vp, _i, _vp, _vp, _vp]),
     "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
-    "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp]),
-    "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
-    "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
-    "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp]),
+    "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _vp]),
+    "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
     "d3f_detect_head": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
 }
 

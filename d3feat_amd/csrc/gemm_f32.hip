@@ -42,8 +42,12 @@ __device__ __forceinline__ float gemm_epilogue(float v, int m, int n, const Gemm
 template <int WM, int WN>  // waves along M / N; WM*WN == 4
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                int M, int N, int K, int vecA, int vecB, int tiles_per_split, float* __restrict__ slab, GemmEpi E) {
+                int M, int N, int K, int vecA, int vecB, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
+                const int* __restrict__ M_dev) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
+    const int Mcap = M;                       // slab stride stays the capacity
+    M = d3f_dyn(M, M_dev);
+    if ((int)(blockIdx.x * BM) >= M) return;  // capacity-sized grid: row block beyond the real row count
     constexpr int A_F4 = BM * GM_BK / 4 / 256;  // float4 loads per thread for the A tile
     constexpr int B_F4 = GM_BK * BN / 4 / 256;  // ... for the B tile (>= 1)
     static_assert(B_F4 >= 1, "tile too small");
@@ -145,16 +149,17 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
     for (int r = 0; r < 16; ++r) {
         const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (gm < M && gn < N) {
-            if (slab) slab[((size_t)blockIdx.z * M + gm) * N + gn] = acc[r];
+            if (slab) slab[((size_t)blockIdx.z * Mcap + gm) * N + gn] = acc[r];
             else C[(size_t)gm * ldc + gn] = gemm_epilogue(acc[r], gm, gn, E);
         }
     }
 }
 
 __global__ void __launch_bounds__(256)
-gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E) {
+gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E,
+                          const int* __restrict__ M_dev) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)M * N) return;
+    if (i >= (long long)d3f_dyn(M, M_dev) * N) return;
     const int m = (int)(i / N), n = (int)(i % N);
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += slab[((size_t)s * M + m) * N + n];
@@ -189,7 +194,7 @@ extern "C" size_t d3f_gemm_workspace_bytes(int M, int N, int K) {
 extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                             const float* row_scale, const float* col_scale, const float* col_shift,
                             const float* residual, int ldr, int leaky, float alpha,
-                            void* workspace, size_t workspace_bytes, void* stream_) {
+                            void* workspace, size_t workspace_bytes, const int* M_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || N < 0 || K < 0 || lda < K || ldb < N || ldc < N || (residual && ldr < N)) return D3F_ERR_ARG;
     if (M == 0 || N == 0) return D3F_OK;
@@ -208,11 +213,11 @@ extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, fl
     if (d3f_cdiv(N, bn) > 65535) return D3F_ERR_ARG;
     dim3 grid(d3f_cdiv(M, bm), d3f_cdiv(N, bn), S);
     if (bn == 32)
-        gemm_f32_kernel<4, 1><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E);
+        gemm_f32_kernel<4, 1><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, M_dev);
     else
-        gemm_f32_kernel<2, 2><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E);
+        gemm_f32_kernel<2, 2><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, M_dev);
     if (S > 1)
-        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E);
+        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) gs_insert_kernel(const float* __restrict_
                                                         unsigned long long capmask, int* __restrict__ slot,
                                                         int* __restrict__ status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= min(N, offs[B])) return;   // N is the capacity, offs[B] the real point count
     const int b = d3f_find_elem(offs, B, i);
     const GsElem e = el[b];
     const float fx = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 0], e.org[0]), dl));
@@ -118,10 +118,10 @@ __global__ void __launch_bounds__(256) gs_insert_kernel(const float* __restrict_
     slot[i] = (int)h;
 }
 
-__global__ void __launch_bounds__(256) gs_mark_kernel(int N, const int* __restrict__ slot, const int* __restrict__ tfirst,
-                                                      int* __restrict__ isfirst) {
+__global__ void __launch_bounds__(256) gs_mark_kernel(int N, const int* __restrict__ n_dev, const int* __restrict__ slot,
+                                                      const int* __restrict__ tfirst, int* __restrict__ isfirst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) isfirst[i] = (tfirst[slot[i]] == i) ? 1 : 0;
+    if (i < N) isfirst[i] = (i < *n_dev && tfirst[slot[i]] == i) ? 1 : 0;
 }
 
 // ---- voxel ids, voxel keys, per-voxel chains ----------------------------------------------------------
@@ -129,9 +129,10 @@ __global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restr
                                                        const unsigned long long* __restrict__ tkey,
                                                        const int* __restrict__ vscan, int* __restrict__ pvid,
                                                        unsigned long long* __restrict__ vkey, int* __restrict__ vhead,
-                                                       int* __restrict__ vcnt, int* __restrict__ pnext) {
+                                                       int* __restrict__ vcnt, int* __restrict__ pnext,
+                                                       const int* __restrict__ n_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= min(N, *n_dev)) return;
     const int s = slot[i];
     const int fi = tfirst[s];
     const int v = vscan[fi];
@@ -142,26 +143,25 @@ __global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restr
 }
 
 __global__ void gs_moffs_kernel(const int* __restrict__ offs, int B, const int* __restrict__ vscan,
-                                const int* __restrict__ status, int* __restrict__ moffs, int* __restrict__ sub_lens) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > B) return;
+                                int* __restrict__ status, int* __restrict__ moffs, int* __restrict__ sub_lens, int out_cap) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;   // B <= 255: one thread
     const int M = status[0];
-    // vscan[offs[b]] = number of voxels created by points before element b (empty tail -> M)
     const int N = offs[B];
-    const int lo = (b == B || offs[b] >= N) ? M : vscan[offs[b]];
-    moffs[b] = lo;
-    if (b < B) {
-        const int hi = (b + 1 == B || offs[b + 1] >= N) ? M : vscan[offs[b + 1]];
-        sub_lens[b] = hi - lo;
-    }
+    // vscan[offs[b]] = number of voxels created by points before element b (empty tail -> M)
+    for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : vscan[offs[b]];
+    // More voxels than the caller's output rows (capacity mode): flag it and report an EMPTY result, so that every
+    // downstream stage of a captured launch sequence runs on zero rows instead of on partially written ones.
+    const bool over = M > out_cap;
+    if (over) atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
+    for (int b = 0; b < B; ++b) sub_lens[b] = over ? 0 : moffs[b + 1] - moffs[b];
 }
 
 // ---- rank of each point inside its voxel chain (= number of chain members with a smaller index) ----------
-__global__ void __launch_bounds__(256) gs_rank_kernel(int N, const int* __restrict__ pvid, const int* __restrict__ vhead,
-                                                      const int* __restrict__ pnext, const int* __restrict__ vstart,
-                                                      int* __restrict__ sorted) {
+__global__ void __launch_bounds__(256) gs_rank_kernel(int N, const int* __restrict__ n_dev, const int* __restrict__ pvid,
+                                                      const int* __restrict__ vhead, const int* __restrict__ pnext,
+                                                      const int* __restrict__ vstart, int* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= min(N, *n_dev)) return;
     const int v = pvid[i];
     int r = 0;
     for (int j = vhead[v]; j >= 0; j = pnext[j]) r += (j < i) ? 1 : 0;
@@ -207,6 +207,7 @@ struct GsOrderArgs {
     int* bh[2];     // per bucket: chain head (last insertion)
     int* tsum;      // tile sums of the reverse scan, element b at + offs[b]/GS_TILE + b
     int* vpos;      // OUT: final position of each voxel inside its element
+    int max_m;      // largest element the grid-wide rounds were launched for (capacity mode); larger ones are skipped
 };
 
 __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A) {
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A) {
 __device__ __forceinline__ bool gs_round(const GsOrderArgs& A, int b, int j, int& M, int& lo, int& hi, int& nb, bool& last) {
     M = A.moffs[b + 1] - A.moffs[b];
     lo = (int)D3F_CHAIN_DEV[j - 1];
-    if (M <= lo) return false;
+    if (M <= lo || M > A.max_m) return false;   // (an element beyond the launch geometry is flagged D3F_ST_OUT_OVERFLOW)
     nb = (int)D3F_CHAIN_DEV[j];
     last = M <= nb;
     hi = last ? M : nb;
@@ -437,16 +438,20 @@ __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int 
 
 // ---- per-voxel in-order accumulation + emit (grid_subsampling.cpp:63-70, :81-92) -----------------------
 __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__ pts, const float* __restrict__ feat,
-                                                       int fdim, const int* __restrict__ status,
+                                                       int fdim, int* __restrict__ status,
                                                        const int* __restrict__ moffs, int B,
                                                        const int* __restrict__ vstart, const int* __restrict__ vcnt,
                                                        const int* __restrict__ sorted, const int* __restrict__ vpos,
-                                                       float* __restrict__ out_p, float* __restrict__ out_f) {
+                                                       float* __restrict__ out_p, float* __restrict__ out_f, int out_cap) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= status[0]) return;
     const int b = d3f_find_elem(moffs, B, v);
     const int n = vcnt[v], st = vstart[v];
     const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
+    if (dest >= (size_t)out_cap) {   // more voxels than the caller's output rows (capacity mode): report, never write
+        atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
+        return;
+    }
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int t = 0; t < n; ++t) {
         const size_t i = (size_t)sorted[st + t];
@@ -518,19 +523,22 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     return bytes + 4096;
 }
 
-extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
-                                        const float* features, int fdim, const int* classes, int ldim,
-                                        float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
-                                        int* status_host, void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (N < 0 || N > (1 << 30) || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f) || fdim < 0 || ldim < 0) return D3F_ERR_ARG;
-    if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_host) return D3F_ERR_ARG;
-    if ((fdim > 0 && (!features || !sub_features)) || (ldim > 0 && (!classes || !sub_classes))) return D3F_ERR_ARG;
-    for (int i = 0; i < B + 2; ++i) status_host[i] = 0;
-    if (N == 0) {
-        D3F_HIP_TRY(hipMemsetAsync(sub_lens_dev, 0, B * sizeof(int), stream));
-        return D3F_OK;
+__global__ void gs_status_kernel(const int* __restrict__ meta, int out_cap, int* __restrict__ status_dev) {
+    if (threadIdx.x == 0) {
+        status_dev[0] = meta[0] > out_cap ? 0 : meta[0];   // rows valid in sub_points (none when it overflowed)
+        status_dev[1] = meta[1];
     }
+}
+
+// Shared implementation.  sync mode (status_host != NULL): ONE host synchronisation after the voxel count is known,
+// everything after it sized by M.  async mode (status_dev != NULL): no host round trip at all -- N and M_cap are
+// capacities, the real sizes live in HBM (lens_dev -> offs[B]; M -> status_dev[0]) and every kernel bounds itself by them,
+// so the call can be captured in a HIP graph and replayed for clouds of any size up to the capacity.
+static int gs_run(const float* points, int N, const int* lens_dev, int B, float dl, const float* features, int fdim,
+                  const int* classes, int ldim, float* sub_points, int M_cap, float* sub_features, int* sub_classes,
+                  int* sub_lens_dev, int* status_host, int* status_dev, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream) {
+    const bool async = status_dev != nullptr;
     GsLayout L = gs_layout(N, B);
     D3fArena ar(workspace, workspace_bytes);
     const size_t n = (size_t)N;
@@ -566,38 +574,45 @@ extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* l
     int* stmp = ar.take<int>(d3f_scan_tmp_ints(N));
     if (!ar.ok) return D3F_ERR_WORKSPACE;
     A.vkey = vkey; A.moffs = moffs; A.offs = offs; A.el = el;
+    A.max_m = async ? (N < M_cap ? N : M_cap) : 0x7fffffff;
 
     int rc;
-    D3F_HIP_TRY(hipMemsetAsync(meta, 0, (B + 2) * sizeof(int), stream));
+    if ((rc = d3f_fill_u32(meta, B + 2, 0u, stream)) != D3F_OK) return rc;
     if ((rc = d3f_offsets_launch(lens_dev, B, offs, stream)) != D3F_OK) return rc;
     if ((rc = d3f_bbox_launch(points, offs, B, N, bbox, stream)) != D3F_OK) return rc;
     gs_prep_kernel<<<d3f_cdiv(B, 64), 64, 0, stream>>>(bbox, offs, B, dl, el, meta);
-    D3F_HIP_TRY(hipMemsetAsync(tkey, 0xFF, L.cap * sizeof(unsigned long long), stream));
-    D3F_HIP_TRY(hipMemsetAsync(tfirst, 0x7F, L.cap * sizeof(int), stream));  // 0x7F7F7F7F > any index
+    if ((rc = d3f_fill_u32(tkey, L.cap * 2, 0xFFFFFFFFu, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_fill_u32(tfirst, L.cap, 0x7F7F7F7Fu, stream)) != D3F_OK) return rc;  // > any index
     const int nblk = d3f_cdiv(N, 256);
     gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
                                                slot, meta);
-    gs_mark_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, vscan);
+    gs_mark_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, slot, tfirst, vscan);
     D3F_LAUNCH_CHECK();
     if ((rc = d3f_exclusive_scan_i32(vscan, vscan, N, stmp, &meta[0], stream)) != D3F_OK) return rc;
-    gs_moffs_kernel<<<d3f_cdiv(B + 1, 64), 64, 0, stream>>>(offs, B, vscan, meta, moffs, meta + 2);
-    D3F_HIP_TRY(hipMemcpyAsync(sub_lens_dev, meta + 2, B * sizeof(int), hipMemcpyDeviceToDevice, stream));
-    // The output size is data dependent (as for the reference op, whose output tensor is allocated after the
-    // computation): ONE host synchronisation here brings back M, the flags and the per-element counts; everything
-    // after it is sized by M instead of N.
-    D3F_HIP_TRY(hipMemcpyAsync(status_host, meta, (B + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
-    D3F_HIP_TRY(hipStreamSynchronize(stream));
-    const int M = status_host[0];
-    if (status_host[1] != 0 || M <= 0) return D3F_OK;  // flags are reported to the caller; nothing more to compute
-    int maxM = 0;
-    for (int b = 0; b < B; ++b) maxM = status_host[2 + b] > maxM ? status_host[2 + b] : maxM;
+    gs_moffs_kernel<<<1, 64, 0, stream>>>(offs, B, vscan, meta, moffs, meta + 2, M_cap);
+    if ((rc = d3f_copy_i32(sub_lens_dev, meta + 2, B, stream)) != D3F_OK) return rc;
+    int M, maxM;       // sizes of the voxel-indexed launches
+    if (!async) {
+        // The output size is data dependent (as for the reference op, whose output tensor is allocated after the
+        // computation): ONE host synchronisation here brings back M, the flags and the per-element counts; everything
+        // after it is sized by M instead of N.
+        D3F_HIP_TRY(hipMemcpyAsync(status_host, meta, (B + 2) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        D3F_HIP_TRY(hipStreamSynchronize(stream));
+        M = status_host[0];
+        if (status_host[1] != 0 || M <= 0) return D3F_OK;  // flags are reported to the caller; nothing more to compute
+        maxM = 0;
+        for (int b = 0; b < B; ++b) maxM = status_host[2 + b] > maxM ? status_host[2 + b] : maxM;
+    } else {
+        M = N < M_cap ? N : M_cap;   // upper bound: voxels <= points, and the caller promises <= M_cap (checked on device)
+        maxM = M;
+    }
 
-    D3F_HIP_TRY(hipMemsetAsync(vhead, 0xFF, (size_t)M * sizeof(int), stream));
-    D3F_HIP_TRY(hipMemsetAsync(vcnt, 0, (size_t)M * sizeof(int), stream));
-    gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, pvid, vkey, vhead, vcnt, pnext);
+    if ((rc = d3f_fill_u32(vhead, (size_t)(async ? N : M), 0xFFFFFFFFu, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_fill_u32(vcnt, (size_t)(async ? N : M), 0u, stream)) != D3F_OK) return rc;
+    gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, pvid, vkey, vhead, vcnt, pnext, offs + B);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_exclusive_scan_i32(vcnt, vstart, M, stmp, nullptr, stream)) != D3F_OK) return rc;
-    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, pvid, vhead, pnext, vstart, sorted);
+    if ((rc = d3f_exclusive_scan_i32(vcnt, vstart, async ? N : M, stmp, nullptr, stream)) != D3F_OK) return rc;
+    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sorted);
     // ---- libstdc++ iteration order ----
     gs_order_small_kernel<<<B, 1024, 0, stream>>>(A);
     for (int j = GS_SMALL_LAST + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
@@ -609,13 +624,62 @@ extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* l
         gs_order_scan_sums_kernel<<<B, 256, 0, stream>>>(A, j);
         gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
     }
-    gs_accum_kernel<<<d3f_cdiv(M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, vcnt, sorted, A.vpos,
-                                                         sub_points, sub_features);
+    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, vcnt,
+                                                                     sorted, A.vpos, sub_points, sub_features, M_cap);
     if (ldim > 0) {
         const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);
         gs_labels_kernel<<<nblk, 256, 0, stream>>>(N, ldim, classes, pvid, moffs, B, A.vpos, sub_classes);
     }
+    if (async) gs_status_kernel<<<1, 64, 0, stream>>>(meta, M_cap, status_dev);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
+                                        const float* features, int fdim, const int* classes, int ldim,
+                                        float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
+                                        int* status_host, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || N > (1 << 30) || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f) || fdim < 0 || ldim < 0) return D3F_ERR_ARG;
+    if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_host) return D3F_ERR_ARG;
+    if ((fdim > 0 && (!features || !sub_features)) || (ldim > 0 && (!classes || !sub_classes))) return D3F_ERR_ARG;
+    for (int i = 0; i < B + 2; ++i) status_host[i] = 0;
+    if (N == 0) return d3f_fill_u32(sub_lens_dev, B, 0u, stream);
+    return gs_run(points, N, lens_dev, B, dl, features, fdim, classes, ldim, sub_points, N, sub_features, sub_classes,
+                  sub_lens_dev, status_host, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* lens_dev, int B, float dl,
+                                              float* sub_points, int M_cap, int* sub_lens_dev, int* status_dev,
+                                              void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N_cap < 1 || N_cap > (1 << 30) || M_cap < 1 || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f)) return D3F_ERR_ARG;
+    if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
+    return gs_run(points, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, nullptr, nullptr, sub_lens_dev,
+                  nullptr, status_dev, workspace, workspace_bytes, stream);
+}
+
+// np.concatenate([pts, pts]) of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:
+// 72-79: every fragment is fed stacked with itself) with the row count read from HBM: out[0:m] = out[m:2m] = pts[0:m],
+// lens_out = [m, m], total = 2m.
+__global__ void __launch_bounds__(256) gs_stack_pair_kernel(const float* __restrict__ pts, int M_cap, const int* __restrict__ m_dev,
+                                                            float* __restrict__ out, int* __restrict__ lens_out,
+                                                            int* __restrict__ total) {
+    const int m = min(*m_dev, M_cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { lens_out[0] = m; lens_out[1] = m; *total = 2 * m; }
+    if (i >= 3 * m) return;
+    const float v = pts[i];
+    out[i] = v;
+    out[(size_t)3 * m + i] = v;
+}
+
+extern "C" int d3f_stack_self_pair(const float* pts, int M_cap, const int* m_dev, float* out, int* lens_out_dev,
+                                   int* total_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M_cap < 1 || !pts || !m_dev || !out || !lens_out_dev || !total_dev) return D3F_ERR_ARG;
+    gs_stack_pair_kernel<<<d3f_cdiv(3ll * M_cap, 256), 256, 0, stream>>>(pts, M_cap, m_dev, out, lens_out_dev, total_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

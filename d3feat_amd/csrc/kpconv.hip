@@ -56,11 +56,11 @@ __device__ __forceinline__ void kp_influences(const KpParams& P, float rx, float
 
 // row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
 // the support row, so it is evaluated once per support instead of once per (query, neighbour).
-__global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict__ f, int Ns, int ldf, int Cin,
-                                                        unsigned char* __restrict__ pos) {
+__global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict__ f, int Ns, const int* __restrict__ Ns_dev,
+                                                        int ldf, int Cin, unsigned char* __restrict__ pos) {
     // one wavefront per row
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (row >= Ns) return;
+    if (row >= d3f_dyn(Ns, Ns_dev)) return;
     float s = 0.f;
     for (int c = lane; c < Cin; c += 64) s += f[(size_t)row * ldf + c];
 #pragma unroll
@@ -72,8 +72,12 @@ template <int LQ>  // lanes per query = Cin / 4
 __global__ void __launch_bounds__(256)
 kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                 int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
-                KpParams P, float* __restrict__ wf, float* __restrict__ inv_cnt) {
+                KpParams P, float* __restrict__ wf, float* __restrict__ inv_cnt, const int* __restrict__ Nq_dev,
+                const int* __restrict__ Ns_dev) {
     constexpr int TQ = 256 / LQ;  // queries per workgroup
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
+    if ((int)(blockIdx.x * TQ) >= Nq) return;   // capacity-sized grid: whole block beyond the real query count
     constexpr int KC = LQ;        // neighbours per chunk (TQ*KC = 256 pairs = one per thread)
     constexpr int WS = KC * 16 + 4;  // per-query stride in floats (+4: de-phase the b128 broadcasts of adjacent queries)
     __shared__ __attribute__((aligned(16))) float lw[TQ * WS];
@@ -149,7 +153,9 @@ __global__ void __launch_bounds__(256)
 kpconv_agg_scalar(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                   int ld_idx, int K, const float* __restrict__ f, int ldf, int Cin,
                   const unsigned char* __restrict__ rowpos, KpParams P, float* __restrict__ wf,
-                  float* __restrict__ inv_cnt) {
+                  float* __restrict__ inv_cnt, const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev) {
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)Nq * Cin) return;
     const int qg = (int)(t / Cin), c = (int)(t % Cin);
@@ -194,7 +200,10 @@ struct KpEpi {
 __global__ void __launch_bounds__(256)
 kpconv_c1_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                        int ld_idx, int K, const float* __restrict__ f, int ldf, KpParams P, const float* __restrict__ W,
-                       int Cout, KpEpi E, float* __restrict__ out, int ldo) {
+                       int Cout, KpEpi E, float* __restrict__ out, int ldo, const int* __restrict__ Nq_dev,
+                       const int* __restrict__ Ns_dev) {
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int q0 = wave * C1_QPW;
@@ -247,7 +256,7 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
                                    const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
                                    int aggregation, const float* W, int Cout, const float* col_scale,
                                    const float* col_shift, const float* residual, int ldr, int leaky, float alpha,
-                                   float* out, int ldo, void* stream_) {
+                                   float* out, int ldo, const int* Nq_dev, const int* Ns_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 1 || num_kp < 1 || num_kp > KP_MAXP - 1 || influence < 0 ||
         influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || Cout < 1 || ldo < Cout ||
@@ -261,18 +270,19 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const long long waves = d3f_cdiv(Nq, C1_QPW);
     kpconv_c1_fused_kernel<<<d3f_cdiv(waves * 64, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E,
-                                                                         out, ldo);
+                                                                         out, ldo, Nq_dev, Ns_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------
-extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, void* stream_) {
+extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev,
+                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Ns < 0 || Cin < 1 || ldf < Cin) return D3F_ERR_ARG;
     if (Ns == 0) return D3F_OK;
     if (!f || !row_pos) return D3F_ERR_ARG;
-    kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, ldf, Cin, row_pos);
+    kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, Ns_dev, ldf, Cin, row_pos);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -280,7 +290,7 @@ extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsign
 extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                                     const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host,
                                     int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
-                                    void* stream_) {
+                                    const int* Nq_dev, const int* Ns_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || Cin < 1 || ldf < Cin || num_kp < 1 || num_kp > KP_MAXP - 1 ||
         influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f))
@@ -293,7 +303,7 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
     const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0);
 #define D3F_AGG(LQ_)                                                                                          \
     kpconv_agg_vec4<LQ_><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, \
-                                                                      P, wf, inv_cnt)
+                                                                      P, wf, inv_cnt, Nq_dev, Ns_dev)
     if (vec && Cin == 4) D3F_AGG(1);
     else if (vec && Cin == 8) D3F_AGG(2);
     else if (vec && Cin == 16) D3F_AGG(4);
@@ -305,7 +315,7 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
     else if (vec && Cin == 1024) D3F_AGG(256);
     else
         kpconv_agg_scalar<<<d3f_cdiv((long long)Nq * Cin, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf,
-                                                                                   Cin, rowpos, P, wf, inv_cnt);
+                                                                                   Cin, rowpos, P, wf, inv_cnt, Nq_dev, Ns_dev);
 #undef D3F_AGG
     D3F_LAUNCH_CHECK();
     return D3F_OK;

@@ -12,8 +12,9 @@ __global__ void __launch_bounds__(256) colmin_init_kernel(unsigned* __restrict__
     if (c < C) cm[c] = 0xFFFFFFFFu;
 }
 
-__global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x, int N1, int ldx, int C,
-                                                     unsigned* __restrict__ cm) {
+__global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x, int N1, const int* __restrict__ N1_dev,
+                                                     int ldx, int C, unsigned* __restrict__ cm) {
+    N1 = d3f_dyn(N1, N1_dev);
     // thread = channel (coalesced across a row); each block strides over rows
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -30,7 +31,10 @@ __global__ void __launch_bounds__(256) colmin_decode_kernel(unsigned* __restrict
 template <int VEC>  // channels per thread (4: 16-byte loads; 1: generic)
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
-                                                      const float* __restrict__ colmin, float* __restrict__ out, int ldo) {
+                                                      const float* __restrict__ colmin, float* __restrict__ out, int ldo,
+                                                      const int* __restrict__ N1_dev, const int* __restrict__ N2_dev) {
+    N1 = d3f_dyn(N1, N1_dev);
+    N2 = d3f_dyn(N2, N2_dev);
     const int CV = C / VEC;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N2 * CV) return;
@@ -69,7 +73,8 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
 }
 
 extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
-                                float* out, int ldo, float* col_min_dev, void* stream_) {
+                                float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev,
+                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N1 < 0 || N2 < 0 || C < 1 || ldx < C || ldo < C || K < 0 || ld_idx < K) return D3F_ERR_ARG;
     if (N2 == 0) return D3F_OK;
@@ -79,15 +84,15 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
     if (N1 > 0) {
         int rows = d3f_cdiv(N1, 32);
         if (rows > 1024) rows = 1024;
-        colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, ldx, C, cm);
+        colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, N1_dev, ldx, C, cm);
     }
     colmin_decode_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
     if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
         maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
-                                                                                      col_min_dev, out, ldo);
+                                                                                      col_min_dev, out, ldo, N1_dev, N2_dev);
     else
         maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, col_min_dev,
-                                                                               out, ldo);
+                                                                               out, ldo, N1_dev, N2_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -99,7 +104,10 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
 __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restrict__ x, int N1, int ldx, int C1,
                                                            const int* __restrict__ idx, int N2, int ld_idx,
                                                            const float* __restrict__ skip, int lds, int C2,
-                                                           float* __restrict__ out, int ldo) {
+                                                           float* __restrict__ out, int ldo, const int* __restrict__ N1_dev,
+                                                           const int* __restrict__ N2_dev) {
+    N1 = d3f_dyn(N1, N1_dev);
+    N2 = d3f_dyn(N2, N2_dev);
     const int Ct = C1 + C2;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N2 * Ct) return;
@@ -115,14 +123,15 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restri
 }
 
 extern "C" int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, const int* idx, int N2, int ld_idx,
-                                    const float* skip, int lds, int C2, float* out, int ldo, void* stream_) {
+                                    const float* skip, int lds, int C2, float* out, int ldo, const int* N1_dev,
+                                    const int* N2_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N1 < 0 || N2 < 0 || C1 < 1 || C2 < 0 || ldx < C1 || ldo < C1 + C2 || ld_idx < 1 || (C2 > 0 && lds < C2))
         return D3F_ERR_ARG;
     if (N2 == 0) return D3F_OK;
     if (!x || !idx || !out || (C2 > 0 && !skip)) return D3F_ERR_ARG;
     upsample_cat_kernel<<<d3f_cdiv((long long)N2 * (C1 + C2), 256), 256, 0, stream>>>(x, N1, ldx, C1, idx, N2, ld_idx, skip,
-                                                                                      lds, C2, out, ldo);
+                                                                                      lds, C2, out, ldo, N1_dev, N2_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -141,11 +150,17 @@ extern "C" int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, con
 __global__ void head_max_init_kernel(const int* __restrict__ lens, const int* __restrict__ include_zero_dev, int B,
                                      unsigned* __restrict__ mx, int* __restrict__ offs) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // include_zero_dev == NULL: derive it from the lengths (datasets/common.py:453-496: a row of in_batches holds the
+        // shadow index iff the cloud is shorter than the longest one, or all clouds have the same length)
+        int longest = 0, all_eq = 1;
+        for (int b = 0; b < B; ++b) longest = max(longest, lens[b]);
+        for (int b = 0; b < B; ++b) all_eq &= (lens[b] == longest);
         int s = 0;
         for (int b = 0; b < B; ++b) {
             offs[b] = s;
             s += lens[b];
-            mx[b] = include_zero_dev[b] ? d3f_f2ord(0.f) : 0u;
+            const int inc = include_zero_dev ? include_zero_dev[b] : ((lens[b] < longest || all_eq) ? 1 : 0);
+            mx[b] = inc ? d3f_f2ord(0.f) : 0u;
         }
         offs[B] = s;
     }
@@ -174,7 +189,9 @@ __global__ void __launch_bounds__(256)
 head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __restrict__ idx, int ld_idx, int K,
             const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
             float* __restrict__ score) {
+    N = min(N, offs[B]);   // N is the capacity, offs[B] the real point count
     const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
+    if ((int)((blockIdx.x * blockDim.x) >> 5) >= N) return;
     const bool active = half < N;
     const int n = active ? half : 0;
     const int b = d3f_find_elem(offs, B, n);
@@ -269,7 +286,7 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || C < 1 || C > 128 || ldx < C || ldd < C || K < 0 || ld_idx < K || B < 1 || B > D3F_MAX_BATCH) return D3F_ERR_ARG;
     if (N == 0) return D3F_OK;
-    if (!x || !idx || !lens_dev || !include_zero_dev || !desc || !score || !scratch_dev) return D3F_ERR_ARG;
+    if (!x || !idx || !lens_dev || !desc || !score || !scratch_dev) return D3F_ERR_ARG;
     unsigned* mx = (unsigned*)scratch_dev;  // [B]
     int* offs = scratch_dev + B;            // [B+1]
     head_max_init_kernel<<<1, 64, 0, stream>>>(lens_dev, include_zero_dev, B, mx, offs);
@@ -291,7 +308,8 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
 __global__ void __launch_bounds__(256) affine_act_kernel(const float* __restrict__ x, int ldx, int M, int N,
                                                          const float* __restrict__ cs, const float* __restrict__ ch,
                                                          const float* __restrict__ res, int ldr, int leaky, float alpha,
-                                                         float* __restrict__ out, int ldo) {
+                                                         float* __restrict__ out, int ldo, const int* __restrict__ M_dev) {
+    M = d3f_dyn(M, M_dev);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)M * N) return;
     const int m = (int)(t / N), n = (int)(t % N);
@@ -304,13 +322,14 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const float* __restrict
 }
 
 extern "C" int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale, const float* col_shift,
-                              const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, void* stream_) {
+                              const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
+                              const int* M_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || N < 0 || ldx < N || ldo < N || (residual && ldr < N)) return D3F_ERR_ARG;
     if (M == 0 || N == 0) return D3F_OK;
     if (!x || !out) return D3F_ERR_ARG;
     affine_act_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(x, ldx, M, N, col_scale, col_shift, residual, ldr,
-                                                                          leaky, alpha, out, ldo);
+                                                                          leaky, alpha, out, ldo, M_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -51,6 +51,7 @@ __global__ void nb_prep_kernel(const unsigned* __restrict__ bbox, const int* __r
             }
             double h = (double)radius * (1.0 + 1.0 / 1048576.0);
             if (!(h > 0.0)) h = 1.0;
+            bool fits = false;
             for (int it = 0; it < 64; ++it) {
                 // dims use the same expression as nb_cell_of, so every support's cell is in range by monotonicity
                 e.inv_h = 1.0 / h;
@@ -60,8 +61,15 @@ __global__ void nb_prep_kernel(const unsigned* __restrict__ bbox, const int* __r
                     e.dims[d] = (n < 1073741824.0) ? (int)n : 1073741824;
                     tot *= n;
                 }
-                if (tot <= (double)per) break;
+                if (tot <= (double)per) { fits = true; break; }
                 h *= 2.0;
+            }
+            if (!fits) {
+                // non-finite coordinates (never produced by the pipeline; possible when a flagged, overflowing capacity-mode
+                // call left garbage rows upstream): one cell, every support a candidate -- slow but memory-safe
+                e.mn[0] = e.mn[1] = e.mn[2] = 0.0;
+                e.inv_h = 0.0;
+                e.dims[0] = e.dims[1] = e.dims[2] = 1;
             }
         }
         e.cbase = (int)base;
@@ -82,7 +90,7 @@ __global__ void __launch_bounds__(256) nb_count_kernel(const float* __restrict__
                                                        int B, const NbElem* __restrict__ el, int* __restrict__ cell_of,
                                                        int* __restrict__ cell_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Ns) return;
+    if (i >= min(Ns, soffs[B])) return;   // Ns is the capacity, soffs[B] the real number of supports
     const int b = d3f_find_elem(soffs, B, i);
     const NbElem e = el[b];
     int cx, cy, cz;
@@ -95,11 +103,12 @@ __global__ void __launch_bounds__(256) nb_count_kernel(const float* __restrict__
     atomicAdd(&cell_cnt[c], 1);
 }
 
-__global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict__ s, int Ns, const int* __restrict__ cell_of,
+__global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict__ s, int Ns, const int* __restrict__ ns_dev,
+                                                         const int* __restrict__ cell_of,
                                                          const int* __restrict__ cell_start, int* __restrict__ cell_cur,
                                                          float4* __restrict__ sorted, int* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Ns) return;
+    if (i >= min(Ns, *ns_dev)) return;
     const int c = cell_of[i];
     const int pos = cell_start[c] + atomicAdd(&cell_cur[c], 1);
     sorted[pos] = make_float4(s[3 * (size_t)i], s[3 * (size_t)i + 1], s[3 * (size_t)i + 2], __int_as_float(i));
@@ -114,14 +123,15 @@ template <bool FIRST_ONLY>
 __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
 nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qoffs, int B,
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
-                 const int* __restrict__ qorder, float r2, int pad, int* __restrict__ out, int ld, int width, int cap,
-                 int* __restrict__ status) {
+                 const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
+                 int ld, int width, int cap, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* hd2 = (float*)smem + (size_t)wave * 2 * cap;
     int* hidx = (int*)hd2 + cap;
     const int wq = blockIdx.x * NB_WAVES_PER_BLOCK + wave;
-    if (wq >= Nq) return;
+    if (wq >= min(Nq, qoffs[B])) return;   // Nq is the capacity, qoffs[B] the real number of queries
+    if (pad == D3F_PAD_NUM_SUPPORTS) pad = *ns_dev;
     // queries that ARE the supports are visited in cell order: neighbouring waves then share their candidate runs in L2
     const int qi = qorder ? qorder[wq] : wq;
     const int b = d3f_find_elem(qoffs, B, qi);
@@ -283,15 +293,15 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
     nb_prep_kernel<<<1, 64, 0, stream>>>(g.bbox, g.soffs, B, radius, nb_cell_budget(Ns), g.el, g.ncells);
     // The cell arrays are sized for the whole budget; scanning all of it keeps the launch shapes static
     // (no host read-back of the real cell count).  cell_start[c] for c >= ncells is the total count.
-    D3F_HIP_TRY(hipMemsetAsync(g.cell_cnt, 0, (size_t)g.cells * 2 * sizeof(int), stream));
+    if ((rc = d3f_fill_u32(g.cell_cnt, (size_t)g.cells * 2, 0u, stream)) != D3F_OK) return rc;
     if (Ns > 0) {
         nb_count_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs, B, g.el, g.cell_of, g.cell_cnt);
         D3F_LAUNCH_CHECK();
     }
     if ((rc = d3f_exclusive_scan_i32(g.cell_cnt, g.cell_start, (int)g.cells, g.stmp, nullptr, stream)) != D3F_OK) return rc;
     if (Ns > 0) {
-        nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.cell_of, g.cell_start, g.cell_cur, g.sorted,
-                                                                 g.order);
+        nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs + B, g.cell_of, g.cell_start, g.cell_cur,
+                                                                 g.sorted, g.order);
         D3F_LAUNCH_CHECK();
     }
     return D3F_OK;
@@ -306,7 +316,7 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
     if (!grid || !status_dev || !scratch_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
     if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
-    D3F_HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int), stream));
+    { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
     if (Nq == 0) return D3F_OK;
     NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
     if (!g.ok) return D3F_ERR_WORKSPACE;
@@ -318,11 +328,13 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     const int* qorder = queries_are_supports ? g.order : nullptr;
     if (first_only) {
         nb_search_kernel<true><<<blocks, 64 * NB_WAVES_PER_BLOCK, 0, stream>>>(
-            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, out, ld, width, 1, status_dev);
+            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, 1,
+            status_dev);
     } else {
         const size_t lds = (size_t)NB_WAVES_PER_BLOCK * cap * 2 * sizeof(float);
         nb_search_kernel<false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(
-            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, out, ld, width, cap, status_dev);
+            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, cap,
+            status_dev);
     }
     D3F_LAUNCH_CHECK();
     return D3F_OK;

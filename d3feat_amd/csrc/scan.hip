@@ -81,13 +81,47 @@ size_t d3f_scan_tmp_ints(int n) { return (size_t)d3f_cdiv(n > 0 ? n : 1, SCAN_TI
 
 int d3f_exclusive_scan_i32(const int* in, int* out, int n, int* tmp, int* total, hipStream_t stream) {
     if (n <= 0) {
-        if (total) D3F_HIP_TRY(hipMemsetAsync(total, 0, sizeof(int), stream));
+        if (total) return d3f_fill_u32(total, 1, 0u, stream);
         return D3F_OK;
     }
     const int nb = d3f_cdiv(n, SCAN_TILE);
     scan_tiles_kernel<<<nb, SCAN_BLOCK, 0, stream>>>(in, out, n, tmp);
     scan_sums_kernel<<<1, SCAN_BLOCK, 0, stream>>>(tmp, nb, total);
     if (nb > 1) scan_add_kernel<<<nb, SCAN_BLOCK, 0, stream>>>(out, n, tmp);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fill / copy of 32-bit words as plain kernels.  Used instead of hipMemsetAsync / hipMemcpyAsync so that a captured launch
+// sequence consists of kernel nodes only (no runtime-implemented memset / memcpy nodes inside the HIP graph).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fill_u32_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = (((uintptr_t)p & 15) == 0) ? n / 4 : 0;
+    uint4* p4 = (uint4*)p;
+    const uint4 v4 = make_uint4(v, v, v, v);
+    for (size_t j = i; j < n4; j += stride) p4[j] = v4;
+    for (size_t j = n4 * 4 + i; j < n; j += stride) p[j] = v;
+}
+
+int d3f_fill_u32(void* p, size_t n_words, unsigned v, hipStream_t stream) {
+    if (n_words == 0) return D3F_OK;
+    long long blocks = d3f_cdiv((long long)(n_words / 4 + 1), 256);
+    if (blocks > 2048) blocks = 2048;
+    fill_u32_kernel<<<(int)blocks, 256, 0, stream>>>((unsigned*)p, n_words, v);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+__global__ void copy_i32_kernel(int* __restrict__ dst, const int* __restrict__ src, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int d3f_copy_i32(int* dst, const int* src, int n, hipStream_t stream) {
+    if (n <= 0) return D3F_OK;
+    copy_i32_kernel<<<d3f_cdiv(n, 256) > 64 ? 64 : d3f_cdiv(n, 256), 256, 0, stream>>>(dst, src, n);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -81,7 +81,7 @@ class Dataset:
 
     # ---- the pyramid ------------------------------------------------------------------------------------------------
     def tf_descriptor_input(self, config, stacked_points, stacked_features, stacked_lengths, batch_inds,
-                            exact_shapes=True, up_first_column_only=False, timings=None):
+                            exact_shapes=True, up_first_column_only=False, timings=None, caps=None):
         """datasets/common.py:1301-1413.
 
         exact_shapes=True reproduces the reference's output shapes: every index matrix has
@@ -92,13 +92,21 @@ class Dataset:
         defers all status checks to one synchronisation at the end.  up_first_column_only additionally computes
         only the nearest neighbour for the upsampling matrices (the only column closest_pool reads,
         models/network_blocks.py:81).
+
+        caps (list of per-level row capacities, implies exact_shapes=False): capacity mode.  Nothing is read back to the
+        host: every level's point tensor has caps[l] rows and carries its real row count as `n_dev` (device int32),
+        the subsamplings run through d3f_batch_grid_subsample_async, and the status words of all ops are left in
+        `self.static_status` (int32[k,2] on the device) for ONE check by the caller.  The launch sequence is then
+        independent of the data, which is what lets d3feat_amd.engine capture it in a HIP graph.
         """
+        if caps is not None:
+            exact_shapes = False
         dev = stacked_points.device
         first_points, first_lengths = stacked_points, stacked_lengths
         lens_dev = ops.as_lens(stacked_lengths, dev)
         stacked_lengths = lens_dev
         # batch weights (datasets/common.py:1307-1310) -- unused at inference, built on the host
-        host_lens = _host_lens(lens_dev)
+        host_lens = _host_lens(lens_dev) if exact_shapes else None
         if exact_shapes:
             bw = (np.float32(min(host_lens)) / np.asarray(host_lens, dtype=np.float32)).astype(np.float32)
             stacked_weights = torch.from_numpy(np.repeat(bw, host_lens)).to(dev)
@@ -146,7 +154,12 @@ class Dataset:
                 conv_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
             if 'pool' in block or 'strided' in block:
                 dl = 2 * r_normal / (config.KP_extent * 2.5)
-                pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)
+                if caps is not None:
+                    pool_p, pool_b, _ = ops.batch_grid_subsample_async(stacked_points, stacked_lengths, dl, caps[layer + 1],
+                                                                       status=status_all[len(pending)])
+                    pending.append(status_all[len(pending)])
+                else:
+                    pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)
                 if 'deformable' in block:
                     r = r_normal * config.density_parameter / (config.KP_extent * 2.5)
                 else:
@@ -170,7 +183,8 @@ class Dataset:
             layer_blocks = []
 
         overflow = False
-        if pending:
+        self.static_status = status_all[:len(pending)] if caps is not None else None
+        if pending and caps is None:
             # one read-back for all searches of the pyramid
             for kmax, flags in status_all[:len(pending)].tolist():
                 if flags & _lib.ST_HIT_OVERFLOW and cap < _lib.NEIGHBOR_CAP:
@@ -282,6 +296,7 @@ class FragmentDataset(Dataset):
         self.ids_list = {'train': [], 'test': list(ids) if ids is not None else ['cloud_%d' % i for i in range(len(clouds))]}
         self.num_test = len(clouds)
         self.fast = fast
+        self.caps = None      # per-level row capacities: capacity mode of tf_descriptor_input (see d3feat_amd.engine)
 
     def get_batch_gen(self, split, config):
         def gen():
@@ -297,8 +312,9 @@ class FragmentDataset(Dataset):
         def tf_map(anc_points, anc_keypts, pos_keypts, obj_inds, stack_lengths, ply_id, backup_points):
             batch_inds = None if self.fast else self.tf_get_batch_inds(stack_lengths)
             # stacked_features = ones([N, 1])  (demo_registration.py:102): a device-side fill
-            stacked_features = torch.ones((anc_points.shape[0], 1), dtype=torch.float32, device=anc_points.device)
+            stacked_features = ops._tag(torch.ones((anc_points.shape[0], 1), dtype=torch.float32, device=anc_points.device),
+                                        anc_points)
             li = self.tf_descriptor_input(config, anc_points, stacked_features, stack_lengths, batch_inds,
-                                          exact_shapes=not self.fast, up_first_column_only=self.fast)
+                                          exact_shapes=not self.fast, up_first_column_only=self.fast, caps=self.caps)
             return li + [stack_lengths, anc_keypts, pos_keypts, ply_id, backup_points]
         return tf_map

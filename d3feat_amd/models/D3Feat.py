@@ -49,12 +49,8 @@ def detection_head(features, inputs):
     lens = inputs['stack_lengths']
     dev = features.device
     lens_dev = ops.as_lens(lens, dev)
+    # datasets/common.py:453-496: a row of in_batches holds the shadow index iff the cloud is shorter than the longest one,
+    # or all clouds have the same length (extra pad column).  The head kernel derives that from the lengths on the device;
+    # pass inputs['in_batches_padded'] (int32[B] on the device) to override.
     include_zero = inputs.get('in_batches_padded')
-    if include_zero is None:
-        # datasets/common.py:453-496: a row of in_batches holds the shadow index iff the cloud is shorter than the
-        # longest one, or all clouds have the same length (extra pad column)
-        host = ops.host_lens(lens_dev if isinstance(lens, torch.Tensor) else lens)
-        mx = max(host)
-        all_eq = all(h == mx for h in host)
-        include_zero = ops.as_lens([1 if (h < mx or all_eq) else 0 for h in host], dev)
     return ops.detect_head(features, inputs['neighbors'][0], lens_dev, include_zero)

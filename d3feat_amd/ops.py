@@ -41,6 +41,36 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---- device-resident sizes ------------------------------------------------------------------------------------------
+# A tensor whose row count is only an upper bound carries the real count as the attribute `n_dev` (int32[1] on the
+# device); every op forwards it to the kernels (the `*_dev` arguments of include/d3feat_amd.h) and tags its outputs.
+def _nd(t):
+    d = getattr(t, "n_dev", None) if t is not None else None
+    return d.data_ptr() if d is not None else None
+
+
+def _tag(out, src):
+    d = getattr(src, "n_dev", None)
+    if d is not None:
+        out.n_dev = d
+    return out
+
+
+class private_workspace:
+    """Scratch buffers allocated inside this context are not shared with (or resized by) later eager calls: used while
+    a HIP graph is being captured, so that the graph keeps its own scratch alive."""
+
+    def __enter__(self):
+        global _WS
+        self.prev, _WS = _WS, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _WS
+        self.kept, _WS = _WS, self.prev
+        return False
+
+
 def workspace(nbytes, device):
     """Stream-ordered scratch: one growable byte buffer per (device, stream)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(device))
@@ -106,6 +136,8 @@ def _raise_flags(flags, what):
             msgs.append("voxel key exceeds 2^56")
         if flags & _lib.ST_HIT_OVERFLOW:
             msgs.append("a query has more than %d in-radius supports" % _lib.NEIGHBOR_CAP)
+        if flags & _lib.ST_OUT_OVERFLOW:
+            msgs.append("more output rows than the capacity of the output buffer")
         raise _lib.D3FeatLibraryError("d3feat_amd.%s: %s" % (what, "; ".join(msgs)))
     return 0
 
@@ -153,12 +185,55 @@ def batch_grid_subsample(points, lens, dl, features=None, classes=None):
     return sub_p[:M], sub_l, (sub_f[:M] if fdim else None), (sub_c[:M] if ldim else None)
 
 
+def batch_grid_subsample_async(points, lens, dl, m_cap, status=None):
+    """Capacity mode of batch_grid_subsample (points only): no host synchronisation.
+    points f32[N_cap,3] (sum(lens) rows valid) -> (sub_points f32[m_cap,3] tagged with n_dev, sub_lens i32[B] device,
+    status i32[2] device = [M, flags])."""
+    lib = _lib.load()
+    points = _req(points, torch.float32, "points", 2).contiguous()
+    dev = points.device
+    N = points.shape[0]
+    lens_t = as_lens(lens, dev)
+    B = lens_t.numel()
+    sub_p = torch.empty((int(m_cap), 3), dtype=torch.float32, device=dev)
+    sub_l = torch.empty((B,), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty((2,), dtype=torch.int32, device=dev)
+    nbytes = lib.d3f_grid_subsample_workspace_bytes(N, B, 0, 0)
+    ws = workspace(nbytes, dev)
+    rc = lib.d3f_batch_grid_subsample_async(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl), sub_p.data_ptr(),
+                                            int(m_cap), sub_l.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream(dev))
+    _lib.check(rc, "batch_grid_subsample_async")
+    sub_p.n_dev = status[0:1]
+    return sub_p, sub_l, status
+
+
+def stack_self_pair(pts):
+    """np.concatenate([pts, pts]) with a device-side row count (pts.n_dev): -> (out f32[2*cap,3] tagged, lens i32[2])."""
+    lib = _lib.load()
+    pts = _req(pts, torch.float32, "pts", 2).contiguous()
+    dev = pts.device
+    cap = pts.shape[0]
+    m_dev = getattr(pts, "n_dev", None)
+    if m_dev is None:
+        m_dev = torch.full((1,), cap, dtype=torch.int32, device=dev)
+    out = torch.empty((2 * cap, 3), dtype=torch.float32, device=dev)
+    lens = torch.empty((2,), dtype=torch.int32, device=dev)
+    total = torch.empty((1,), dtype=torch.int32, device=dev)
+    rc = lib.d3f_stack_self_pair(pts.data_ptr(), cap, m_dev.data_ptr(), out.data_ptr(), lens.data_ptr(), total.data_ptr(),
+                                 _stream(dev))
+    _lib.check(rc, "stack_self_pair")
+    out.n_dev = total
+    return out, lens
+
+
 class NeighborGrid:
     """Cell grid over a stacked support cloud (see d3f_neighbor_grid_build); owns its device memory."""
 
     def __init__(self, supports, s_lens, radius):
         lib = _lib.load()
-        self.supports = _req(supports, torch.float32, "supports", 2).contiguous()
+        self.supports = _tag(_req(supports, torch.float32, "supports", 2).contiguous(), supports)
         dev = self.supports.device
         self.Ns = self.supports.shape[0]
         self.s_lens = as_lens(s_lens, dev)
@@ -186,13 +261,16 @@ class NeighborGrid:
             status = torch.empty((2,), dtype=torch.int32, device=dev)
         scratch = torch.empty((self.B + 1,), dtype=torch.int32, device=dev)
         same = 1 if (queries.data_ptr() == self.supports.data_ptr() and Nq == self.Ns) else 0
+        if pad_value is None:
+            # BatchOrderedNeighbors pads with the number of supports: known only on the device in capacity mode
+            pad_value = _lib.PAD_NUM_SUPPORTS if getattr(self.supports, "n_dev", None) is not None else self.Ns
         with _timed("nb_search", dict(Nq=Nq, Ns=self.Ns, width=int(width), first_only=int(bool(first_only))), dev):
             rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
                                               ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),
-                                              int(self.Ns if pad_value is None else pad_value), int(cap),
+                                              int(pad_value), int(cap),
                                               1 if first_only else 0, status.data_ptr(), scratch.data_ptr(), _stream(dev))
         _lib.check(rc, "neighbor_grid_search")
-        return out, status
+        return _tag(out, queries), status
 
 
 def batch_radius_neighbors(queries, supports, q_lens, s_lens, radius, width, ld=None, out=None, pad_value=None, cap=192,
@@ -236,9 +314,9 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
                               col_scale.data_ptr() if col_scale is not None else None,
                               col_shift.data_ptr() if col_shift is not None else None,
                               residual.data_ptr() if residual is not None else None, ldr,
-                              1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _stream(dev))
+                              1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _nd(A), _stream(dev))
     _lib.check(rc, "gemm_f32")
-    return out
+    return _tag(out, A)
 
 
 def kpconv_aggregate(query_points, support_points, neighbors_indices, features, K_points, KP_extent,
@@ -265,14 +343,17 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
     inv_cnt = torch.empty((Nq,), dtype=torch.float32, device=dev)
     row_pos = torch.empty((max(Ns, 1),), dtype=torch.uint8, device=dev)
     st = _stream(dev)
-    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, Cin, row_pos.data_ptr(), st), "row_positive")
+    nq_dev, ns_dev = _nd(query_points), _nd(support_points)
+    if ns_dev is None:
+        ns_dev = _nd(features)
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, Cin, row_pos.data_ptr(), ns_dev, st), "row_positive")
     with _timed("kpconv_aggregate", dict(Nq=Nq, Ns=Ns, K=K, Cin=Cin), dev):
         rc = lib.d3f_kpconv_aggregate(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
                                       Cin, row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent),
                                       _INFLUENCE[KP_influence], _AGGREGATION[aggregation_mode], wf.data_ptr(),
-                                      inv_cnt.data_ptr(), st)
+                                      inv_cnt.data_ptr(), nq_dev, ns_dev, st)
     _lib.check(rc, "kpconv_aggregate")
-    return wf, inv_cnt
+    return _tag(wf, query_points), _tag(inv_cnt, query_points)
 
 
 def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
@@ -303,9 +384,10 @@ def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K
                                      col_scale.data_ptr() if col_scale is not None else None,
                                      col_shift.data_ptr() if col_shift is not None else None,
                                      residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
-                                     float(alpha), out.data_ptr(), cout, _stream(dev))
+                                     float(alpha), out.data_ptr(), cout, _nd(query_points), _nd(support_points),
+                                     _stream(dev))
     _lib.check(rc, "kpconv_fused_c1")
-    return out
+    return _tag(out, query_points)
 
 
 def ind_max_pool(x, inds):
@@ -316,9 +398,9 @@ def ind_max_pool(x, inds):
     out = torch.empty((inds.shape[0], x.shape[1]), dtype=torch.float32, device=dev)
     colmin = torch.empty((x.shape[1],), dtype=torch.float32, device=dev)
     rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
-                              inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _stream(dev))
+                              inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _stream(dev))
     _lib.check(rc, "ind_max_pool")
-    return out
+    return _tag(out, inds)
 
 
 def closest_pool_cat(x, inds, skip=None):
@@ -336,9 +418,9 @@ def closest_pool_cat(x, inds, skip=None):
     out = torch.empty((inds.shape[0], C1 + C2), dtype=torch.float32, device=dev)
     rc = lib.d3f_closest_pool_cat(x.data_ptr(), x.shape[0], ldx, C1, inds.data_ptr(), inds.shape[0], ldi,
                                   skip.data_ptr() if skip is not None else None, lds, C2, out.data_ptr(), C1 + C2,
-                                  _stream(dev))
+                                  _nd(x), _nd(inds), _stream(dev))
     _lib.check(rc, "closest_pool_cat")
-    return out
+    return _tag(out, inds)
 
 
 def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev):
@@ -353,10 +435,10 @@ def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev):
     score = torch.empty((N, 1), dtype=torch.float32, device=dev)
     scratch = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
     rc = lib.d3f_detect_head(x.data_ptr(), N, ldx, Cc, nb.data_ptr(), ldi, nb.shape[1],
-                             stack_lengths_dev.data_ptr(), include_zero_dev.data_ptr(), B, desc.data_ptr(), Cc,
-                             score.data_ptr(), scratch.data_ptr(), _stream(dev))
+                             stack_lengths_dev.data_ptr(), include_zero_dev.data_ptr() if include_zero_dev is not None else None,
+                             B, desc.data_ptr(), Cc, score.data_ptr(), scratch.data_ptr(), _stream(dev))
     _lib.check(rc, "detect_head")
-    return desc, score
+    return _tag(desc, x), _tag(score, x)
 
 
 def affine_act(x, col_scale=None, col_shift=None, residual=None, leaky=False, alpha=0.2):
@@ -371,6 +453,6 @@ def affine_act(x, col_scale=None, col_shift=None, residual=None, leaky=False, al
     rc = lib.d3f_affine_act(x.data_ptr(), ldx, M, N, col_scale.data_ptr() if col_scale is not None else None,
                             col_shift.data_ptr() if col_shift is not None else None,
                             residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0, float(alpha),
-                            out.data_ptr(), N, _stream(x.device))
+                            out.data_ptr(), N, _nd(x), _stream(x.device))
     _lib.check(rc, "affine_act")
-    return out
+    return _tag(out, x)

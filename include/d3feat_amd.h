@@ -30,12 +30,26 @@ extern "C" {
 #define D3F_ST_NEG_CELL 2        /* floor((p-origin)/dl) < 0 (the reference's (size_t) cast would be UB, :52-54) */
 #define D3F_ST_KEY_RANGE 4       /* voxel key >= 2^56 */
 #define D3F_ST_HIT_OVERFLOW 8    /* a query has more in-radius supports than D3F_NEIGHBOR_CAP */
+#define D3F_ST_OUT_OVERFLOW 16   /* capacity mode: more output rows than the caller's buffer holds (nothing is written out of bounds) */
+
+/* pad_value of the neighbour searches meaning "the number of supports as known on the DEVICE" (sum of s_lens_dev) --
+ * what BatchOrderedNeighbors pads with (neighbors.cpp:324) when the host only knows an upper bound of Ns */
+#define D3F_PAD_NUM_SUPPORTS (-2147483647 - 1)
 
 #define D3F_MAX_BATCH 255        /* batch elements per stacked call */
 #define D3F_NEIGHBOR_CAP 1024    /* max in-radius supports per query that can be ordered */
 #define D3F_NUM_KP_MAX 16        /* kernel points per KPConv (reference uses 15) */
 
 int d3f_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident sizes ("capacity mode").  The reference's ops have data-dependent output sizes, which costs a host
+ * round trip per op (5 per fragment on this path).  Every entry point below therefore also works with sizes that live
+ * in HBM: the int size arguments are then UPPER BOUNDS (they size launch grids and buffers) and the real sizes are read on
+ * the device -- from the lens arrays for the preprocessing ops, from the optional `*_dev` pointers (NULL = use the host
+ * value) for the network ops.  A whole fragment is then a fixed launch sequence: captured once as a HIP graph, replayed
+ * for any cloud up to the capacity, with one status read-back at the end.
+ * ------------------------------------------------------------------------------------------- */
 
 /* ---------------------------------------------------------------------------------------------
  * Grid subsampling.
@@ -56,6 +70,17 @@ int d3f_version(void);
  * When a flag is raised the outputs are not computed.
  * ------------------------------------------------------------------------------------------- */
 size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int ldim);
+/* Capacity-mode form (points only): no host synchronisation.  `points` has N_cap rows of which sum(lens_dev) are valid;
+ * sub_points has M_cap rows; status_dev i32[2] (DEVICE) = [M, OR of D3F_ST_* flags]; M > M_cap raises
+ * D3F_ST_OUT_OVERFLOW.  Workspace: d3f_grid_subsample_workspace_bytes(N_cap, B, 0, 0). */
+int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* lens_dev, int B, float dl,
+                                   float* sub_points, int M_cap, int* sub_lens_dev, int* status_dev,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+/* The self-pair stacking of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:72-79:
+ * np.concatenate([pts, pts])) with the row count m read from HBM: out f32[2*M_cap,3] rows [0,m) and [m,2m) = pts[0,m);
+ * lens_out_dev i32[2] = [m, m]; total_dev i32[1] = 2m. */
+int d3f_stack_self_pair(const float* pts, int M_cap, const int* m_dev, float* out, int* lens_out_dev, int* total_dev,
+                        void* stream);
 int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
                              const float* features, int fdim, const int* classes, int ldim,
                              float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,
@@ -77,6 +102,8 @@ int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, in
  *                      [1] = OR of D3F_ST_* flags
  * `width` plays the role of datasets/common.py:399-406 (big_neighborhood_filter): pass the layer's
  * neighborhood limit; pass width = ld >= Kmax to get the untruncated matrix.
+ * Nq / Ns are upper bounds (buffer rows): the real counts are sum(q_lens_dev) / sum(s_lens_dev), read on the device.
+ * pad_value D3F_PAD_NUM_SUPPORTS pads with the device-side number of supports.
  * ------------------------------------------------------------------------------------------- */
 size_t d3f_radius_neighbors_workspace_bytes(int Nq, int Ns, int B);
 int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* supports, int Ns,
@@ -116,14 +143,15 @@ int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const 
  *   q f32[Nq,3]  s f32[Ns,3]  idx i32[Nq,ld_idx] (K columns used)  f f32[Ns,ldf] (Cin columns used)
  *   kp_host f32[num_kp,3] (HOST pointer: 45 floats passed by value to the kernel)  wf f32[Nq, num_kp*Cin]  inv_cnt f32[Nq]
  * Phase 2 is d3f_gemm_f32(wf, K_values reshaped [num_kp*Cin, Cout]) with row_scale = inv_cnt.
+ * Nq_dev / Ns_dev (device i32, may be NULL): real row counts when Nq / Ns are capacities (see "Device-resident sizes").
  * ------------------------------------------------------------------------------------------- */
 /* row_pos[s] = (sum_c f[s,c] > 0): the per-support test behind the neighbour count (:250-251), evaluated once
  * per support row.  row_pos u8[Ns]. */
-int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, void* stream);
+int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev, void* stream);
 int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                          const float* f, int ldf, int Cin, const unsigned char* row_pos, const float* kp_host,
                          int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
-                         void* stream);
+                         const int* Nq_dev, const int* Ns_dev, void* stream);
 
 /* Whole KPConv_ops (kernels/convolution_ops.py:161-255) + the fused inference epilogue for Cin = 1 -- the input
  * layer of every shipped model (`simple` block on the all-ones features, models/network_blocks.py:222-244):
@@ -132,7 +160,8 @@ int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const i
 int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                         const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
                         int aggregation, const float* W, int Cout, const float* col_scale, const float* col_shift,
-                        const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, void* stream);
+                        const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
+                        const int* Nq_dev, const int* Ns_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
@@ -148,7 +177,7 @@ size_t d3f_gemm_workspace_bytes(int M, int N, int K);
 int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                  const float* row_scale, const float* col_scale, const float* col_shift,
                  const float* residual, int ldr, int leaky, float alpha,
-                 void* workspace, size_t workspace_bytes, void* stream);
+                 void* workspace, size_t workspace_bytes, const int* M_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling / upsampling gathers.
@@ -158,21 +187,25 @@ int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int
  *   col_min_dev: f32[C] scratch written by d3f_ind_max_pool.
  * ------------------------------------------------------------------------------------------- */
 int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
-                     float* out, int ldo, float* col_min_dev, void* stream);
+                     float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev, void* stream);
 int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, const int* idx, int N2, int ld_idx,
-                         const float* skip, int lds, int C2, float* out, int ldo, void* stream);
+                         const float* skip, int lds, int C2, float* out, int ldo, const int* N1_dev, const int* N2_dev,
+                         void* stream);
 
 /* Stand-alone form of the GEMM epilogue (models/network_blocks.py:149-160 batch_norm in inference mode folded to
  * scale/shift, :185-186 leaky_relu, residual add):  out = act(x * col_scale + col_shift + residual). */
 int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale, const float* col_shift,
-                   const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, void* stream);
+                   const float* residual, int ldr, int leaky, float alpha, float* out, int ldo, const int* M_dev,
+                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * D3Feat head: descriptors + detection scores.  Replaces models/D3Feat.py:65-115.
  *   x f32[N,C] (ldx)  un-normalised output of last_unary;  idx i32[N,ld_idx] level-0 neighbours (K columns)
  *   lens_dev i32[B] points per stacked cloud (B = 2 in the reference, any B >= 1 here)
- *   include_zero_dev i32[B] (device): 1 if the cloud's row of in_batches contains the shadow index (so that
- *       the per-cloud maximum of :84-85 includes the zero row) -- datasets/common.py:453-496
+ *   include_zero_dev i32[B] (device) or NULL: 1 if the cloud's row of in_batches contains the shadow index (so that
+ *       the per-cloud maximum of :84-85 includes the zero row) -- datasets/common.py:453-496; NULL derives it from
+ *       lens_dev on the device (shorter than the longest cloud, or all clouds equally long)
+ *   N is an upper bound: the real point count is sum(lens_dev)
  *   desc f32[N,C] = l2_normalize(x, eps 1e-10);  score f32[N]
  *   scratch_dev: >= 2*B+2 ints of device scratch.  C <= 128.
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,112 @@
+"""The fragment engine (d3feat_amd/engine.py): whole fragment as one replayed HIP graph with device-resident sizes.
+Its results must not depend on the capacities: indices / points bit-equal to the eager op-by-op path, descriptors and
+scores equal up to fp32 summation order (the split-K plan of the contraction depends on the capacity), and within the
+1e-4 bar of the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(device):
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    cfg = threedmatch_config()
+    W = build_variables(cfg, seed=42, randomize_bn=True).values
+    limits = np.asarray([37, 35, 36, 38, 38], np.int32)
+    return cfg, W, limits
+
+
+def _frag(seed, n_raw=40000):
+    from d3feat_amd.utils.synthetic import room_fragment
+    return room_fragment(seed, n_raw=n_raw, edge=1.0)
+
+
+def _close(a, b, tol):
+    a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def test_engine_matches_eager_and_oracle(device, setup, coracle):
+    from d3feat_amd.engine import FragmentEngine
+    from oracle import network_np as onp
+    cfg, W, limits = setup
+    eng = FragmentEngine(cfg, W, limits, raw_cap=60000, n0_cap=14000, slots=2, device=device)
+    raws = [torch.from_numpy(_frag(s, n)).to(device) for s, n in ((7, 40000), (8, 30000), (9, 52000))]
+    # two fragments in flight, then a third reusing slot 0: the same graphs replayed for three different sizes
+    eng.submit(0, raws[0])
+    eng.submit(1, raws[1])
+    outs = [tuple(t.clone() for t in eng.fetch(0)), tuple(t.clone() for t in eng.fetch(1))]
+    outs.append(tuple(t.clone() for t in eng.run(raws[2], slot=0)))
+    assert eng.fallbacks == 0
+    for raw, (pts, d, s) in zip(raws, outs):
+        ep, ed, es = eng.run_eager(raw)
+        assert pts.shape == ep.shape and torch.equal(pts, ep)
+        _close(d, ed, 2e-6)
+        _close(s, es, 2e-6)
+    # against the oracle (pyramid + network) for the first fragment
+    raw = raws[0].cpu().numpy()
+    sub = coracle.grid_subsampling(raw, 0.03)
+    pts, d, s = outs[0]
+    assert np.array_equal(pts.cpu().numpy()[: len(sub)].view(np.uint32), sub.view(np.uint32))
+    inp = onp.descriptor_input(cfg, np.concatenate([sub, sub]), np.ones((2 * len(sub), 1), np.float32),
+                               np.asarray([len(sub)] * 2, np.int32), limits,
+                               lambda q, s_, ql, sl, r: coracle.batch_neighbors(q, s_, ql, sl, r),
+                               lambda p, l, dl: coracle.batch_grid_subsampling(p, l, dl))
+    want_d, want_s = onp.forward(cfg, W, inp)
+    assert np.abs(d.cpu().numpy() - want_d).max() <= 1e-4
+    assert np.abs(s.cpu().numpy() - want_s).max() <= 1e-4 * max(1.0, np.abs(want_s).max())
+
+
+def test_engine_capacity_overflow_falls_back(device, setup):
+    from d3feat_amd.engine import FragmentEngine
+    cfg, W, limits = setup
+    eng = FragmentEngine(cfg, W, limits, raw_cap=45000, n0_cap=3000, slots=1, device=device)
+    raw = torch.from_numpy(_frag(11, 40000)).to(device)          # ~10k voxels > n0_cap
+    pts, d, s = eng.run(raw)
+    assert eng.fallbacks == 1
+    ep, ed, es = eng.run_eager(raw)
+    assert torch.equal(pts, ep) and torch.equal(d, ed) and torch.equal(s, es)
+    big = torch.from_numpy(_frag(12, 50000)).to(device)          # more raw points than raw_cap
+    pts, d, s = eng.run(big)
+    assert eng.fallbacks == 2 and pts.shape[0] == d.shape[0] == s.shape[0]
+    small = torch.from_numpy(_frag(13, 1000)).to(device)         # fits: the graph is still healthy after fallbacks
+    pts, d, s = eng.run(small)
+    assert eng.fallbacks == 2
+    ep, ed, es = eng.run_eager(small)
+    assert torch.equal(pts, ep)
+    _close(d, ed, 2e-6)
+
+
+def test_capacity_mode_ops_match_sync_ops(device, coracle):
+    """The async subsample and the capacity-mode searches, op by op, against the oracle (bit-exact)."""
+    from d3feat_amd import ops
+    raw = _frag(21, 30000)
+    n = len(raw)
+    cap = 40000
+    buf = torch.zeros((cap, 3), dtype=torch.float32, device=device)
+    buf[:n] = torch.from_numpy(raw).to(device)
+    lens = torch.tensor([n], dtype=torch.int32, device=device)
+    sub, sub_l, st = ops.batch_grid_subsample_async(buf, lens, 0.03, 12000)
+    want = coracle.grid_subsampling(raw, 0.03)
+    m, flags = st.tolist()
+    assert flags == 0 and m == len(want) and sub_l.tolist() == [m]
+    assert np.array_equal(sub[:m].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # too small an output buffer: flagged, nothing written out of bounds
+    guard = torch.full((100 + 8, 3), 7.0, device=device)
+    sub2, _, st2 = ops.batch_grid_subsample_async(buf, lens, 0.03, 100)
+    assert st2.tolist()[1] & 16
+    pair, plens = ops.stack_self_pair(sub)
+    assert plens.tolist() == [m, m] and int(pair.n_dev.item()) == 2 * m
+    assert torch.equal(pair[:m], sub[:m]) and torch.equal(pair[m:2 * m], sub[:m])
+    grid = ops.NeighborGrid(pair, plens, 0.075)
+    out, status = grid.search(pair, plens, 37)
+    L = np.asarray([m, m], np.int32)
+    wn = coracle.batch_neighbors(np.concatenate([want, want]), np.concatenate([want, want]), L, L, np.float32(0.075))
+    got = out[: 2 * m].cpu().numpy()
+    k = min(37, wn.shape[1])
+    assert np.array_equal(got[:, :k], wn[:, :k])
+    assert status.tolist()[0] == wn.shape[1]
