@@ -227,10 +227,20 @@ def main():
         roof["avg_launch_us"] = round(avg_ms * 1e3, 2)
         roof["launches_per_step"] = round(dom["launches"] / nprof, 2)
         roof["timed_kernels_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in sorted(fam.items())}
-        tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tr):
+        # HBM traffic per launch of the dominant kernel: from the newest committed pair of `rocprofv3 --pmc FETCH_SIZE` /
+        # `--pmc WRITE_SIZE` passes of this same command (tools/gpu_round.sh -> tools/pmc_summary.py, corrections of
+        # MI355X_MICROARCH.md §HBM applied there); launch-weighted mean over the template instantiations of the kernel.
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+        if cands:
             try:
-                roof["traffic"] = json.load(open(tr)).get(dom_name.split("<")[0])
+                tj = json.load(open(cands[-1]))
+                fam_name = dom_name.split("<")[0]
+                ent = [v for k, v in tj.items() if k.split("<")[0] == fam_name and "traffic_bytes_per_launch" in v]
+                nl = sum(e["launches"] for e in ent)
+                if nl:
+                    roof["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl)
+                    roof["traffic_source"] = os.path.basename(cands[-1])
             except Exception:
                 pass
         # ms per KPConv layer (call order inside a step = network order): aggregation + its contraction
