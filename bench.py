@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
     ap.add_argument("--slots", type=int, default=3, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
     ap.add_argument("--eager", action="store_true", help="op-by-op eager path instead of the graph engine")
+    ap.add_argument("--raw-points", type=int, default=300000, help="raw points per synthetic fragment (config #2: 300k)")
+    ap.add_argument("--edge", type=float, default=1.68, help="room edge in metres (config #2: 1.68 -> ~30k pts at 0.03 m)")
     return ap.parse_args()
 
 
@@ -103,7 +105,7 @@ def main():
     W = build_variables(cfg, seed=42).values
     # synthetic fragments of this rank, raw points resident in HBM before timing starts
     seeds = [rank * 1000 + i for i in range(args.pool)]
-    raws_host = [room_fragment(s) for s in seeds]
+    raws_host = [room_fragment(s, n_raw=args.raw_points, edge=args.edge) for s in seeds]
     raws = [torch.from_numpy(r).to(device) for r in raws_host]
 
     # neighbourhood limits: calibrated like init_test_input_pipeline on this rank's pool, histograms summed over ranks

@@ -8,12 +8,14 @@
 //
 // v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, 64 cycles, exact fp32: bitwise an fmaf chain in k order) --
 // the 1e-4 parity bar is an fp32 bar, so the contraction stays in fp32 on the MFMA pipe (157 TF peak).
-// 256-thread workgroup = 4 wavefronts, each owning one 32x32 accumulator tile; workgroup tile 64x64 (2x2 waves)
-// or 128x32 (4x1, for Cout <= 32); BK = 32.  A and B tiles are staged through LDS (A rows padded to 33 floats:
+// 256-thread workgroup = 4 wavefronts, each owning TM x TN 32x32 accumulator tiles; workgroup tiles 128x128 (2x2 waves x
+// 2x2 tiles), 128x64, 64x64 or 128x32 (4x1 waves, for Cout <= 32), chosen per shape; BK = 32.  A and B tiles are staged through LDS (A rows padded to 33 floats:
 // the MFMA A fragment reads a column of the tile, 33 is odd so the 32 lanes hit 32 banks), next tile prefetched
 // into registers while the current one is multiplied.  Skinny problems (few output tiles, long K: the deep
 // KPConv layers) are split along K into slabs that a second kernel reduces in a fixed order (deterministic).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,18 +41,18 @@ __device__ __forceinline__ float gemm_epilogue(float v, int m, int n, const Gemm
     return v;
 }
 
-template <int WM, int WN>  // waves along M / N; WM*WN == 4
+template <int WM, int WN, int TM, int TN>  // waves along M / N (WM*WN == 4); 32x32 MFMA tiles per wave along M / N
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                 int M, int N, int K, int vecA, int vecB, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
                 const int* __restrict__ M_dev) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int A_F4 = BM * GM_BK / 4 / 256;  // float4 loads per thread for the A tile
+    constexpr int B_F4 = GM_BK * BN / 4 / 256;  // ... for the B tile (>= 1)
+    static_assert(WM * WN == 4 && A_F4 >= 1 && B_F4 >= 1, "tile shape");
     const int Mcap = M;                       // slab stride stays the capacity
     M = d3f_dyn(M, M_dev);
     if ((int)(blockIdx.x * BM) >= M) return;  // capacity-sized grid: row block beyond the real row count
-    constexpr int A_F4 = BM * GM_BK / 4 / 256;  // float4 loads per thread for the A tile
-    constexpr int B_F4 = GM_BK * BN / 4 / 256;  // ... for the B tile (>= 1)
-    static_assert(B_F4 >= 1, "tile too small");
     __shared__ float As[2][BM * GM_SA];                                 // double buffered: one barrier per k-tile
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * BN];
 
@@ -118,25 +120,36 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (t_begin < t_end) {
         load_tile(t_begin);
         store_tile(0);
     }
     __syncthreads();
-    const int arow = (wm * 32 + (lane & 31)) * GM_SA + (lane >> 5);
-    const int bcol = (lane >> 5) * BN + wn * 32 + (lane & 31);
+    // A fragment: lane reads column (k + lane/32) of row (lane%32) of its 32-row tile; B fragment: row (k + lane/32), col lane%32
+    const int arow = (wm * TM * 32 + (lane & 31)) * GM_SA + (lane >> 5);
+    const int bcol = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
         if (t + 1 < t_end) load_tile(t + 1);   // global -> registers, in flight while this tile is multiplied
 #pragma unroll
         for (int kk = 0; kk < GM_BK / 2; ++kk) {
-            const float a = As[cur][arow + kk * 2];
-            const float b = Bs[cur][bcol + kk * 2 * BN];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][arow + i * 32 * GM_SA + kk * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][bcol + j * 32 + kk * 2 * BN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < t_end) store_tile(cur ^ 1);
         __syncthreads();
@@ -144,13 +157,19 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
     }
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int gn = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (gm < M && gn < N) {
-            if (slab) slab[((size_t)blockIdx.z * Mcap + gm) * N + gn] = acc[r];
-            else C[(size_t)gm * ldc + gn] = gemm_epilogue(acc[r], gm, gn, E);
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gm < M && gn < N) {
+                    if (slab) slab[((size_t)blockIdx.z * Mcap + gm) * N + gn] = acc[i][j][r];
+                    else C[(size_t)gm * ldc + gn] = gemm_epilogue(acc[i][j][r], gm, gn, E);
+                }
+            }
         }
     }
 }
@@ -166,9 +185,16 @@ gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, f
     C[(size_t)m * ldc + n] = gemm_epilogue(v, m, n, E);
 }
 
+// Tile selection.  Large tiles (each wave owns 2x2 / 2x1 MFMA tiles: half the LDS traffic per flop, 4 independent
+// accumulator chains) when the problem still fills the chip with them; smaller tiles / split K for the skinny deep layers.
 static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
-    if (N <= 32) { bm = 128; bn = 32; } else { bm = 64; bn = 64; }
-    const long long blocks = (long long)d3f_cdiv(M, bm) * d3f_cdiv(N, bn);
+    const long long fill = 384;   // workgroups wanted before the tile may grow (256 CUs, 2 resident workgroups each)
+    auto blocks_of = [&](int m, int n) { return (long long)d3f_cdiv(M, m) * d3f_cdiv(N, n); };
+    if (N <= 32) { bm = 128; bn = 32; }
+    else if (N > 64 && blocks_of(128, 128) >= fill) { bm = 128; bn = 128; }
+    else if (blocks_of(128, 64) >= fill) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+    const long long blocks = blocks_of(bm, bn);
     const int nt = d3f_cdiv(K, GM_BK);
     // Skinny problems are latency bound per k-tile (global -> LDS -> MFMA): give every CU ~4 co-resident workgroups by
     // splitting K, as long as each split keeps >= 4 k-tiles.
@@ -179,6 +205,15 @@ static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
         S = (int)(want < maxs ? want : maxs);
         if (S > 64) S = 64;
         if (S < 1) S = 1;
+    }
+    // tuning knob (tools/gemm_bench.py): D3F_GEMM_FORCE="bm,bn,S" overrides the choice; unset in production
+    if (const char* f = getenv("D3F_GEMM_FORCE")) {
+        int fbm = 0, fbn = 0, fs = 0;
+        if (sscanf(f, "%d,%d,%d", &fbm, &fbn, &fs) == 3 && N > 32 &&
+            ((fbm == 128 && fbn == 128) || (fbm == 128 && fbn == 64) || (fbm == 64 && fbn == 64))) {
+            bm = fbm; bn = fbn;
+            S = fs < 1 ? 1 : (fs > nt ? nt : fs);
+        }
     }
     tps = d3f_cdiv(nt, S);
     S = d3f_cdiv(nt, tps);
@@ -212,10 +247,14 @@ extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, fl
     const int vecB = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
     if (d3f_cdiv(N, bn) > 65535) return D3F_ERR_ARG;
     dim3 grid(d3f_cdiv(M, bm), d3f_cdiv(N, bn), S);
-    if (bn == 32)
-        gemm_f32_kernel<4, 1><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, M_dev);
-    else
-        gemm_f32_kernel<2, 2><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, M_dev);
+#define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \
+    gemm_f32_kernel<WM_, WN_, TM_, TN_><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, \
+                                                                  M_dev)
+    if (bn == 32) D3F_GEMM(4, 1, 1, 1);
+    else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2);
+    else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1);
+    else D3F_GEMM(2, 2, 1, 1);
+#undef D3F_GEMM
     if (S > 1)
         gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
     D3F_LAUNCH_CHECK();

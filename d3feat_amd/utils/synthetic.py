@@ -25,7 +25,9 @@ def room_fragment(seed=0, n_raw=300000, edge=1.68, jitter=0.002):
         pts[m, o[0]] = uv[m, 0] * ext[o[0]]
         pts[m, o[1]] = uv[m, 1] * ext[o[1]]
     n_sph = n_raw - n_box
-    centers = np.stack([rng.uniform(0.5, ex - 0.5, 3), rng.uniform(0.5, ey - 0.5, 3), np.full(3, 0.3)], 1)
+    # sphere centres keep 0.5 m from the walls (rooms narrower than 1 m: on the centre line); same draws for edge >= 1
+    centers = np.stack([rng.uniform(min(0.5, ex / 2), max(ex - 0.5, ex / 2), 3),
+                        rng.uniform(min(0.5, ey / 2), max(ey - 0.5, ey / 2), 3), np.full(3, 0.3)], 1)
     which = rng.integers(0, 3, n_sph)
     d = rng.standard_normal((n_sph, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of d3f_gemm_f32 on the GEMM shapes of one 30k-point self-pair, HIP-event timed.
+    python tools/gemm_bench.py            # planner's choice
+    python tools/gemm_bench.py sweep      # every tile / split-K candidate per shape (tuning the planner)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from d3feat_amd import ops  # noqa: E402
+
+N0, N1, N2, N3, N4 = 58739, 14580, 3632, 905, 197
+SHAPES = [  # (M, K, N, count)
+    (N0, 64, 32, 1), (N0, 480, 32, 1), (N0, 32, 128, 1), (N0, 64, 128, 1), (N0, 128, 32, 1), (N1, 480, 32, 1), (N1, 32, 128, 1),
+    (N1, 128, 64, 1), (N1, 960, 64, 1), (N1, 64, 256, 1), (N1, 128, 256, 1), (N1, 256, 64, 1), (N2, 960, 64, 1), (N2, 64, 256, 1),
+    (N2, 256, 128, 1), (N2, 1920, 128, 1), (N2, 128, 512, 1), (N2, 256, 512, 1), (N2, 512, 128, 1), (N3, 1920, 128, 1),
+    (N3, 128, 512, 1), (N3, 512, 256, 1), (N3, 3840, 256, 1), (N3, 256, 1024, 1), (N3, 512, 1024, 1), (N3, 1024, 256, 1),
+    (N4, 3840, 256, 1), (N4, 256, 1024, 1), (N4, 1024, 512, 1), (N4, 7680, 512, 1), (N4, 512, 2048, 1), (N4, 1024, 2048, 1),
+    (N3, 3072, 512, 1), (N2, 1024, 256, 1), (N1, 512, 128, 1), (N0, 256, 64, 1), (N0, 64, 32, 1)]
+
+
+def time_one(A, B, reps=20):
+    for _ in range(3):
+        ops.gemm(A, B, leaky=True)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        ops.gemm(A, B, leaky=True)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3   # us
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    sweep = len(sys.argv) > 1 and sys.argv[1] == "sweep"
+    tot_us, tot_fl = 0.0, 0.0
+    for (M, K, N, cnt) in SHAPES:
+        A = torch.randn(M, K, device=dev)
+        B = torch.randn(K, N, device=dev)
+        fl = 2.0 * M * K * N
+        os.environ.pop("D3F_GEMM_FORCE", None)
+        us = time_one(A, B)
+        line = "M=%6d K=%5d N=%5d  plan %7.1f us %6.1f TF" % (M, K, N, us, fl / us / 1e6)
+        if sweep and N > 32:
+            best = (us, "plan")
+            for bm, bn in ((128, 128), (128, 64), (64, 64)):
+                for S in (1, 2, 4, 8, 16, 32):
+                    if S > max(1, K // 32 // 2):
+                        continue
+                    os.environ["D3F_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, S)
+                    u = time_one(A, B, reps=10)
+                    if u < best[0]:
+                        best = (u, "%dx%d S=%d" % (bm, bn, S))
+            line += "   best %7.1f us (%s)" % best
+            os.environ.pop("D3F_GEMM_FORCE", None)
+        print(line, flush=True)
+        tot_us += us
+        tot_fl += fl
+    print("total %.1f us for %.2f GFLOP = %.1f TF/s" % (tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
+
+
+if __name__ == "__main__":
+    main()
