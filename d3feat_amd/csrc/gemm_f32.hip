@@ -188,11 +188,11 @@ gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, f
 // Tile selection.  Large tiles (each wave owns 2x2 / 2x1 MFMA tiles: half the LDS traffic per flop, 4 independent
 // accumulator chains) when the problem still fills the chip with them; smaller tiles / split K for the skinny deep layers.
 static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
-    const long long fill = 384;   // workgroups wanted before the tile may grow (256 CUs, 2 resident workgroups each)
+    // Measured on MI355X over the network's 37 shapes (tools/gemm_bench.py sweep): these GEMMs are small (<= 3 GFLOP) and
+    // latency / bandwidth bound, so the 64x64 tile -- 33 KB of LDS, 4 workgroups resident per CU -- beats the register-
+    // tiled 128x128 / 128x64 variants everywhere; the larger tiles stay available through D3F_GEMM_FORCE for big problems.
     auto blocks_of = [&](int m, int n) { return (long long)d3f_cdiv(M, m) * d3f_cdiv(N, n); };
     if (N <= 32) { bm = 128; bn = 32; }
-    else if (N > 64 && blocks_of(128, 128) >= fill) { bm = 128; bn = 128; }
-    else if (blocks_of(128, 64) >= fill) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
     const long long blocks = blocks_of(bm, bn);
     const int nt = d3f_cdiv(K, GM_BK);

@@ -18,7 +18,7 @@
 //           into the wave's LDS segment with a ballot + popcount prefix (variable-length lists); the <=K hits
 //           are ordered by rank counting (each lane counts how many hits precede its own -- keys are unique so
 //           ranks are a permutation) and the first `width` ranks are stored straight into the output row.
-#include "common.h"
+#include "prims.h"
 
 struct NbElem {
     double mn[3];
@@ -31,9 +31,9 @@ struct NbElem {
 
 // one thread per element: choose the cell edge (>= radius*(1+2^-20); doubled until the element's grid fits
 // its share of the cell budget), grid dims and cell base.
-__global__ void nb_prep_kernel(const unsigned* __restrict__ bbox, const int* __restrict__ soffs, int B, float radius,
-                               long long cell_budget, NbElem* __restrict__ el, int* __restrict__ ncells_total) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void nb_prep(const unsigned* __restrict__ bbox, const int* __restrict__ soffs, int B, float radius,
+                                        long long cell_budget, NbElem* __restrict__ el, int* __restrict__ ncells_total) {
+    if (threadIdx.x != 0) return;
     long long base = 0;
     const long long per = cell_budget / B;
     for (int b = 0; b < B; ++b) {
@@ -46,8 +46,8 @@ __global__ void nb_prep_kernel(const unsigned* __restrict__ bbox, const int* __r
         } else {
             double mx[3];
             for (int d = 0; d < 3; ++d) {
-                e.mn[d] = (double)d3f_ord2f(bbox[b * 6 + d]);
-                mx[d] = (double)d3f_ord2f(bbox[b * 6 + 3 + d]);
+                e.mn[d] = (double)d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                mx[d] = (double)d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
             double h = (double)radius * (1.0 + 1.0 / 1048576.0);
             if (!(h > 0.0)) h = 1.0;
@@ -79,6 +79,12 @@ __global__ void nb_prep_kernel(const unsigned* __restrict__ bbox, const int* __r
     *ncells_total = (int)base;
 }
 
+// epilogue of the bounding-box kernel: the last workgroup derives the grid geometry from the finished boxes
+struct NbPrepEpi {
+    const unsigned* bbox; const int* soffs; int B; float radius; long long cell_budget; NbElem* el; int* ncells;
+    __device__ __forceinline__ void operator()() const { nb_prep(bbox, soffs, B, radius, cell_budget, el, ncells); }
+};
+
 __device__ __forceinline__ void nb_cell_of(const NbElem& e, float x, float y, float z, int& cx, int& cy, int& cz) {
     // monotone in each coordinate; (double)x - mn is exact for fp32 inputs of comparable magnitude
     cx = (int)floor(((double)x - e.mn[0]) * e.inv_h);
@@ -105,12 +111,13 @@ __global__ void __launch_bounds__(256) nb_count_kernel(const float* __restrict__
 
 __global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict__ s, int Ns, const int* __restrict__ ns_dev,
                                                          const int* __restrict__ cell_of,
-                                                         const int* __restrict__ cell_start, int* __restrict__ cell_cur,
+                                                         const int* __restrict__ cell_start, const int* __restrict__ cell_base,
+                                                         int* __restrict__ cell_cur,
                                                          float4* __restrict__ sorted, int* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(Ns, *ns_dev)) return;
     const int c = cell_of[i];
-    const int pos = cell_start[c] + atomicAdd(&cell_cur[c], 1);
+    const int pos = d3f_scan_at(cell_start, cell_base, c) + atomicAdd(&cell_cur[c], 1);
     sorted[pos] = make_float4(s[3 * (size_t)i], s[3 * (size_t)i + 1], s[3 * (size_t)i + 2], __int_as_float(i));
     order[pos] = i;
 }
@@ -121,8 +128,9 @@ __global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict
 // the wave-uniform run prefix), so a typical query needs two 64-wide candidate loads instead of 9+ dependent steps.
 template <bool FIRST_ONLY>
 __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
-nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qoffs, int B,
-                 const NbElem* __restrict__ el, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
+                 const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
+                 const float4* __restrict__ sorted,
                  const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
                  int ld, int width, int cap, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,11 +138,14 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qo
     float* hd2 = (float*)smem + (size_t)wave * 2 * cap;
     int* hidx = (int*)hd2 + cap;
     const int wq = blockIdx.x * NB_WAVES_PER_BLOCK + wave;
-    if (wq >= min(Nq, qoffs[B])) return;   // Nq is the capacity, qoffs[B] the real number of queries
+    int nq_real = 0;
+    for (int j = 0; j < B; ++j) nq_real += qlens[j];
+    if (wq >= min(Nq, nq_real)) return;   // Nq is the capacity, sum(qlens) the real number of queries
     if (pad == D3F_PAD_NUM_SUPPORTS) pad = *ns_dev;
     // queries that ARE the supports are visited in cell order: neighbouring waves then share their candidate runs in L2
     const int qi = qorder ? qorder[wq] : wq;
-    const int b = d3f_find_elem(qoffs, B, qi);
+    int b = 0;   // batch element of the query: the last one starting at or before qi (lens -> offsets on the fly, B is small)
+    for (int j = 1, start = qlens[0]; j < B; ++j) { if (qi >= start) b = j; start += qlens[j]; }
     const NbElem e = el[b];
     const float qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
     int cx, cy, cz;
@@ -150,7 +161,7 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qo
         const int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
         if (x0 <= x1 && y >= 0 && y < e.dims[1] && z >= 0 && z < e.dims[2]) {
             const int rowbase = e.cbase + e.dims[0] * (y + e.dims[1] * z);
-            bound = cell_start[rowbase + (lane < 9 ? x0 : x1 + 1)];
+            bound = d3f_scan_at(cell_start, cell_base, rowbase + (lane < 9 ? x0 : x1 + 1));
         }
     }
     const int hi_l = __shfl_down(bound, 9, 64);
@@ -243,7 +254,7 @@ static long long nb_cell_budget(int Ns) {
 
 // The grid object is a plain arena inside caller-owned memory; build and search carve it identically.
 struct NbGrid {
-    int* soffs; unsigned* bbox; NbElem* el; int* ncells; int* cell_cnt; int* cell_cur; int* cell_start; int* cell_of;
+    int* soffs; unsigned* bbox; NbElem* el; int* ncells; unsigned* counters; int* cell_cnt; int* cell_cur; int* cell_start; int* cell_of;
     float4* sorted; int* order; int* stmp;
     long long cells;
     bool ok;
@@ -257,13 +268,14 @@ static NbGrid nb_carve(void* ws, size_t bytes, int Ns, int B) {
     g.bbox = ar.take<unsigned>(B * 6);
     g.el = ar.take<NbElem>(B);
     g.ncells = ar.take<int>(16);
+    g.counters = (unsigned*)(g.ncells + 8);   // two ticket counters behind the cell count
     g.cell_cnt = ar.take<int>((size_t)g.cells * 2);   // [counts | cursors]: one memset
     g.cell_cur = g.cell_cnt ? g.cell_cnt + g.cells : nullptr;
     g.cell_start = ar.take<int>((size_t)g.cells);
     g.cell_of = ar.take<int>(ns);
     g.sorted = ar.take<float4>(ns);
     g.order = ar.take<int>(ns);
-    g.stmp = ar.take<int>(d3f_scan_tmp_ints((int)g.cells));
+    g.stmp = ar.take<int>(d3f_scan_base_ints((int)g.cells));
     g.ok = ar.ok;
     return g;
 }
@@ -276,7 +288,7 @@ extern "C" size_t d3f_neighbor_grid_bytes(int Ns, int B) {
     bytes += d3f_align((B + 1) * sizeof(int)) + d3f_align(B * 6 * sizeof(unsigned)) + d3f_align(B * sizeof(NbElem)) + d3f_align(64);
     bytes += d3f_align((size_t)cells * 2 * sizeof(int)) + d3f_align((size_t)cells * sizeof(int));
     bytes += 2 * d3f_align(ns * sizeof(int)) + d3f_align(ns * sizeof(float4));
-    bytes += d3f_align(d3f_scan_tmp_ints((int)cells) * sizeof(int));
+    bytes += d3f_align(d3f_scan_base_ints((int)cells) * sizeof(int));
     return bytes + 1024;
 }
 
@@ -288,20 +300,24 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
     NbGrid g = nb_carve(grid, grid_bytes, Ns, B);
     if (!g.ok) return D3F_ERR_WORKSPACE;
     int rc;
-    if ((rc = d3f_offsets_launch(s_lens_dev, B, g.soffs, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_bbox_launch(supports, g.soffs, B, Ns, g.bbox, stream)) != D3F_OK) return rc;
-    nb_prep_kernel<<<1, 64, 0, stream>>>(g.bbox, g.soffs, B, radius, nb_cell_budget(Ns), g.el, g.ncells);
-    // The cell arrays are sized for the whole budget; scanning all of it keeps the launch shapes static
-    // (no host read-back of the real cell count).  cell_start[c] for c >= ncells is the total count.
-    if ((rc = d3f_fill_u32(g.cell_cnt, (size_t)g.cells * 2, 0u, stream)) != D3F_OK) return rc;
+    // 5 launches: reset (offsets, boxes, tickets, cell counters) -> boxes (+ grid geometry in the last workgroup) ->
+    // histogram -> one-launch scan -> scatter.  The cell arrays are sized for the whole budget; scanning all of it keeps
+    // the launch shapes static (no host read-back of the real cell count).
+    const D3fFill none{nullptr, 0ull, 0u};
+    if ((rc = d3f_begin_launch(s_lens_dev, B, g.soffs, g.bbox, g.counters, 2,
+                               D3fFill{(unsigned*)g.cell_cnt, (unsigned long long)g.cells * 2ull, 0u}, none, none, none,
+                               stream)) != D3F_OK) return rc;
+    NbPrepEpi prep{g.bbox, g.soffs, B, radius, nb_cell_budget(Ns), g.el, g.ncells};
+    if ((rc = d3f_bbox_launch_t(supports, g.soffs, B, Ns, g.bbox, g.counters, prep, stream)) != D3F_OK) return rc;
     if (Ns > 0) {
         nb_count_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs, B, g.el, g.cell_of, g.cell_cnt);
         D3F_LAUNCH_CHECK();
     }
-    if ((rc = d3f_exclusive_scan_i32(g.cell_cnt, g.cell_start, (int)g.cells, g.stmp, nullptr, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_scan_fold_launch(D3fScanIn{g.cell_cnt}, (int)g.cells, g.cell_start, g.stmp, g.counters + 1, D3fNoEpi{},
+                                   stream)) != D3F_OK) return rc;
     if (Ns > 0) {
-        nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs + B, g.cell_of, g.cell_start, g.cell_cur,
-                                                                 g.sorted, g.order);
+        nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs + B, g.cell_of, g.cell_start, g.stmp,
+                                                                 g.cell_cur, g.sorted, g.order);
         D3F_LAUNCH_CHECK();
     }
     return D3F_OK;
@@ -310,31 +326,28 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
 extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
                                         const int* q_lens_dev, int B, float radius, int queries_are_supports,
                                         int* out, int ld, int width, int pad_value, int cap, int first_only,
-                                        int* status_dev, int* scratch_dev, void* stream_) {
+                                        int reset_status, int* status_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
     if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
-    if (!grid || !status_dev || !scratch_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
+    if (!grid || !status_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
     if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
-    { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
+    if (reset_status) { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
     if (Nq == 0) return D3F_OK;
     NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
     if (!g.ok) return D3F_ERR_WORKSPACE;
-    int rc;
-    int* qoffs = scratch_dev;  // B + 1 ints
-    if ((rc = d3f_offsets_launch(q_lens_dev, B, qoffs, stream)) != D3F_OK) return rc;
     const float r2 = radius * radius;
     const int blocks = d3f_cdiv(Nq, NB_WAVES_PER_BLOCK);
     const int* qorder = queries_are_supports ? g.order : nullptr;
     if (first_only) {
         nb_search_kernel<true><<<blocks, 64 * NB_WAVES_PER_BLOCK, 0, stream>>>(
-            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, 1,
-            status_dev);
+            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width,
+            1, status_dev);
     } else {
         const size_t lds = (size_t)NB_WAVES_PER_BLOCK * cap * 2 * sizeof(float);
         nb_search_kernel<false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(
-            queries, Nq, qoffs, B, g.el, g.cell_start, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, cap,
-            status_dev);
+            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width,
+            cap, status_dev);
     }
     D3F_LAUNCH_CHECK();
     return D3F_OK;
@@ -343,7 +356,7 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
 extern "C" size_t d3f_radius_neighbors_workspace_bytes(int Nq, int Ns, int B) {
     (void)Nq;
     if (Ns < 0 || B < 1) return 0;
-    return d3f_neighbor_grid_bytes(Ns, B) + d3f_align((B + 1) * sizeof(int)) + 256;
+    return d3f_neighbor_grid_bytes(Ns, B) + 256;
 }
 
 // One-shot form (build + search), the direct replacement of the BatchOrderedNeighbors op.
@@ -355,12 +368,9 @@ extern "C" int d3f_batch_radius_neighbors(const float* queries, int Nq, const fl
     if (!status_dev || !q_lens_dev || !s_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out))) || (Ns > 0 && !supports))
         return D3F_ERR_ARG;
     const size_t gb = d3f_neighbor_grid_bytes(Ns, B);
-    const size_t sb = d3f_align((B + 1) * sizeof(int));
-    if (!workspace || workspace_bytes < gb + sb) return D3F_ERR_WORKSPACE;
-    int* scratch = (int*)((char*)workspace + d3f_align(gb));
-    if (d3f_align(gb) + sb > workspace_bytes) return D3F_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < gb) return D3F_ERR_WORKSPACE;
     int rc = d3f_neighbor_grid_build(supports, Ns, s_lens_dev, B, radius, workspace, gb, stream_);
     if (rc != D3F_OK) return rc;
     return d3f_neighbor_grid_search(workspace, gb, Ns, queries, Nq, q_lens_dev, B, radius, 0, out, ld, width, pad_value,
-                                    D3F_NEIGHBOR_CAP, 0, status_dev, scratch, stream_);
+                                    D3F_NEIGHBOR_CAP, 0, 1, status_dev, stream_);
 }

@@ -117,7 +117,7 @@ class Dataset:
         layer_blocks = []
         input_points, input_neighbors, input_pools, input_upsamples, input_batches_len = [], [], [], [], []
         pending = []
-        status_all = torch.empty((64, 2), dtype=torch.int32, device=dev)
+        status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)   # one fill: the searches do not reset theirs
         arch = config.architecture
         cap = getattr(self, '_neighbor_cap', 192)
         grids = {}
@@ -132,7 +132,8 @@ class Dataset:
             grid = grids.get(key)
             if grid is None:
                 grid = grids[key] = ops.NeighborGrid(s, sl, r)
-            out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)])
+            out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)],
+                                      reset_status=False)
             pending.append(status)
             return out
 

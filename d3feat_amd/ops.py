@@ -245,8 +245,10 @@ class NeighborGrid:
                                          self.mem.data_ptr(), self.nbytes, _stream(dev))
         _lib.check(rc, "neighbor_grid_build")
 
-    def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None):
-        """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation."""
+    def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None,
+               reset_status=True):
+        """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation.  reset_status=False: the caller has
+        zeroed `status` (saves one launch per search)."""
         lib = _lib.load()
         queries = _req(queries, torch.float32, "queries", 2).contiguous()
         dev = queries.device
@@ -259,7 +261,6 @@ class NeighborGrid:
             out = torch.empty((Nq, ld), dtype=torch.int32, device=dev)
         if status is None:
             status = torch.empty((2,), dtype=torch.int32, device=dev)
-        scratch = torch.empty((self.B + 1,), dtype=torch.int32, device=dev)
         same = 1 if (queries.data_ptr() == self.supports.data_ptr() and Nq == self.Ns) else 0
         if pad_value is None:
             # BatchOrderedNeighbors pads with the number of supports: known only on the device in capacity mode
@@ -268,7 +269,8 @@ class NeighborGrid:
             rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
                                               ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),
                                               int(pad_value), int(cap),
-                                              1 if first_only else 0, status.data_ptr(), scratch.data_ptr(), _stream(dev))
+                                              1 if first_only else 0, 1 if reset_status else 0, status.data_ptr(),
+                                              _stream(dev))
         _lib.check(rc, "neighbor_grid_search")
         return _tag(out, queries), status
 

@@ -123,15 +123,16 @@ int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* suppor
  *       first_only            1: only column 0 (the nearest support, ties by index) is computed -- all that
  *                             closest_pool reads of the upsampling matrices (models/network_blocks.py:81);
  *                             columns 1..width-1 are filled with pad_value
- *       scratch_dev           >= B+1 ints
+ *       reset_status          1: status_dev is zeroed first (one extra launch); 0: the caller zeroed it (a captured
+ *                             fragment zeroes the status words of all its ops with one fill)
  */
 size_t d3f_neighbor_grid_bytes(int Ns, int B);
 int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev, int B, float radius,
                             void* grid, size_t grid_bytes, void* stream);
 int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
                              const int* q_lens_dev, int B, float radius, int queries_are_supports,
-                             int* out, int ld, int width, int pad_value, int cap, int first_only,
-                             int* status_dev, int* scratch_dev, void* stream);
+                             int* out, int ld, int width, int pad_value, int cap, int first_only, int reset_status,
+                             int* status_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * KPConv, phase 1: neighbour gather + kernel-point influence + weighted aggregation.
