@@ -21,7 +21,7 @@
 //     {bucket first-position (atomicMin), bucket sizes, reverse scan, rank inside bucket chain}, each fully
 //     parallel; one 1024-thread workgroup per batch element runs all rounds inside one launch (total work
 //     ~2M element-steps), batch elements in parallel.
-#include "common.h"
+#include "prims.h"
 
 #define GS_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GS_KEYBITS 56
@@ -51,9 +51,9 @@ __device__ __forceinline__ unsigned long long gs_mix(unsigned long long x) {
 }
 
 // ---- per-element origin / grid dims (grid_subsampling.cpp:24-30), one thread per element -------------
-__global__ void gs_prep_kernel(const unsigned* __restrict__ bbox, const int* __restrict__ offs, int B, float dl,
-                               GsElem* __restrict__ el, int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void gs_prep(const unsigned* __restrict__ bbox, const int* __restrict__ offs, int B, float dl,
+                                        GsElem* __restrict__ el, int* __restrict__ status) {
+    const int b = threadIdx.x;   // run by ONE 256-thread workgroup (B <= 255)
     if (b >= B) return;
     GsElem e;
     e.pad0 = 0;
@@ -67,8 +67,8 @@ __global__ void gs_prep_kernel(const unsigned* __restrict__ bbox, const int* __r
         float mx[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float mn = d3f_ord2f(bbox[b * 6 + d]);
-            mx[d] = d3f_ord2f(bbox[b * 6 + 3 + d]);
+            float mn = d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mx[d] = d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             e.org[d] = __fmul_rn(floorf(__fmul_rn(mn, inv)), dl);
         }
         e.NX = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(mx[0], e.org[0]), dl)) + 1ull;
@@ -86,11 +86,16 @@ __global__ void gs_prep_kernel(const unsigned* __restrict__ bbox, const int* __r
     e.bbase = base;
     el[b] = e;
 }
+// epilogue of the bounding-box kernel (last workgroup): origin / grid dims of every element from the finished boxes
+struct GsPrepEpi {
+    const unsigned* bbox; const int* offs; int B; float dl; GsElem* el; int* status;
+    __device__ __forceinline__ void operator()() const { gs_prep(bbox, offs, B, dl, el, status); }
+};
 
 // ---- voxel key per point + hash insert (grid_subsampling.cpp:49-59) ----------------------------------
 __global__ void __launch_bounds__(256) gs_insert_kernel(const float* __restrict__ pts, int N, const int* __restrict__ offs,
                                                         int B, float dl, const GsElem* __restrict__ el,
-                                                        unsigned long long* __restrict__ tkey, int* __restrict__ tfirst,
+                                                        unsigned long long* __restrict__ tkey, unsigned* __restrict__ tfirst,
                                                         unsigned long long capmask, int* __restrict__ slot,
                                                         int* __restrict__ status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,58 +119,72 @@ __global__ void __launch_bounds__(256) gs_insert_kernel(const float* __restrict_
         if (prev == GS_EMPTY || prev == word) break;
         h = (h + 1) & capmask;
     }
-    atomicMin(&tfirst[h], i);
+    atomicMin(&tfirst[h], (unsigned)i);
     slot[i] = (int)h;
 }
 
-__global__ void __launch_bounds__(256) gs_mark_kernel(int N, const int* __restrict__ n_dev, const int* __restrict__ slot,
-                                                      const int* __restrict__ tfirst, int* __restrict__ isfirst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) isfirst[i] = (i < *n_dev && tfirst[slot[i]] == i) ? 1 : 0;
-}
+// first-occurrence flag of point i, the input of the voxel-id scan (fused into the scan kernel)
+struct GsMarkIn {
+    const int* n_dev; const int* slot; const unsigned* tfirst;
+    __device__ __forceinline__ int operator()(int i) const { return (i < *n_dev && tfirst[slot[i]] == (unsigned)i) ? 1 : 0; }
+};
 
 // ---- voxel ids, voxel keys, per-voxel chains ----------------------------------------------------------
-__global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restrict__ slot, const int* __restrict__ tfirst,
+__global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restrict__ slot, const unsigned* __restrict__ tfirst,
                                                        const unsigned long long* __restrict__ tkey,
-                                                       const int* __restrict__ vscan, int* __restrict__ pvid,
+                                                       const int* __restrict__ vscan, const int* __restrict__ vbase,
+                                                       int* __restrict__ pvid,
                                                        unsigned long long* __restrict__ vkey, int* __restrict__ vhead,
                                                        int* __restrict__ vcnt, int* __restrict__ pnext,
                                                        const int* __restrict__ n_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(N, *n_dev)) return;
     const int s = slot[i];
-    const int fi = tfirst[s];
-    const int v = vscan[fi];
+    const int fi = (int)tfirst[s];
+    const int v = d3f_scan_at(vscan, vbase, fi);
     pvid[i] = v;
     if (fi == i) vkey[v] = tkey[s] & GS_KEYMASK;
     pnext[i] = atomicExch(&vhead[v], i);
     atomicAdd(&vcnt[v], 1);
 }
 
-__global__ void gs_moffs_kernel(const int* __restrict__ offs, int B, const int* __restrict__ vscan,
-                                int* __restrict__ status, int* __restrict__ moffs, int* __restrict__ sub_lens, int out_cap) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;   // B <= 255: one thread
-    const int M = status[0];
-    const int N = offs[B];
-    // vscan[offs[b]] = number of voxels created by points before element b (empty tail -> M)
-    for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : vscan[offs[b]];
-    // More voxels than the caller's output rows (capacity mode): flag it and report an EMPTY result, so that every
-    // downstream stage of a captured launch sequence runs on zero rows instead of on partially written ones.
-    const bool over = M > out_cap;
-    if (over) atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
-    for (int b = 0; b < B; ++b) sub_lens[b] = over ? 0 : moffs[b + 1] - moffs[b];
-}
+// epilogue of the voxel-id scan (last workgroup, total = M): per-element voxel offsets, the reported lengths and status
+struct GsMoffsEpi {
+    const int* offs; int B; const int* vscan; const int* vbase; int* meta; int* moffs; int* sub_lens; int* status_dev;
+    int out_cap;
+    __device__ __forceinline__ void operator()(int M) const {
+        if (threadIdx.x != 0) return;   // B <= 255: one thread
+        meta[0] = M;
+        const int N = offs[B];
+        // scan value at offs[b] = number of voxels created by points before element b (empty tail -> M)
+        for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : d3f_scan_at(vscan, vbase, offs[b]);
+        // More voxels than the caller's output rows (capacity mode): flag it and report an EMPTY result, so that every
+        // downstream stage of a captured launch sequence runs on zero rows instead of on partially written ones.
+        const bool over = M > out_cap;
+        if (over) atomicOr(&meta[1], D3F_ST_OUT_OVERFLOW);
+        for (int b = 0; b < B; ++b) {
+            const int l = over ? 0 : moffs[b + 1] - moffs[b];
+            meta[2 + b] = l;
+            sub_lens[b] = l;
+        }
+        if (status_dev) {
+            status_dev[0] = over ? 0 : M;   // rows valid in sub_points (none when it overflowed)
+            status_dev[1] = __hip_atomic_load(&meta[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
 
 // ---- rank of each point inside its voxel chain (= number of chain members with a smaller index) ----------
 __global__ void __launch_bounds__(256) gs_rank_kernel(int N, const int* __restrict__ n_dev, const int* __restrict__ pvid,
                                                       const int* __restrict__ vhead, const int* __restrict__ pnext,
-                                                      const int* __restrict__ vstart, int* __restrict__ sorted) {
+                                                      const int* __restrict__ vstart, const int* __restrict__ sbase,
+                                                      int* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(N, *n_dev)) return;
     const int v = pvid[i];
     int r = 0;
     for (int j = vhead[v]; j >= 0; j = pnext[j]) r += (j < i) ? 1 : 0;
-    sorted[vstart[v] + r] = i;
+    sorted[d3f_scan_at(vstart, sbase, v) + r] = i;
 }
 
 // ---- libstdc++ unordered_map iteration order (closed form, see file header) --------------------------
@@ -324,57 +343,8 @@ __global__ void __launch_bounds__(256) gs_order_insert_kernel(GsOrderArgs A, int
     A.bkt[o + t] = bk;
 }
 
-// tile-local reverse exclusive scan of c[t] = (t first of its bucket) ? bucket size : 0, over u = hi-1-t
-__global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A, int j) {
-    __shared__ int wsum[4];
-    const int b = blockIdx.y;
-    int M, lo, hi, nb;
-    bool last;
-    if (!gs_round(A, b, j, M, lo, hi, nb, last)) return;
-    const int tile = blockIdx.x;
-    if (tile * GS_TILE >= hi) return;
-    const int o = A.offs[b];
-    const long long bbase = A.el[b].bbase;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int c[4], s = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int u = tile * GS_TILE + tid * 4 + k, t = hi - 1 - u;
-        c[k] = 0;
-        if (u < hi) {
-            const int bk = A.bkt[o + t];
-            c[k] = (A.bf[j & 1][bbase + bk] == t) ? A.bc[j & 1][bbase + bk] : 0;
-        }
-        s += c[k];
-    }
-    int x = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int v = wsum[q];
-        if (q < w) wbase += v;
-        tot += v;
-    }
-    int run = wbase + x - s;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int u = tile * GS_TILE + tid * 4 + k;
-        if (u < hi) A.cd[o + hi - 1 - u] = run;
-        run += c[k];
-    }
-    if (tid == 0) A.tsum[o / GS_TILE + b + tile] = tot;
-}
-
-__global__ void __launch_bounds__(256) gs_order_scan_sums_kernel(GsOrderArgs A, int j) {
-    __shared__ int wsum[4];
-    const int b = blockIdx.x;
+// exclusive scan of one element's tile sums (run by ONE workgroup of 256 threads)
+__device__ __forceinline__ void gs_order_scan_sums(const GsOrderArgs& A, int j, int b, int* wsum) {
     int M, lo, hi, nb;
     bool last;
     if (!gs_round(A, b, j, M, lo, hi, nb, last)) return;
@@ -384,7 +354,7 @@ __global__ void __launch_bounds__(256) gs_order_scan_sums_kernel(GsOrderArgs A, 
     int carry = 0;
     for (int c0 = 0; c0 < ntiles; c0 += 256) {
         const int i = c0 + tid;
-        const int v = (i < ntiles) ? ts[i] : 0;
+        const int v = (i < ntiles) ? __hip_atomic_load(&ts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         int x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -403,6 +373,61 @@ __global__ void __launch_bounds__(256) gs_order_scan_sums_kernel(GsOrderArgs A, 
         __syncthreads();
         if (i < ntiles) ts[i] = carry + wbase + x - v;
         carry += tot;
+    }
+}
+
+// tile-local reverse exclusive scan of c[t] = (t first of its bucket) ? bucket size : 0, over u = hi-1-t; the last
+// workgroup of the launch then scans every element's tile sums (gs_order_place adds them)
+__global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A, int j, int B, unsigned* __restrict__ counter) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y;
+    int M, lo, hi, nb;
+    bool last;
+    const int tile = blockIdx.x;
+    const bool active = gs_round(A, b, j, M, lo, hi, nb, last) && tile * GS_TILE < hi;   // workgroup-uniform
+    if (active) {
+        const int o = A.offs[b];
+        const long long bbase = A.el[b].bbase;
+        const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+        int c[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = tile * GS_TILE + tid * 4 + k, t = hi - 1 - u;
+            c[k] = 0;
+            if (u < hi) {
+                const int bk = A.bkt[o + t];
+                c[k] = (A.bf[j & 1][bbase + bk] == t) ? A.bc[j & 1][bbase + bk] : 0;
+            }
+            s += c[k];
+        }
+        int x = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int v = wsum[q];
+            if (q < w) wbase += v;
+            tot += v;
+        }
+        int run = wbase + x - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = tile * GS_TILE + tid * 4 + k;
+            if (u < hi) A.cd[o + hi - 1 - u] = run;
+            run += c[k];
+        }
+        if (tid == 0) A.tsum[o / GS_TILE + b + tile] = tot;
+    }
+    if (!d3f_last_block(counter, gridDim.x * gridDim.y)) return;
+    for (int e = 0; e < B; ++e) {
+        __syncthreads();
+        gs_order_scan_sums(A, j, e, wsum);
     }
 }
 
@@ -440,13 +465,14 @@ __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int 
 __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__ pts, const float* __restrict__ feat,
                                                        int fdim, int* __restrict__ status,
                                                        const int* __restrict__ moffs, int B,
-                                                       const int* __restrict__ vstart, const int* __restrict__ vcnt,
+                                                       const int* __restrict__ vstart, const int* __restrict__ sbase,
+                                                       const int* __restrict__ vcnt,
                                                        const int* __restrict__ sorted, const int* __restrict__ vpos,
                                                        float* __restrict__ out_p, float* __restrict__ out_f, int out_cap) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= status[0]) return;
     const int b = d3f_find_elem(moffs, B, v);
-    const int n = vcnt[v], st = vstart[v];
+    const int n = vcnt[v], st = d3f_scan_at(vstart, sbase, v);
     const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
     if (dest >= (size_t)out_cap) {   // more voxels than the caller's output rows (capacity mode): report, never write
         atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
@@ -519,15 +545,8 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     bytes += 14 * d3f_align(n * sizeof(int));               // slot vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx cd bkt
     bytes += 6 * d3f_align((size_t)L.bucket_total * sizeof(int));
     bytes += d3f_align((n / GS_TILE + B + 8) * sizeof(int));
-    bytes += d3f_align(d3f_scan_tmp_ints(N) * sizeof(int));
+    bytes += 2 * d3f_align(d3f_scan_base_ints(N) * sizeof(int)) + d3f_align(64 * sizeof(unsigned));
     return bytes + 4096;
-}
-
-__global__ void gs_status_kernel(const int* __restrict__ meta, int out_cap, int* __restrict__ status_dev) {
-    if (threadIdx.x == 0) {
-        status_dev[0] = meta[0] > out_cap ? 0 : meta[0];   // rows valid in sub_points (none when it overflowed)
-        status_dev[1] = meta[1];
-    }
 }
 
 // Shared implementation.  sync mode (status_host != NULL): ONE host synchronisation after the voxel count is known,
@@ -544,17 +563,19 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     const size_t n = (size_t)N;
     int* offs = ar.take<int>(B + 1);
     int* moffs = ar.take<int>(B + 1);
-    int* meta = ar.take<int>(B + 2);   // [M, flags, sub_lens...]
     unsigned* bbox = ar.take<unsigned>(B * 6);
     GsElem* el = ar.take<GsElem>(B);
+    unsigned* counters = ar.take<unsigned>(64);   // ticket counters: [0] boxes, [1] voxel-id scan, [2] start scan, [4 + j] round j
+    // [tkey | tfirst | vhead] are reset to 0xFFFFFFFF and [meta | vcnt] to 0 by ONE launch: keep each group contiguous
     unsigned long long* tkey = ar.take<unsigned long long>(L.cap);
-    int* tfirst = ar.take<int>(L.cap);
+    unsigned* tfirst = ar.take<unsigned>(L.cap);
+    int* vhead = ar.take<int>(n);
+    int* meta = ar.take<int>(B + 2);   // [M, flags, sub_lens...]
+    int* vcnt = ar.take<int>(n);
     unsigned long long* vkey = ar.take<unsigned long long>(n);
     int* slot = ar.take<int>(n);
     int* vscan = ar.take<int>(n);
     int* pvid = ar.take<int>(n);
-    int* vhead = ar.take<int>(n);
-    int* vcnt = ar.take<int>(n);
     int* pnext = ar.take<int>(n);
     int* vstart = ar.take<int>(n);
     int* sorted = ar.take<int>(n);
@@ -571,26 +592,31 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         A.bh[k] = ar.take<int>((size_t)L.bucket_total);
     }
     A.tsum = ar.take<int>(n / GS_TILE + B + 8);
-    int* stmp = ar.take<int>(d3f_scan_tmp_ints(N));
+    int* vbase = ar.take<int>(d3f_scan_base_ints(N));   // tile offsets of the voxel-id scan
+    int* sbase = ar.take<int>(d3f_scan_base_ints(N));   // ... of the voxel-start scan
     if (!ar.ok) return D3F_ERR_WORKSPACE;
     A.vkey = vkey; A.moffs = moffs; A.offs = offs; A.el = el;
     A.max_m = async ? (N < M_cap ? N : M_cap) : 0x7fffffff;
 
+    // 9 + 3 * rounds launches (was 27 + 4 * rounds): reset -> boxes (+ grid geometry) -> keys / hash insert ->
+    // voxel-id scan (first-occurrence flags fused in, per-element offsets / lengths / status in its last workgroup) ->
+    // chains -> start scan -> in-chain rank -> iteration order (small rounds in one workgroup, large rounds grid-wide) ->
+    // in-order accumulation.
     int rc;
-    if ((rc = d3f_fill_u32(meta, B + 2, 0u, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_offsets_launch(lens_dev, B, offs, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_bbox_launch(points, offs, B, N, bbox, stream)) != D3F_OK) return rc;
-    gs_prep_kernel<<<d3f_cdiv(B, 64), 64, 0, stream>>>(bbox, offs, B, dl, el, meta);
-    if ((rc = d3f_fill_u32(tkey, L.cap * 2, 0xFFFFFFFFu, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_fill_u32(tfirst, L.cap, 0x7F7F7F7Fu, stream)) != D3F_OK) return rc;  // > any index
+    const D3fFill none{nullptr, 0ull, 0u};
+    const unsigned long long ones_words = (unsigned long long)((char*)(vhead + n) - (char*)tkey) / 4ull;
+    const unsigned long long zero_words = (unsigned long long)((char*)(vcnt + n) - (char*)meta) / 4ull;
+    if ((rc = d3f_begin_launch(lens_dev, B, offs, bbox, counters, 64, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
+                               D3fFill{(unsigned*)meta, zero_words, 0u}, none, none, stream)) != D3F_OK) return rc;
+    GsPrepEpi prep{bbox, offs, B, dl, el, meta};
+    if ((rc = d3f_bbox_launch_t(points, offs, B, N, bbox, counters, prep, stream)) != D3F_OK) return rc;
     const int nblk = d3f_cdiv(N, 256);
     gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
                                                slot, meta);
-    gs_mark_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, slot, tfirst, vscan);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_exclusive_scan_i32(vscan, vscan, N, stmp, &meta[0], stream)) != D3F_OK) return rc;
-    gs_moffs_kernel<<<1, 64, 0, stream>>>(offs, B, vscan, meta, moffs, meta + 2, M_cap);
-    if ((rc = d3f_copy_i32(sub_lens_dev, meta + 2, B, stream)) != D3F_OK) return rc;
+    GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap};
+    if ((rc = d3f_scan_fold_launch(GsMarkIn{offs + B, slot, tfirst}, N, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
+        return rc;
     int M, maxM;       // sizes of the voxel-indexed launches
     if (!async) {
         // The output size is data dependent (as for the reference op, whose output tensor is allocated after the
@@ -607,12 +633,11 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         maxM = M;
     }
 
-    if ((rc = d3f_fill_u32(vhead, (size_t)(async ? N : M), 0xFFFFFFFFu, stream)) != D3F_OK) return rc;
-    if ((rc = d3f_fill_u32(vcnt, (size_t)(async ? N : M), 0u, stream)) != D3F_OK) return rc;
-    gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, pvid, vkey, vhead, vcnt, pnext, offs + B);
+    gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, vbase, pvid, vkey, vhead, vcnt, pnext, offs + B);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_exclusive_scan_i32(vcnt, vstart, async ? N : M, stmp, nullptr, stream)) != D3F_OK) return rc;
-    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sorted);
+    if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
+        return rc;
+    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
     // ---- libstdc++ iteration order ----
     gs_order_small_kernel<<<B, 1024, 0, stream>>>(A);
     for (int j = GS_SMALL_LAST + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
@@ -620,18 +645,16 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         const int hi = (int)((long long)maxM < nbj ? (long long)maxM : nbj);
         dim3 g(d3f_cdiv(hi, 256), B), gt(d3f_cdiv(hi, GS_TILE), B);
         gs_order_insert_kernel<<<g, 256, 0, stream>>>(A, j);
-        gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j);
-        gs_order_scan_sums_kernel<<<B, 256, 0, stream>>>(A, j);
+        gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j);
         gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
     }
-    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, vcnt,
-                                                                     sorted, A.vpos, sub_points, sub_features, M_cap);
+    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
+                                                                     vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
     if (ldim > 0) {
         const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);
         gs_labels_kernel<<<nblk, 256, 0, stream>>>(N, ldim, classes, pvid, moffs, B, A.vpos, sub_classes);
     }
-    if (async) gs_status_kernel<<<1, 64, 0, stream>>>(meta, M_cap, status_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -39,7 +39,7 @@ __device__ __forceinline__ bool d3f_last_block(unsigned* counter, unsigned nbloc
 
 // offs[0..B] = prefix sums of lens; bbox[b*6 + {0,1,2}] = 0xFFFFFFFF (min slots), {3,4,5} = 0 (max slots); counters = 0;
 // fills f0..f3 (n = 0: unused).  Any grid size; 256 threads.
-__global__ void __launch_bounds__(256) begin_kernel(const int* __restrict__ lens, int B, int* __restrict__ offs,
+static __global__ void __launch_bounds__(256) begin_kernel(const int* __restrict__ lens, int B, int* __restrict__ offs,
                                                     unsigned* __restrict__ bbox, unsigned* __restrict__ counters,
                                                     int ncounters, D3fFill f0, D3fFill f1, D3fFill f2, D3fFill f3) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
