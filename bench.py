@@ -29,6 +29,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The engine keeps several fragments in flight on separate HIP streams; by default the ROCm runtime multiplexes all
+# streams of a process onto 4 hardware queues.  Must be set before the HIP runtime initialises (i.e. before torch).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
@@ -42,8 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-fragments", type=int, default=2)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
-    ap.add_argument("--slots", type=int, default=3, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
+    ap.add_argument("--slots", type=int, default=4, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
     ap.add_argument("--eager", action="store_true", help="op-by-op eager path instead of the graph engine")
+    ap.add_argument("--no-instrument", action="store_true", help="skip the per-launch HIP-event pass (clean rocprof runs)")
     ap.add_argument("--raw-points", type=int, default=300000, help="raw points per synthetic fragment (config #2: 300k)")
     ap.add_argument("--edge", type=float, default=1.68, help="room edge in metres (config #2: 1.68 -> ~30k pts at 0.03 m)")
     return ap.parse_args()
@@ -133,7 +137,8 @@ def main():
         from d3feat_amd.engine import FragmentEngine
         raw_cap = int(max(r.shape[0] for r in raws) * 1.05) + 1024
         n0_cap = (int(max(len(x) for x in subs) * 1.3) + 1023) // 1024 * 1024
-        engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, slots=args.slots, device=device)
+        engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, slots=args.slots, device=device,
+                                n0_hint=int(np.mean([len(x) for x in subs])))
 
     def run(nsteps):
         """nsteps fragments through the hot path; returns the last fragment's (pts, desc, score)."""
@@ -174,7 +179,7 @@ def main():
 
     # ---- instrumented pass (untimed): per-launch HIP events on the launch stream --------------------------------
     layers, roof = None, None
-    if rank == 0:
+    if rank == 0 and not args.no_instrument:
         nprof = max(3, min(args.steps, 8))
         ops.PROFILE = []
         for i in range(nprof):

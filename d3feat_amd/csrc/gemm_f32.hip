@@ -52,15 +52,17 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
     static_assert(WM * WN == 4 && A_F4 >= 1 && B_F4 >= 1, "tile shape");
     const int Mcap = M;                       // slab stride stays the capacity
     M = d3f_dyn(M, M_dev);
-    if ((int)(blockIdx.x * BM) >= M) return;  // capacity-sized grid: row block beyond the real row count
+    // grid = (n tiles, k splits, m tiles): the row tile is the SLOWEST dispatch dimension, so in capacity mode the live
+    // workgroups are the first contiguous run of the dispatch order (dense over XCDs / CUs) and the empty ones trail
+    if ((int)(blockIdx.z * BM) >= M) return;  // capacity-sized grid: row block beyond the real row count
     __shared__ float As[2][BM * GM_SA];                                 // double buffered: one barrier per k-tile
     __shared__ __attribute__((aligned(16))) float Bs[2][GM_BK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // x walks M: neighbouring blocks share the B panel in L2
+    const int m0 = blockIdx.z * BM, n0 = blockIdx.x * BN;  // neighbouring workgroups share the A row tile in L2
     const int nt_all = (K + GM_BK - 1) / GM_BK;
-    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_begin = blockIdx.y * tiles_per_split;
     const int t_end = min(nt_all, t_begin + tiles_per_split);
 
     float4 ra[A_F4], rb[B_F4];
@@ -166,7 +168,7 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (gm < M && gn < N) {
-                    if (slab) slab[((size_t)blockIdx.z * Mcap + gm) * N + gn] = acc[i][j][r];
+                    if (slab) slab[((size_t)blockIdx.y * Mcap + gm) * N + gn] = acc[i][j][r];
                     else C[(size_t)gm * ldc + gn] = gemm_epilogue(acc[i][j][r], gm, gn, E);
                 }
             }
@@ -187,7 +189,10 @@ gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, f
 
 // Tile selection.  Large tiles (each wave owns 2x2 / 2x1 MFMA tiles: half the LDS traffic per flop, 4 independent
 // accumulator chains) when the problem still fills the chip with them; smaller tiles / split K for the skinny deep layers.
-static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
+static void gemm_plan(int M, int N, int K, int M_hint, int& bm, int& bn, int& S, int& tps) {
+    // capacity mode: M is only an upper bound; split K for the row count the caller EXPECTS (skinny deep layers would
+    // otherwise be planned as if they filled the chip and run their whole K loop in a handful of workgroups)
+    if (M_hint > 0 && M_hint < M) M = M_hint;
     // Measured on MI355X over the network's 37 shapes (tools/gemm_bench.py sweep): these GEMMs are small (<= 3 GFLOP) and
     // latency / bandwidth bound, so the 64x64 tile -- 33 KB of LDS, 4 workgroups resident per CU -- beats the register-
     // tiled 128x128 / 128x64 variants everywhere; the larger tiles stay available through D3F_GEMM_FORCE for big problems.
@@ -219,24 +224,24 @@ static void gemm_plan(int M, int N, int K, int& bm, int& bn, int& S, int& tps) {
     S = d3f_cdiv(nt, tps);
 }
 
-extern "C" size_t d3f_gemm_workspace_bytes(int M, int N, int K) {
+extern "C" size_t d3f_gemm_workspace_bytes(int M, int N, int K, int M_hint) {
     if (M <= 0 || N <= 0 || K <= 0) return 256;
     int bm, bn, S, tps;
-    gemm_plan(M, N, K, bm, bn, S, tps);
+    gemm_plan(M, N, K, M_hint, bm, bn, S, tps);
     return S > 1 ? d3f_align((size_t)S * M * N * sizeof(float)) + 256 : 256;
 }
 
 extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                             const float* row_scale, const float* col_scale, const float* col_shift,
                             const float* residual, int ldr, int leaky, float alpha,
-                            void* workspace, size_t workspace_bytes, const int* M_dev, void* stream_) {
+                            void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || N < 0 || K < 0 || lda < K || ldb < N || ldc < N || (residual && ldr < N)) return D3F_ERR_ARG;
     if (M == 0 || N == 0) return D3F_OK;
     if (!C || (K > 0 && (!A || !B))) return D3F_ERR_ARG;
     GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
     int bm, bn, S, tps;
-    gemm_plan(M, N, K > 0 ? K : 1, bm, bn, S, tps);
+    gemm_plan(M, N, K > 0 ? K : 1, M_hint, bm, bn, S, tps);
     float* slab = nullptr;
     if (S > 1) {
         const size_t need = (size_t)S * M * N * sizeof(float);
@@ -245,8 +250,8 @@ extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, fl
     }
     const int vecA = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
     const int vecB = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
-    if (d3f_cdiv(N, bn) > 65535) return D3F_ERR_ARG;
-    dim3 grid(d3f_cdiv(M, bm), d3f_cdiv(N, bn), S);
+    if (d3f_cdiv(M, bm) > 65535) return D3F_ERR_ARG;
+    dim3 grid(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm));
 #define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \
     gemm_f32_kernel<WM_, WN_, TM_, TN_><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, \
                                                                   M_dev)

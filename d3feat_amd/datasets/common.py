@@ -156,8 +156,10 @@ class Dataset:
             if 'pool' in block or 'strided' in block:
                 dl = 2 * r_normal / (config.KP_extent * 2.5)
                 if caps is not None:
+                    hints = getattr(self, 'hints', None)
                     pool_p, pool_b, _ = ops.batch_grid_subsample_async(stacked_points, stacked_lengths, dl, caps[layer + 1],
-                                                                       status=status_all[len(pending)])
+                                                                       status=status_all[len(pending)],
+                                                                       m_hint=hints[layer + 1] if hints else 0)
                     pending.append(status_all[len(pending)])
                 else:
                     pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)
@@ -298,6 +300,7 @@ class FragmentDataset(Dataset):
         self.num_test = len(clouds)
         self.fast = fast
         self.caps = None      # per-level row capacities: capacity mode of tf_descriptor_input (see d3feat_amd.engine)
+        self.hints = None     # per-level expected row counts (launch planning only)
 
     def get_batch_gen(self, split, config):
         def gen():

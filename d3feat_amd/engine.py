@@ -24,13 +24,23 @@ from .datasets.common import FragmentDataset
 from .models.KPFCNN_model import KernelPointFCNN
 
 
-def level_caps(n0_cap, num_layers, ratio=0.5):
+def level_caps(n0_cap, num_layers, ratio=0.4):
     """Row capacities of the stacked self-pair pyramid: level 0 holds 2*n0_cap rows, every further level `ratio` of the
-    previous (grid subsampling at a doubled cell size keeps ~1/4 of surface samples; 1/2 leaves a wide margin)."""
+    previous.  Grid subsampling at a doubled cell size keeps ~0.25-0.27 of surface samples; a cloud that
+    exceeds a capacity is flagged on the device and recomputed by the eager path, so the ratio trades memory / idle
+    workgroups against fallbacks, never correctness."""
     caps = [2 * int(n0_cap)]
     for _ in range(1, num_layers):
         caps.append(max(int(np.ceil(caps[-1] * ratio)), 256))
     return caps
+
+
+def level_hints(n0_hint, num_layers, ratio=0.26):
+    """Expected row counts per level (launch planning only, e.g. the K split of the skinny deep-layer contractions)."""
+    h = [2 * int(n0_hint)]
+    for _ in range(1, num_layers):
+        h.append(max(int(h[-1] * ratio), 64))
+    return h
 
 
 class _Slot:
@@ -38,14 +48,16 @@ class _Slot:
 
 
 class FragmentEngine:
-    def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.5, slots=2,
-                 device=None, seed=42):
+    def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
+                 device=None, seed=42, n0_hint=None):
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.device = config, device
         self.limits = np.asarray(neighborhood_limits, np.int32)
         self.raw_cap, self.n0_cap = int(raw_cap), int(n0_cap)
         self.caps = level_caps(n0_cap, config.num_layers, level_ratio)
+        self.n0_hint = int(n0_hint if n0_hint is not None else n0_cap / 1.3)
+        self.hints = level_hints(self.n0_hint, config.num_layers)
         self.model = KernelPointFCNN(None, config, weights=weights, seed=seed, device=device)
         # eager fallback path (also the warm-up that uploads the weights before any capture)
         self._eager_ds = FragmentDataset([], fast=True)
@@ -59,7 +71,7 @@ class FragmentEngine:
     def _sequence(self, sl):
         cfg = self.cfg
         sub, _, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.n0_cap,
-                                                     status=sl.status0)
+                                                     status=sl.status0, m_hint=self.n0_hint)
         pts, lens = ops.stack_self_pair(sub)
         flat = sl.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
@@ -77,6 +89,7 @@ class FragmentEngine:
         sl.ds.device = dev
         sl.ds.neighborhood_limits = self.limits
         sl.ds.caps = self.caps
+        sl.ds.hints = self.hints
         sl.map = sl.ds.get_tf_mapping(self.cfg)
         sl.busy = False
         sl.n_raw = 0

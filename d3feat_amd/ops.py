@@ -53,6 +53,7 @@ def _tag(out, src):
     d = getattr(src, "n_dev", None)
     if d is not None:
         out.n_dev = d
+        out.n_hint = getattr(src, "n_hint", 0)   # expected row count (host int): plans launches, never bounds them
     return out
 
 
@@ -185,7 +186,7 @@ def batch_grid_subsample(points, lens, dl, features=None, classes=None):
     return sub_p[:M], sub_l, (sub_f[:M] if fdim else None), (sub_c[:M] if ldim else None)
 
 
-def batch_grid_subsample_async(points, lens, dl, m_cap, status=None):
+def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0):
     """Capacity mode of batch_grid_subsample (points only): no host synchronisation.
     points f32[N_cap,3] (sum(lens) rows valid) -> (sub_points f32[m_cap,3] tagged with n_dev, sub_lens i32[B] device,
     status i32[2] device = [M, flags])."""
@@ -206,6 +207,7 @@ def batch_grid_subsample_async(points, lens, dl, m_cap, status=None):
                                             _stream(dev))
     _lib.check(rc, "batch_grid_subsample_async")
     sub_p.n_dev = status[0:1]
+    sub_p.n_hint = int(m_hint)
     return sub_p, sub_l, status
 
 
@@ -225,6 +227,7 @@ def stack_self_pair(pts):
                                  _stream(dev))
     _lib.check(rc, "stack_self_pair")
     out.n_dev = total
+    out.n_hint = 2 * int(getattr(pts, "n_hint", 0) or 0)
     return out, lens
 
 
@@ -308,7 +311,8 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
             _req(v, torch.float32, name)
             if v.numel() != n or not v.is_contiguous():
                 raise ValueError("%s must be a contiguous vector of %d" % (name, n))
-    nbytes = lib.d3f_gemm_workspace_bytes(M, N, K)
+    hint = int(getattr(A, "n_hint", 0) or 0)
+    nbytes = lib.d3f_gemm_workspace_bytes(M, N, K, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=K), dev):
         rc = lib.d3f_gemm_f32(A.data_ptr(), lda, Bm.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
@@ -316,7 +320,7 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
                               col_scale.data_ptr() if col_scale is not None else None,
                               col_shift.data_ptr() if col_shift is not None else None,
                               residual.data_ptr() if residual is not None else None, ldr,
-                              1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _nd(A), _stream(dev))
+                              1 if leaky else 0, float(alpha), ws.data_ptr(), ws.numel(), _nd(A), hint, _stream(dev))
     _lib.check(rc, "gemm_f32")
     return _tag(out, A)
 

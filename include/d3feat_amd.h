@@ -173,12 +173,14 @@ int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const in
  * row_scale / col_scale / col_shift / residual may be NULL (identity); act = LeakyReLU(alpha) when
  * leaky != 0.  A f32[M,K] (lda), B f32[K,N] (ldb), C f32[M,N] (ldc), residual f32[M,N] (ldr).
  * workspace is used only when the call decides to split K (skinny shapes).
+ * M_dev (device i32, may be NULL): real row count when M is a capacity; M_hint (0 = none): the row count the caller
+ * expects, used only to plan the K split (pass the same value to d3f_gemm_workspace_bytes).
  * ------------------------------------------------------------------------------------------- */
-size_t d3f_gemm_workspace_bytes(int M, int N, int K);
+size_t d3f_gemm_workspace_bytes(int M, int N, int K, int M_hint);
 int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                  const float* row_scale, const float* col_scale, const float* col_shift,
                  const float* residual, int ldr, int leaky, float alpha,
-                 void* workspace, size_t workspace_bytes, const int* M_dev, void* stream);
+                 void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling / upsampling gathers.

@@ -82,11 +82,11 @@ def test_exports_are_unmangled_c_symbols(lib):
 def test_host_side_argument_checks_need_no_gpu(lib):
     """Entry points validate sizes before touching the device: invalid arguments come back as D3F_ERR_ARG."""
     assert lib.d3f_version() >= 100
-    assert lib.d3f_gemm_f32(None, 0, None, 0, None, 0, -1, 4, 4, None, None, None, None, 0, 0, 0.2, None, 0, None, None) == -3
+    assert lib.d3f_gemm_f32(None, 0, None, 0, None, 0, -1, 4, 4, None, None, None, None, 0, 0, 0.2, None, 0, None, 0, None) == -3
     assert lib.d3f_batch_grid_subsample(None, 10, None, 1, 0.1, None, 0, None, 0, None, None, None, None, None, None, 0, None) == -3
     assert lib.d3f_neighbor_grid_build(None, 5, None, 0, 0.1, None, 0, None) == -3
     assert lib.d3f_grid_subsample_workspace_bytes(30000, 2, 0, 0) > 30000 * 4 * 14
-    assert lib.d3f_gemm_workspace_bytes(390, 512, 7680) >= 256
+    assert lib.d3f_gemm_workspace_bytes(390, 512, 7680, 0) >= 256
     assert lib.d3f_neighbor_grid_bytes(60000, 2) > 60000 * 16
 
 
