@@ -37,6 +37,8 @@ SIGNATURES = {
                                  _f, _vp, _i, _vp, _vp, _vp]),
     "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),
+    "d3f_gemm_upsample_cat_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _sz,
+                                       _vp, _vp, _i, _vp]),
     "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),

@@ -22,6 +22,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM_BK 32
 #define GM_SA (GM_BK + 1)
 
+// Optional composite A operand (decoder of models/D3Feat.py:55-63): A = [ x'[gidx[m, 0]] | A2[m] ] -- the nearest-upsample
+// gather (closest_pool, models/network_blocks.py:69-83: x' = x + zero row) and the skip concatenation feed the unary
+// contraction directly, so the concatenated [N, C1 + C2] tensor is never written to / re-read from HBM.
+struct GemmGather {
+    const int* gidx;      // NULL: A rows are used in place
+    int ld_gidx;
+    int N1;               // rows of A (the gather source); indices outside [0, N1) read the zero row
+    const int* N1_dev;
+    const float* A2;      // NULL: no second operand
+    int lda2;
+    int K1;               // columns taken from A (multiple of 4 when A2 != NULL)
+};
+
 struct GemmEpi {
     const float* row_scale;
     const float* col_scale;
@@ -45,7 +58,7 @@ template <int WM, int WN, int TM, int TN>  // waves along M / N (WM*WN == 4); 32
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                 int M, int N, int K, int vecA, int vecB, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
-                const int* __restrict__ M_dev) {
+                const int* __restrict__ M_dev, GemmGather G) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int A_F4 = BM * GM_BK / 4 / 256;  // float4 loads per thread for the A tile
     constexpr int B_F4 = GM_BK * BN / 4 / 256;  // ... for the B tile (>= 1)
@@ -67,6 +80,22 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
 
     float4 ra[A_F4], rb[B_F4];
 
+    // source row of each A-tile row this thread stages (fixed across k-tiles): the row itself, or the gathered one
+    int srow[A_F4];
+    {
+        const int n1 = d3f_dyn(G.N1, G.N1_dev);
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int gm = m0 + ((tid + i * 256) >> 3);
+            int sr = gm < M ? gm : -1;
+            if (G.gidx && sr >= 0) {
+                sr = G.gidx[(size_t)gm * G.ld_gidx];
+                if (sr < 0 || sr >= n1) sr = -2;      // shadow neighbour: zero row
+            }
+            srow[i] = sr;
+        }
+    }
+
     auto load_tile = [&](int t) {
         const int k0 = t * GM_BK;
 #pragma unroll
@@ -76,13 +105,25 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
             const int gm = m0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gm < M) {
-                const float* p = A + (size_t)gm * lda + k;
-                if (vecA && k + 3 < K) v = *(const float4*)p;
-                else {
-                    if (k < K) v.x = p[0];
-                    if (k + 1 < K) v.y = p[1];
-                    if (k + 2 < K) v.z = p[2];
-                    if (k + 3 < K) v.w = p[3];
+                if (G.A2 && k >= G.K1) {          // second operand: skip features, row gm
+                    const float* p = G.A2 + (size_t)gm * G.lda2 + (k - G.K1);
+                    if (k + 3 < K) v = *(const float4*)p;
+                    else {
+                        if (k < K) v.x = p[0];
+                        if (k + 1 < K) v.y = p[1];
+                        if (k + 2 < K) v.z = p[2];
+                        if (k + 3 < K) v.w = p[3];
+                    }
+                } else if (srow[i] >= 0) {
+                    const int kend = G.A2 ? G.K1 : K;
+                    const float* p = A + (size_t)srow[i] * lda + k;
+                    if (vecA && k + 3 < kend) v = *(const float4*)p;
+                    else {
+                        if (k < kend) v.x = p[0];
+                        if (k + 1 < kend) v.y = p[1];
+                        if (k + 2 < kend) v.z = p[2];
+                        if (k + 3 < kend) v.w = p[3];
+                    }
                 }
             }
             ra[i] = v;
@@ -231,15 +272,42 @@ extern "C" size_t d3f_gemm_workspace_bytes(int M, int N, int K, int M_hint) {
     return S > 1 ? d3f_align((size_t)S * M * N * sizeof(float)) + 256 : 256;
 }
 
+static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, GemmEpi E,
+                    GemmGather G, void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, hipStream_t stream);
+
 extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                             const float* row_scale, const float* col_scale, const float* col_shift,
                             const float* residual, int ldr, int leaky, float alpha,
                             void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || N < 0 || K < 0 || lda < K || ldb < N || ldc < N || (residual && ldr < N)) return D3F_ERR_ARG;
     if (M == 0 || N == 0) return D3F_OK;
     if (!C || (K > 0 && (!A || !B))) return D3F_ERR_ARG;
     GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
+    GemmGather G{nullptr, 0, M, nullptr, nullptr, 0, K};
+    return gemm_run(A, lda, B, ldb, C, ldc, M, N, K, E, G, workspace, workspace_bytes, M_dev, M_hint, (hipStream_t)stream_);
+}
+
+// Decoder step of models/D3Feat.py:39-63 + the unary block that follows it (models/network_blocks.py:207-219), one launch:
+//   out = act( ([ x'[idx[m,0]] | skip[m] ] @ W) * col_scale + col_shift ),   x' = x + zero row (closest_pool :69-83)
+// x f32[N1,C1] (ldx), idx i32[M, ld_idx] (column 0 used), skip f32[M,C2] (lds; may be NULL with C2 = 0), W f32[C1+C2, N].
+extern "C" int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1, const int* idx, int ld_idx,
+                                         const float* skip, int lds, int C2, const float* W, int ldb, float* C, int ldc,
+                                         int M, int N, const float* col_scale, const float* col_shift, int leaky, float alpha,
+                                         void* workspace, size_t workspace_bytes, const int* M_dev, const int* N1_dev,
+                                         int M_hint, void* stream_) {
+    if (M < 0 || N < 0 || N1 < 0 || C1 < 1 || C2 < 0 || ldx < C1 || ld_idx < 1 || ldb < N || ldc < N || (C2 > 0 && lds < C2))
+        return D3F_ERR_ARG;
+    if (C2 > 0 && (C1 % 4 != 0)) return D3F_ERR_ARG;
+    if (M == 0 || N == 0) return D3F_OK;
+    if (!x || !idx || !W || !C || (C2 > 0 && !skip)) return D3F_ERR_ARG;
+    GemmEpi E{nullptr, col_scale, col_shift, nullptr, 0, leaky, alpha};
+    GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
+    if (C2 > 0 && ((lds % 4 != 0) || (((uintptr_t)skip & 15) != 0))) return D3F_ERR_ARG;
+    return gemm_run(x, ldx, W, ldb, C, ldc, M, N, C1 + C2, E, G, workspace, workspace_bytes, M_dev, M_hint, (hipStream_t)stream_);
+}
+
+static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, GemmEpi E,
+                    GemmGather G, void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, hipStream_t stream) {
     int bm, bn, S, tps;
     gemm_plan(M, N, K > 0 ? K : 1, M_hint, bm, bn, S, tps);
     float* slab = nullptr;
@@ -254,7 +322,7 @@ extern "C" int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, fl
     dim3 grid(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm));
 #define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \
     gemm_f32_kernel<WM_, WN_, TM_, TN_><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, \
-                                                                  M_dev)
+                                                                  M_dev, G)
     if (bn == 32) D3F_GEMM(4, 1, 1, 1);
     else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2);
     else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1);

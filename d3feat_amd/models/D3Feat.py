@@ -29,8 +29,11 @@ def assemble_FCNN_blocks(inputs, config, dropout_prob):
         with variable_scope('uplayer_{:d}/{:s}_{:d}'.format(layer, block, block_in_layer)):
             if block == 'nearest_upsample':
                 # D3Feat.py:39-63 for this block type: closest_pool, then concat with the encoder skip F[layer-1]
+                # ... kept lazy: the unary block that follows contracts [gathered | skip] directly (ops.UpsampleCat)
                 with variable_scope('nearest_upsample'):
-                    features = ops.closest_pool_cat(features, inputs['upsamples'][layer - 1], F[layer - 1])
+                    if isinstance(features, ops.UpsampleCat):
+                        features = features.materialize()
+                    features = ops.UpsampleCat(features, inputs['upsamples'][layer - 1], F[layer - 1])
             else:
                 features = get_block_ops(block)(layer, inputs, features, r, fdim, config, training)
         block_in_layer += 1
@@ -41,6 +44,8 @@ def assemble_FCNN_blocks(inputs, config, dropout_prob):
             block_in_layer = 0
             if block != 'nearest_upsample':
                 raise NotImplementedError('only nearest_upsample decoders are implemented')
+    if isinstance(features, ops.UpsampleCat):
+        features = features.materialize()
     return detection_head(features, inputs)
 
 

@@ -123,6 +123,10 @@ def unary_block(layer_ind, inputs, features, radius, fdim, config, training):
     """:207-219."""
     _check_inference(training)
     w = weight_variable([int(features.shape[1]), fdim])
+    if isinstance(features, ops.UpsampleCat):
+        # decoder: nearest upsampling + skip concatenation (models/D3Feat.py:55-63) fused into this contraction
+        e = _epilogue(fdim, config, True)
+        return ops.gemm_upsample_cat(features, w, col_scale=e['col_scale'], col_shift=e['col_shift'], leaky=True, alpha=0.2)
     return conv_ops.unary_convolution(features, w, epilogue=_epilogue(fdim, config, True))
 
 
@@ -176,12 +180,23 @@ def nearest_upsample_block(layer_ind, inputs, features, radius, fdim, config, tr
         return closest_pool(features, inputs['upsamples'][layer_ind - 1])
 
 
+def _materialized(block_fn):
+    """Blocks other than `unary` take a real tensor: materialise a pending nearest-upsample concatenation first."""
+    def wrapped(layer_ind, inputs, features, radius, fdim, config, training):
+        if isinstance(features, ops.UpsampleCat):
+            features = features.materialize()
+        return block_fn(layer_ind, inputs, features, radius, fdim, config, training)
+    wrapped.__name__ = block_fn.__name__
+    wrapped.__doc__ = block_fn.__doc__
+    return wrapped
+
+
 def get_block_ops(block_name):
     """:982-1042 for the block types of the shipped architectures (results/*/parameters.txt:19)."""
     table = {'unary': unary_block, 'last_unary': last_unary_block, 'simple': simple_block, 'resnetb': resnetb_block,
              'resnetb_strided': resnetb_strided_block, 'nearest_upsample': nearest_upsample_block}
     if block_name in table:
-        return table[block_name]
+        return table[block_name] if block_name == 'unary' else _materialized(table[block_name])
     known_unsupported = ('simple_strided', 'resnet', 'resnetb_light', 'resnetb_deformable', 'inception_deformable',
                          'resnetb_light_strided', 'resnetb_deformable_strided', 'inception_deformable_strided', 'vgg',
                          'max_pool', 'max_pool_wide', 'global_average', 'simple_upsample', 'resnetb_upsample')

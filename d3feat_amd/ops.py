@@ -325,6 +325,51 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
     return _tag(out, A)
 
 
+class UpsampleCat:
+    """The not-yet-materialised result of nearest_upsample + skip concatenation (models/D3Feat.py:55-63):
+    rows [ x'[inds[n,0]] | skip[n] ].  The unary block that follows consumes it through gemm_upsample_cat (one launch, no
+    intermediate tensor); anything else calls .materialize()."""
+
+    def __init__(self, x, inds, skip=None):
+        self.x, self.inds, self.skip = x, inds, skip
+        self.shape = (inds.shape[0], x.shape[1] + (skip.shape[1] if skip is not None else 0))
+        self.device = x.device
+        _tag(self, inds)
+
+    def materialize(self):
+        return closest_pool_cat(self.x, self.inds, self.skip)
+
+
+def gemm_upsample_cat(u, W, col_scale=None, col_shift=None, leaky=False, alpha=0.2):
+    """out = act(([ x'[inds[:,0]] | skip ] @ W) * col_scale + col_shift) without building the concatenation."""
+    lib = _lib.load()
+    x, ldx = _rows(_req(u.x, torch.float32, "x"), "x")
+    inds, ldi = _rows(_req(u.inds, torch.int32, "inds"), "inds")
+    W, ldb = _rows(_req(W, torch.float32, "W"), "W")
+    C1, C2, lds, skip = x.shape[1], 0, 0, None
+    if u.skip is not None:
+        skip, lds = _rows(_req(u.skip, torch.float32, "skip"), "skip")
+        C2 = skip.shape[1]
+    M, N = inds.shape[0], W.shape[1]
+    if W.shape[0] != C1 + C2:
+        raise ValueError("gemm_upsample_cat: W has %d rows, operands %d + %d columns" % (W.shape[0], C1, C2))
+    if C2 and (C1 % 4 or lds % 4 or skip.data_ptr() % 16):
+        return gemm(u.materialize(), W, col_scale=col_scale, col_shift=col_shift, leaky=leaky, alpha=alpha)
+    dev = x.device
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    hint = int(getattr(inds, "n_hint", 0) or 0)
+    nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
+    ws = workspace(nbytes, dev)
+    with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
+        rc = lib.d3f_gemm_upsample_cat_f32(x.data_ptr(), x.shape[0], ldx, C1, inds.data_ptr(), ldi,
+                                           skip.data_ptr() if C2 else None, lds, C2, W.data_ptr(), ldb, out.data_ptr(), N, M, N,
+                                           col_scale.data_ptr() if col_scale is not None else None,
+                                           col_shift.data_ptr() if col_shift is not None else None, 1 if leaky else 0,
+                                           float(alpha), ws.data_ptr(), ws.numel(), _nd(inds), _nd(x), hint, _stream(dev))
+    _lib.check(rc, "gemm_upsample_cat_f32")
+    return _tag(out, inds)
+
+
 def kpconv_aggregate(query_points, support_points, neighbors_indices, features, K_points, KP_extent,
                      KP_influence="linear", aggregation_mode="sum"):
     """-> (wf f32[Nq, num_kp*Cin], inv_cnt f32[Nq])   (phase 1 of KPConv_ops)."""

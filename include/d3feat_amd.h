@@ -182,6 +182,18 @@ int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int
                  const float* residual, int ldr, int leaky, float alpha,
                  void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, void* stream);
 
+/* Decoder step: nearest upsampling + skip concatenation + the unary block that consumes them, as ONE contraction whose
+ * A operand is composed on the fly (the concatenated tensor never exists in HBM).  Replaces models/D3Feat.py:39-63
+ * (closest_pool, models/network_blocks.py:69-83, then tf.concat) followed by unary_block (models/network_blocks.py:207-219):
+ *   C[m, :] = act( ([ x'[idx[m,0]] | skip[m] ] @ W) * col_scale + col_shift ),   x' = x with a zero row appended
+ *   x f32[N1,C1] (ldx), idx i32[M, ld_idx] (column 0 is read), skip f32[M,C2] (lds; NULL when C2 = 0), W f32[C1+C2, N] (ldb)
+ *   C1 % 4 == 0 when C2 > 0.  M_dev / N1_dev / M_hint as for d3f_gemm_f32; workspace: d3f_gemm_workspace_bytes(M, N, C1+C2, M_hint). */
+int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1, const int* idx, int ld_idx,
+                              const float* skip, int lds, int C2, const float* W, int ldb, float* C, int ldc,
+                              int M, int N, const float* col_scale, const float* col_shift, int leaky, float alpha,
+                              void* workspace, size_t workspace_bytes, const int* M_dev, const int* N1_dev,
+                              int M_hint, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Pooling / upsampling gathers.
  *   d3f_ind_max_pool      models/network_blocks.py:51-66  out[n,c] = max_k x'[idx[n,k],c], x' = x + row of column minima

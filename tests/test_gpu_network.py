@@ -241,3 +241,29 @@ def test_full_forward_vs_oracle(device, coracle):
     flat2 = ds2.get_tf_mapping(cfg)(*ds2._to_device(next(iter(gen()))))
     m2 = KernelPointFCNN(flat2, cfg, weights=W)
     assert torch.equal(m2.out_features, model.out_features) and torch.equal(m2.out_scores, model.out_scores)
+
+
+@pytest.mark.parametrize("C1,C2,N", [(128, 64, 64), (1024, 2048, 512), (64, 0, 32)])
+def test_gemm_upsample_cat_equals_materialised(device, C1, C2, N):
+    """The fused decoder contraction ([gathered | skip] @ W) is the same arithmetic as gather+concat followed by the GEMM:
+    identical k order -> bit-identical results; shadow indices read the zero row."""
+    from d3feat_amd import ops
+    rng = np.random.default_rng(C1 + C2)
+    n1, m = 700, 2500
+    x = _t(rng.standard_normal((n1, C1)).astype(np.float32), device)
+    skip = _t(rng.standard_normal((m, C2)).astype(np.float32), device) if C2 else None
+    idx = rng.integers(0, n1 + 1, (m, 3)).astype(np.int32)        # n1 = shadow index
+    idx[::17, 0] = n1
+    W = _t((rng.standard_normal((C1 + C2, N)) / np.sqrt(C1 + C2)).astype(np.float32), device)
+    cs = _t(rng.random(N).astype(np.float32) + 0.5, device)
+    ch = _t(rng.standard_normal(N).astype(np.float32), device)
+    u = ops.UpsampleCat(x, _t(idx, device), skip)
+    assert u.shape == (m, C1 + C2)
+    got = ops.gemm_upsample_cat(u, W, col_scale=cs, col_shift=ch, leaky=True)
+    want = ops.gemm(u.materialize(), W, col_scale=cs, col_shift=ch, leaky=True)
+    assert torch.equal(got, want)
+    ref = np.concatenate([np.concatenate([x.cpu().numpy(), np.zeros((1, C1), np.float32)])[idx[:, 0]]] +
+                         ([skip.cpu().numpy()] if C2 else []), 1).astype(np.float64) @ W.cpu().numpy().astype(np.float64)
+    ref = ref * cs.cpu().numpy() + ch.cpu().numpy()
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    _close(got.cpu().numpy(), ref, 2e-5)
