@@ -32,13 +32,15 @@ template <int VEC>  // channels per thread (4: 16-byte loads; 1: generic)
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
                                                       const float* __restrict__ colmin, float* __restrict__ out, int ldo,
-                                                      const int* __restrict__ N1_dev, const int* __restrict__ N2_dev) {
+                                                      const int* __restrict__ N1_dev, const int* __restrict__ N2_dev,
+                                                      const int* __restrict__ row_order) {
     N1 = d3f_dyn(N1, N1_dev);
     N2 = d3f_dyn(N2, N2_dev);
     const int CV = C / VEC;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N2 * CV) return;
-    const int n = (int)(t / CV), c = (int)(t % CV) * VEC;
+    const int slot = (int)(t / CV), c = (int)(t % CV) * VEC;
+    const int n = row_order ? row_order[slot] : slot;   // spatially coherent visiting order (see kpconv.hip)
     float sh[VEC], m[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { sh[v] = colmin[c + v]; m[v] = -3.402823466e38f; }
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
 
 extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
                                 float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev,
-                                void* stream_) {
+                                const int* row_order, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N1 < 0 || N2 < 0 || C < 1 || ldx < C || ldo < C || K < 0 || ld_idx < K) return D3F_ERR_ARG;
     if (N2 == 0) return D3F_OK;
@@ -89,10 +91,11 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
     colmin_decode_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
     if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
         maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
-                                                                                      col_min_dev, out, ldo, N1_dev, N2_dev);
+                                                                                      col_min_dev, out, ldo, N1_dev, N2_dev,
+                                                                                      row_order);
     else
         maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, col_min_dev,
-                                                                               out, ldo, N1_dev, N2_dev);
+                                                                               out, ldo, N1_dev, N2_dev, row_order);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -188,12 +191,12 @@ template <int CPL>  // channels per lane: C <= 32 * CPL
 __global__ void __launch_bounds__(256)
 head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __restrict__ idx, int ld_idx, int K,
             const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
-            float* __restrict__ score) {
+            float* __restrict__ score, const int* __restrict__ row_order) {
     N = min(N, offs[B]);   // N is the capacity, offs[B] the real point count
     const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
     if ((int)((blockIdx.x * blockDim.x) >> 5) >= N) return;
     const bool active = half < N;
-    const int n = active ? half : 0;
+    const int n = active ? (row_order ? row_order[half] : half) : 0;   // spatially coherent visiting order
     const int b = d3f_find_elem(offs, B, n);
     const float den = d3f_ord2f(mx[b]) + 1e-6f;
     float xv[CPL], yv[CPL], sum[CPL];
@@ -282,7 +285,7 @@ head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __res
 
 extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
                                const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
-                               int* scratch_dev, void* stream_) {
+                               int* scratch_dev, const int* row_order, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || C < 1 || C > 128 || ldx < C || ldd < C || K < 0 || ld_idx < K || B < 1 || B > D3F_MAX_BATCH) return D3F_ERR_ARG;
     if (N == 0) return D3F_OK;
@@ -295,9 +298,9 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     if (chunks < 1) chunks = 1;
     head_max_kernel<<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
     const int blocks = d3f_cdiv((long long)N * 32, 256);
-    if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score);
-    else if (C <= 64) head_kernel<2><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score);
-    else head_kernel<4><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score);
+    if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
+    else if (C <= 64) head_kernel<2><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
+    else head_kernel<4><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

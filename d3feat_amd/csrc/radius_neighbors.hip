@@ -292,6 +292,14 @@ extern "C" size_t d3f_neighbor_grid_bytes(int Ns, int B) {
     return bytes + 1024;
 }
 
+// byte offset, inside a built grid object, of `order`: i32[Ns] = support indices sorted by cell -- a spatially coherent
+// processing order for any per-point kernel over the same cloud (neighbouring entries share most of their neighbours)
+extern "C" size_t d3f_neighbor_grid_order_offset(int Ns, int B) {
+    if (Ns < 0 || B < 1) return 0;
+    NbGrid g = nb_carve((void*)0x1000, (size_t)1 << 60, Ns, B);
+    return (size_t)((char*)g.order - (char*)0x1000);
+}
+
 extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev, int B, float radius,
                                        void* grid, size_t grid_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

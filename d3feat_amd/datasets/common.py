@@ -132,6 +132,8 @@ class Dataset:
             grid = grids.get(key)
             if grid is None:
                 grid = grids[key] = ops.NeighborGrid(s, sl, r)
+                if getattr(s, 'order', None) is None:
+                    s.order = grid.order   # cell-sorted visiting order of this level's points (ops._order)
             out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)],
                                       reset_status=False)
             pending.append(status)
@@ -199,6 +201,12 @@ class Dataset:
             self._neighbor_cap = _lib.NEIGHBOR_CAP
             return self.tf_descriptor_input(config, first_points, stacked_features, first_lengths, batch_inds,
                                             exact_shapes=exact_shapes, up_first_column_only=up_first_column_only)
+
+        # rows of pools[l] are the points of level l+1: give them that level's spatially coherent visiting order
+        for l in range(len(input_pools) - 1):
+            o = getattr(input_points[l + 1], 'order', None)
+            if o is not None and input_pools[l].shape[0] > 0:
+                input_pools[l].order = o
 
         if exact_shapes:
             stacked_batch_inds_0 = self.tf_stack_batch_inds(input_batches_len[0])

@@ -44,6 +44,12 @@ def _stream(device):
 # ---- device-resident sizes ------------------------------------------------------------------------------------------
 # A tensor whose row count is only an upper bound carries the real count as the attribute `n_dev` (int32[1] on the
 # device); every op forwards it to the kernels (the `*_dev` arguments of include/d3feat_amd.h) and tags its outputs.
+def _order(t):
+    """Spatially coherent visiting order attached to a point / index tensor (attribute `order`, int32), or None."""
+    o = getattr(t, "order", None) if t is not None else None
+    return o.data_ptr() if o is not None else None
+
+
 def _nd(t):
     d = getattr(t, "n_dev", None) if t is not None else None
     return d.data_ptr() if d is not None else None
@@ -247,6 +253,9 @@ class NeighborGrid:
         rc = lib.d3f_neighbor_grid_build(self.supports.data_ptr(), self.Ns, self.s_lens.data_ptr(), self.B, self.radius,
                                          self.mem.data_ptr(), self.nbytes, _stream(dev))
         _lib.check(rc, "neighbor_grid_build")
+        # support indices sorted by cell (a view into the grid object): a spatially coherent visiting order
+        off = lib.d3f_neighbor_grid_order_offset(self.Ns, self.B)
+        self.order = self.mem[off: off + 4 * max(self.Ns, 1)].view(torch.int32)
 
     def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None,
                reset_status=True):
@@ -275,6 +284,9 @@ class NeighborGrid:
                                               1 if first_only else 0, 1 if reset_status else 0, status.data_ptr(),
                                               _stream(dev))
         _lib.check(rc, "neighbor_grid_search")
+        o = getattr(queries, "order", None)
+        if o is not None:
+            out.order = o         # rows of the index matrix = the queries: same visiting order
         return _tag(out, queries), status
 
 
@@ -402,7 +414,7 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
         rc = lib.d3f_kpconv_aggregate(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
                                       Cin, row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent),
                                       _INFLUENCE[KP_influence], _AGGREGATION[aggregation_mode], wf.data_ptr(),
-                                      inv_cnt.data_ptr(), nq_dev, ns_dev, st)
+                                      inv_cnt.data_ptr(), nq_dev, ns_dev, _order(query_points), st)
     _lib.check(rc, "kpconv_aggregate")
     return _tag(wf, query_points), _tag(inv_cnt, query_points)
 
@@ -449,7 +461,8 @@ def ind_max_pool(x, inds):
     out = torch.empty((inds.shape[0], x.shape[1]), dtype=torch.float32, device=dev)
     colmin = torch.empty((x.shape[1],), dtype=torch.float32, device=dev)
     rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
-                              inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _stream(dev))
+                              inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _order(inds),
+                              _stream(dev))
     _lib.check(rc, "ind_max_pool")
     return _tag(out, inds)
 
@@ -487,7 +500,7 @@ def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev):
     scratch = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
     rc = lib.d3f_detect_head(x.data_ptr(), N, ldx, Cc, nb.data_ptr(), ldi, nb.shape[1],
                              stack_lengths_dev.data_ptr(), include_zero_dev.data_ptr() if include_zero_dev is not None else None,
-                             B, desc.data_ptr(), Cc, score.data_ptr(), scratch.data_ptr(), _stream(dev))
+                             B, desc.data_ptr(), Cc, score.data_ptr(), scratch.data_ptr(), _order(nb), _stream(dev))
     _lib.check(rc, "detect_head")
     return _tag(desc, x), _tag(score, x)
 

@@ -127,6 +127,10 @@ int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* suppor
  *                             fragment zeroes the status words of all its ops with one fill)
  */
 size_t d3f_neighbor_grid_bytes(int Ns, int B);
+/* byte offset inside a built grid of `order` i32[Ns]: the support indices sorted by cell.  Passing it as q_order /
+ * row_order to the per-point kernels below makes them visit points in a spatially coherent order (neighbouring
+ * workgroup rows share their gathered neighbours in L1 / L2); results do not depend on it. */
+size_t d3f_neighbor_grid_order_offset(int Ns, int B);
 int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev, int B, float radius,
                             void* grid, size_t grid_bytes, void* stream);
 int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
@@ -152,7 +156,7 @@ int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* ro
 int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                          const float* f, int ldf, int Cin, const unsigned char* row_pos, const float* kp_host,
                          int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
-                         const int* Nq_dev, const int* Ns_dev, void* stream);
+                         const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
 
 /* Whole KPConv_ops (kernels/convolution_ops.py:161-255) + the fused inference epilogue for Cin = 1 -- the input
  * layer of every shipped model (`simple` block on the all-ones features, models/network_blocks.py:222-244):
@@ -202,7 +206,8 @@ int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1, const int
  *   col_min_dev: f32[C] scratch written by d3f_ind_max_pool.
  * ------------------------------------------------------------------------------------------- */
 int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
-                     float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev, void* stream);
+                     float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev, const int* row_order,
+                     void* stream);
 int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, const int* idx, int N2, int ld_idx,
                          const float* skip, int lds, int C2, float* out, int ldo, const int* N1_dev, const int* N2_dev,
                          void* stream);
@@ -226,7 +231,7 @@ int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale
  * ------------------------------------------------------------------------------------------- */
 int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
                     const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
-                    int* scratch_dev, void* stream);
+                    int* scratch_dev, const int* row_order, void* stream);
 
 #ifdef __cplusplus
 }
