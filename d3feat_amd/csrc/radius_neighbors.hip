@@ -19,6 +19,7 @@
 //           are ordered by rank counting (each lane counts how many hits precede its own -- keys are unique so
 //           ranks are a permutation) and the first `width` ranks are stored straight into the output row.
 #include "prims.h"
+#include <cstdlib>
 
 struct NbElem {
     double mn[3];
@@ -126,7 +127,11 @@ __global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict
 // Latency is the enemy here (each query touches ~100 candidates in 9 runs): the 18 run bounds are fetched by 18
 // lanes in ONE round trip, the 9 runs are then walked as a single virtual list (lane -> run by comparing against
 // the wave-uniform run prefix), so a typical query needs two 64-wide candidate loads instead of 9+ dependent steps.
-template <bool FIRST_ONLY>
+// LPQ lanes cooperate on one query (64 = one wavefront per query; 32 / 16 = two / four queries per wavefront).  A typical
+// query has ~120 candidates and ~40 hits: with a whole wavefront per query half the lanes idle in every phase and the kernel
+// is bound by the dependent memory round trips per wavefront, so packing several queries into a wavefront raises the work
+// in flight per round trip.  Lane groups are independent: shuffles use width LPQ, ballots are masked to the group.
+template <bool FIRST_ONLY, int LPQ>
 __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
 nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
@@ -134,15 +139,18 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
                  const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
                  int ld, int width, int cap, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* hd2 = (float*)smem + (size_t)wave * 2 * cap;
+    constexpr int QPB = 64 * NB_WAVES_PER_BLOCK / LPQ;   // queries per workgroup
+    const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
+    const int gshift = (threadIdx.x & 63) - lane;         // first lane of this group inside its wavefront
+    const unsigned long long gmask = (LPQ == 64) ? ~0ull : (((1ull << LPQ) - 1ull) << gshift);
+    float* hd2 = (float*)smem + (size_t)grp * 2 * cap;
     int* hidx = (int*)hd2 + cap;
-    const int wq = blockIdx.x * NB_WAVES_PER_BLOCK + wave;
+    const int wq = blockIdx.x * QPB + grp;
     int nq_real = 0;
     for (int j = 0; j < B; ++j) nq_real += qlens[j];
     if (wq >= min(Nq, nq_real)) return;   // Nq is the capacity, sum(qlens) the real number of queries
     if (pad == D3F_PAD_NUM_SUPPORTS) pad = *ns_dev;
-    // queries that ARE the supports are visited in cell order: neighbouring waves then share their candidate runs in L2
+    // queries that ARE the supports are visited in cell order: neighbouring groups then share their candidate runs in L2
     const int qi = qorder ? qorder[wq] : wq;
     int b = 0;   // batch element of the query: the last one starting at or before qi (lens -> offsets on the fly, B is small)
     for (int j = 1, start = qlens[0]; j < B; ++j) { if (qi >= start) b = j; start += qlens[j]; }
@@ -164,46 +172,54 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
             bound = d3f_scan_at(cell_start, cell_base, rowbase + (lane < 9 ? x0 : x1 + 1));
         }
     }
-    const int hi_l = __shfl_down(bound, 9, 64);
+    static_assert(LPQ >= 32, "the 18 run bounds live in one lane group");
+    const int hi_l = __shfl_down(bound, 9, LPQ);
     const int len_l = (lane < 9) ? hi_l - bound : 0;
-    // wave-uniform run offsets: off[j] = lo[j] - prefix[j]; prefix kept for the lane -> run test
+    // group-uniform run offsets: off[j] = lo[j] - prefix[j]; prefix kept for the lane -> run test
     int pre[10], off[9];
     pre[0] = 0;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        const int lo_j = __shfl(bound, j, 64);
-        const int ln_j = __shfl(len_l, j, 64);
+        const int lo_j = __shfl(bound, j, LPQ);
+        const int ln_j = __shfl(len_l, j, LPQ);
         off[j] = lo_j - pre[j];
         pre[j + 1] = pre[j] + ln_j;
     }
     const int T = pre[9];
-    int n = 0;  // wave-uniform hit count
-    const unsigned long long lt = d3f_lanemask_lt();
+    int n = 0;  // group-uniform hit count
+    const unsigned long long lt = (1ull << lane) - 1ull;
     float bd2 = 3.4e38f;
     int bidx = 0x7fffffff;
-    for (int v0 = 0; v0 < T; v0 += 64) {
-        const int v = v0 + lane;
-        bool hit = false;
-        float d2 = 0.f;
-        int si = 0;
-        if (v < T) {
+    // two candidate loads in flight per lane: the loads of consecutive steps are independent, only the hit compaction is
+    // sequential, so issue both before consuming either (halves the exposed memory round trips of this loop)
+    for (int v0 = 0; v0 < T; v0 += 2 * LPQ) {
+        float4 sp[2];
+        bool in[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int v = v0 + u * LPQ + lane;
+            in[u] = v < T;
             int t = v + off[0];
 #pragma unroll
             for (int j = 1; j < 9; ++j) t = (v >= pre[j]) ? v + off[j] : t;
-            const float4 sp = sorted[t];
-            const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
-            d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            si = __float_as_int(sp.w);
-            hit = d2 < r2;
+            sp[u] = in[u] ? sorted[t] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const unsigned long long m = __ballot(hit);
-        if (FIRST_ONLY) {
-            if (hit && (d2 < bd2 || (d2 == bd2 && si < bidx))) { bd2 = d2; bidx = si; }
-        } else if (hit) {
-            const int pos = n + __popcll(m & lt);
-            if (pos < cap) { hd2[pos] = d2; hidx[pos] = si; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (v0 + u * LPQ >= T) break;   // group-uniform
+            const float dx = __fsub_rn(qx, sp[u].x), dy = __fsub_rn(qy, sp[u].y), dz = __fsub_rn(qz, sp[u].z);
+            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const int si = __float_as_int(sp[u].w);
+            const bool hit = in[u] && d2 < r2;
+            const unsigned long long m = (__ballot(hit) & gmask) >> gshift;   // hits of this group, bit = lane in group
+            if (FIRST_ONLY) {
+                if (hit && (d2 < bd2 || (d2 == bd2 && si < bidx))) { bd2 = d2; bidx = si; }
+            } else if (hit) {
+                const int pos = n + __popcll(m & lt);
+                if (pos < cap) { hd2[pos] = d2; hidx[pos] = si; }
+            }
+            n += __popcll(m);
         }
-        n += __popcll(m);
     }
     if (lane == 0) {
         // one shared word: an unconditional atomic per query serialises at ~12 ns each in L2 (60k queries = 0.7 ms);
@@ -213,35 +229,41 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     }
     int* row = out + (size_t)qi * ld;
     if (FIRST_ONLY) {
-        // lexicographic (d2, index) minimum over the wave
+        // lexicographic (d2, index) minimum over the group
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float od = __shfl_xor(bd2, o, 64);
-            const int oi = __shfl_xor(bidx, o, 64);
+        for (int o = LPQ / 2; o > 0; o >>= 1) {
+            const float od = __shfl_xor(bd2, o, LPQ);
+            const int oi = __shfl_xor(bidx, o, LPQ);
             if (od < bd2 || (od == bd2 && oi < bidx)) { bd2 = od; bidx = oi; }
         }
         if (lane == 0 && width > 0) row[0] = (n > 0) ? bidx : pad;
-        for (int j = 1 + lane; j < width; j += 64) row[j] = pad;
+        for (int j = 1 + lane; j < width; j += LPQ) row[j] = pad;
         return;
     }
     const int m = min(n, cap);
+    // rank counting, four hits per LDS read (ds_read_b128 broadcasts): pad the tail of the last quad with +inf keys
+    const int m4 = (m + 3) & ~3;
+    if (m + lane < m4) { hd2[m + lane] = 3.4e38f; hidx[m + lane] = 0x7fffffff; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int e0 = 0; e0 < m; e0 += 64) {
+    for (int e0 = 0; e0 < m; e0 += LPQ) {
         const int ei = e0 + lane;
         if (ei < m) {
             const float kd = hd2[ei];
             const int ki = hidx[ei];
             int rank = 0;
-            for (int j = 0; j < m; ++j) {
-                const float dj = hd2[j];
-                const int ij = hidx[j];
-                rank += (dj < kd || (dj == kd && ij < ki)) ? 1 : 0;
+            for (int j = 0; j < m4; j += 4) {
+                const float4 dj = *(const float4*)&hd2[j];
+                const int4 ij = *(const int4*)&hidx[j];
+                rank += (dj.x < kd || (dj.x == kd && ij.x < ki)) ? 1 : 0;
+                rank += (dj.y < kd || (dj.y == kd && ij.y < ki)) ? 1 : 0;
+                rank += (dj.z < kd || (dj.z == kd && ij.z < ki)) ? 1 : 0;
+                rank += (dj.w < kd || (dj.w == kd && ij.w < ki)) ? 1 : 0;
             }
             if (rank < width) row[rank] = ki;
         }
     }
-    for (int j = m + lane; j < width; j += 64) row[j] = pad;
+    for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,18 +367,23 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
     if (!g.ok) return D3F_ERR_WORKSPACE;
     const float r2 = radius * radius;
-    const int blocks = d3f_cdiv(Nq, NB_WAVES_PER_BLOCK);
     const int* qorder = queries_are_supports ? g.order : nullptr;
-    if (first_only) {
-        nb_search_kernel<true><<<blocks, 64 * NB_WAVES_PER_BLOCK, 0, stream>>>(
-            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width,
-            1, status_dev);
-    } else {
-        const size_t lds = (size_t)NB_WAVES_PER_BLOCK * cap * 2 * sizeof(float);
-        nb_search_kernel<false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(
-            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width,
-            cap, status_dev);
-    }
+    // lanes per query: 32 (two queries per wavefront) unless the ordering budget is large (rare, dense clouds);
+    // D3F_NB_LPQ=64 restores one wavefront per query (tuning knob)
+    cap = (cap + 3) & ~3;   // LDS segments are read four hits at a time
+    int lpq = cap > 256 ? 64 : 32;
+    if (const char* f = getenv("D3F_NB_LPQ")) { if (atoi(f) == 64) lpq = 64; else if (atoi(f) == 32) lpq = 32; }
+    const int qpb = 64 * NB_WAVES_PER_BLOCK / lpq;
+    const int blocks = d3f_cdiv(Nq, qpb);
+    const size_t lds = first_only ? 0 : (size_t)qpb * cap * 2 * sizeof(float);
+    const int kcap = first_only ? 1 : cap;
+#define D3F_NB(FO_, LPQ_)                                                                                              \
+    nb_search_kernel<FO_, LPQ_><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                                      \
+        queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
+        kcap, status_dev)
+    if (first_only) { if (lpq == 64) D3F_NB(true, 64); else D3F_NB(true, 32); }
+    else { if (lpq == 64) D3F_NB(false, 64); else D3F_NB(false, 32); }
+#undef D3F_NB
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
