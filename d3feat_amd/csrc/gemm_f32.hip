@@ -295,11 +295,13 @@ extern "C" int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1
                                          int M, int N, const float* col_scale, const float* col_shift, int leaky, float alpha,
                                          void* workspace, size_t workspace_bytes, const int* M_dev, const int* N1_dev,
                                          int M_hint, void* stream_) {
-    if (M < 0 || N < 0 || N1 < 0 || C1 < 1 || C2 < 0 || ldx < C1 || ld_idx < 1 || ldb < N || ldc < N || (C2 > 0 && lds < C2))
+    if (M < 0 || N < 0 || N1 < 0 || C1 < 1 || C2 < 0 || ldx < C1 || (idx && ld_idx < 1) || ldb < N || ldc < N ||
+        (C2 > 0 && lds < C2))
         return D3F_ERR_ARG;
     if (C2 > 0 && (C1 % 4 != 0)) return D3F_ERR_ARG;
     if (M == 0 || N == 0) return D3F_OK;
-    if (!x || !idx || !W || !C || (C2 > 0 && !skip)) return D3F_ERR_ARG;
+    if (!x || !W || !C || (C2 > 0 && !skip)) return D3F_ERR_ARG;   // idx == NULL: rows of x are used in place (N1 >= M)
+    if (!idx && N1 < M) return D3F_ERR_ARG;
     GemmEpi E{nullptr, col_scale, col_shift, nullptr, 0, leaky, alpha};
     GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
     if (C2 > 0 && ((lds % 4 != 0) || (((uintptr_t)skip & 15) != 0))) return D3F_ERR_ARG;

@@ -152,13 +152,26 @@ def _resnetb(layer_ind, inputs, features, radius, fdim, config, strided):
         x = KPConv(q, s, nb, x, w, radius, config, epilogue=_epilogue(fdim // 2, config, True))
     with variable_scope('shortcut'):
         shortcut = ind_max_pool(features, inputs['pools'][layer_ind]) if strided else features
-        if int(shortcut.shape[1]) != 2 * fdim:
-            w = weight_variable([int(shortcut.shape[1]), 2 * fdim])
-            shortcut = conv_ops.unary_convolution(shortcut, w, epilogue=_epilogue(2 * fdim, config, False))
+        need_sc = int(shortcut.shape[1]) != 2 * fdim
+        # leaky_relu(bn(conv3(x)) + bn(shortcut(f))): both unary branches as ONE contraction over [x | f], the batch-norm
+        # scales folded into the stacked weights -- no shortcut tensor, no residual re-read, one launch less
+        fuse = need_sc and config.use_batch_norm and (fdim // 2) % 4 == 0
+        sc_w = sc_bn = None
+        if need_sc:
+            vs = _vs()
+            sc_w = vs.weight_variable([int(shortcut.shape[1]), 2 * fdim])
+            if fuse:
+                sc_bn = vs.batch_norm_variables(2 * fdim)
+            else:
+                shortcut = conv_ops.unary_convolution(shortcut, vs.tensor(sc_w), epilogue=_epilogue(2 * fdim, config, False))
     with variable_scope('conv3'):
-        w = weight_variable([fdim // 2, 2 * fdim])
+        vs = _vs()
+        w3 = vs.weight_variable([fdim // 2, 2 * fdim])
+        if fuse:
+            W, shift = vs.stacked_branches(w3, vs.batch_norm_variables(2 * fdim), sc_w, sc_bn)
+            return ops.gemm_cat2(x, shortcut, W, col_shift=shift, leaky=True, alpha=0.2)
         # leaky_relu(batch_norm(conv3) + shortcut): the add and the activation ride in the contraction's epilogue
-        return conv_ops.unary_convolution(x, w, epilogue=_epilogue(2 * fdim, config, True, residual=shortcut))
+        return conv_ops.unary_convolution(x, vs.tensor(w3), epilogue=_epilogue(2 * fdim, config, True, residual=shortcut))
 
 
 def resnetb_block(layer_ind, inputs, features, radius, fdim, config, training):

@@ -92,6 +92,24 @@ class VariableStore:
             self._dev[key] = t
         return t
 
+    def stacked_branches(self, w1, bn1, w2, bn2, eps=1e-6):
+        """The two branches of a resnet block that meet in an add -- leaky(bn(x @ W1) + bn(f @ W2)), models/network_blocks.py:
+        321-368 -- as ONE contraction: [x | f] @ [W1 * s1 ; W2 * s2] + (t1 + t2), the inference batch-norm scales folded into
+        the stacked weights (s = gamma * rsqrt(var + eps), t = beta - mean * s).  -> (W [C1+C2, N], shift [N]) on the device."""
+        key = ('stack', w1, w2)
+        t = self._dev.get(key)
+        if t is None:
+            def fold(names):
+                g, b, m, v = (self.values[n].astype(np.float32) for n in names)
+                sc = (g / np.sqrt(v + np.float32(eps))).astype(np.float32)
+                return sc, (b - m * sc).astype(np.float32)
+            s1, t1 = fold(bn1)
+            s2, t2 = fold(bn2)
+            W = np.concatenate([self.values[w1] * s1[None, :], self.values[w2] * s2[None, :]], 0).astype(np.float32)
+            t = (torch.from_numpy(np.ascontiguousarray(W)).to(self.device), torch.from_numpy(t1 + t2).to(self.device))
+            self._dev[key] = t
+        return t
+
     def invalidate_device(self):
         self._dev = {}
 

@@ -382,6 +382,32 @@ def gemm_upsample_cat(u, W, col_scale=None, col_shift=None, leaky=False, alpha=0
     return _tag(out, inds)
 
 
+def gemm_cat2(A1, A2, W, col_scale=None, col_shift=None, leaky=False, alpha=0.2):
+    """out = act(([A1 | A2] @ W) * col_scale + col_shift) without building the concatenation (same rows in A1 and A2)."""
+    lib = _lib.load()
+    A1, ld1 = _rows(_req(A1, torch.float32, "A1"), "A1")
+    A2, ld2 = _rows(_req(A2, torch.float32, "A2"), "A2")
+    W, ldb = _rows(_req(W, torch.float32, "W"), "W")
+    M, C1, C2, N = A1.shape[0], A1.shape[1], A2.shape[1], W.shape[1]
+    if A2.shape[0] != M or W.shape[0] != C1 + C2:
+        raise ValueError("gemm_cat2: operands %s | %s, W %s" % (tuple(A1.shape), tuple(A2.shape), tuple(W.shape)))
+    if C1 % 4 or ld2 % 4 or A2.data_ptr() % 16:
+        return gemm(torch.cat([A1, A2], 1), W, col_scale=col_scale, col_shift=col_shift, leaky=leaky, alpha=alpha)
+    dev = A1.device
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    hint = int(getattr(A1, "n_hint", 0) or 0)
+    nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
+    ws = workspace(nbytes, dev)
+    with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
+        rc = lib.d3f_gemm_upsample_cat_f32(A1.data_ptr(), M, ld1, C1, None, 0, A2.data_ptr(), ld2, C2, W.data_ptr(), ldb,
+                                           out.data_ptr(), N, M, N,
+                                           col_scale.data_ptr() if col_scale is not None else None,
+                                           col_shift.data_ptr() if col_shift is not None else None, 1 if leaky else 0,
+                                           float(alpha), ws.data_ptr(), ws.numel(), _nd(A1), _nd(A1), hint, _stream(dev))
+    _lib.check(rc, "gemm_cat2")
+    return _tag(out, A1)
+
+
 def kpconv_aggregate(query_points, support_points, neighbors_indices, features, K_points, KP_extent,
                      KP_influence="linear", aggregation_mode="sum"):
     """-> (wf f32[Nq, num_kp*Cin], inv_cnt f32[Nq])   (phase 1 of KPConv_ops)."""

@@ -191,7 +191,9 @@ int d3f_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int
  * (closest_pool, models/network_blocks.py:69-83, then tf.concat) followed by unary_block (models/network_blocks.py:207-219):
  *   C[m, :] = act( ([ x'[idx[m,0]] | skip[m] ] @ W) * col_scale + col_shift ),   x' = x with a zero row appended
  *   x f32[N1,C1] (ldx), idx i32[M, ld_idx] (column 0 is read), skip f32[M,C2] (lds; NULL when C2 = 0), W f32[C1+C2, N] (ldb)
- *   C1 % 4 == 0 when C2 > 0.  M_dev / N1_dev / M_hint as for d3f_gemm_f32; workspace: d3f_gemm_workspace_bytes(M, N, C1+C2, M_hint). */
+ *   C1 % 4 == 0 when C2 > 0.  M_dev / N1_dev / M_hint as for d3f_gemm_f32; workspace: d3f_gemm_workspace_bytes(M, N, C1+C2, M_hint).
+ * idx == NULL: no gather, A = [ x[m] | skip[m] ] -- used to contract the two branches of a resnet block in one launch
+ * (models/network_blocks.py:321-368: conv3 + shortcut, batch-norm scales folded into the stacked weights). */
 int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1, const int* idx, int ld_idx,
                               const float* skip, int lds, int C2, const float* W, int ldb, float* C, int ldc,
                               int M, int N, const float* col_scale, const float* col_shift, int leaky, float alpha,
