@@ -229,7 +229,7 @@ struct GsOrderArgs {
     int max_m;      // largest element the grid-wide rounds were launched for (capacity mode); larger ones are skipped
 };
 
-__global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A) {
+__global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int small_last) {
     __shared__ int wsum[16];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A) {
     const long long bbase = A.el[b].bbase;
     int lo = 0;
     bool done = false;
-    for (int j = 0; j <= GS_SMALL_LAST; ++j) {
+    for (int j = 0; j <= small_last && j < D3F_NCHAIN; ++j) {
         const int nb = (int)D3F_CHAIN_DEV[j];
         const double inv_nb = 1.0 / (double)nb;
         const bool last = M <= nb;
@@ -304,9 +304,9 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A) {
         if (last) { done = true; break; }
         lo = hi;
     }
-    if (!done) {
+    if (!done && small_last + 1 < D3F_NCHAIN) {
         // prepare the bucket arrays of the first grid-wide round
-        const int j = GS_SMALL_LAST + 1;
+        const int j = small_last + 1;
         const int nb = (int)D3F_CHAIN_DEV[j];
         int* BF = A.bf[j & 1] + bbase;
         int* BC = A.bc[j & 1] + bbase;
@@ -615,7 +615,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
                                                slot, meta);
     D3F_LAUNCH_CHECK();
     GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap};
-    if ((rc = d3f_scan_fold_launch(GsMarkIn{offs + B, slot, tfirst}, N, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
+    if ((rc = d3f_scan_fold_launch(GsMarkIn{offs + B, slot, tfirst}, N, offs + B, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
         return rc;
     int M, maxM;       // sizes of the voxel-indexed launches
     if (!async) {
@@ -635,12 +635,16 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
 
     gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, vbase, pvid, vkey, vhead, vcnt, pnext, offs + B);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
+    if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, meta, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
         return rc;
     gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
     // ---- libstdc++ iteration order ----
-    gs_order_small_kernel<<<B, 1024, 0, stream>>>(A);
-    for (int j = GS_SMALL_LAST + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
+    // Rounds > GS_SMALL_LAST are spread grid-wide.  (Keeping ALL rounds in the single workgroup per element saves ~50 launches
+    // per fragment but was measured slower end to end, 580 vs 640 fragments/s: the serial rounds of the 30 k-voxel stage sit
+    // on every fragment's critical path and four fragments in flight do not hide them.)
+    const int small_last = GS_SMALL_LAST;
+    gs_order_small_kernel<<<B, 1024, 0, stream>>>(A, small_last);
+    for (int j = small_last + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
         const long long nbj = (long long)D3F_CHAIN_HOST[j];
         const int hi = (int)((long long)maxM < nbj ? (long long)maxM : nbj);
         dim3 g(d3f_cdiv(hi, 256), B), gt(d3f_cdiv(hi, GS_TILE), B);

@@ -157,9 +157,10 @@ __device__ __forceinline__ int d3f_scan_at(const int* __restrict__ local, const 
 // in(i) -> item i (i < n).  local[i] = exclusive scan inside i's tile; base[t] = sum of the tiles before t (written by the
 // last workgroup); epi(total) runs in the last workgroup (all 256 threads) after `base` is complete.
 template <class In, class Epi>
-__global__ void __launch_bounds__(256) scan_fold_kernel(In in, int n, int* __restrict__ local, int* __restrict__ base,
-                                                        unsigned* __restrict__ counter, Epi epi) {
+__global__ void __launch_bounds__(256) scan_fold_kernel(In in, int n, const int* __restrict__ n_dev, int* __restrict__ local,
+                                                        int* __restrict__ base, unsigned* __restrict__ counter, Epi epi) {
     __shared__ int lds[4];
+    n = d3f_dyn(n, n_dev);   // items beyond the device-side count are zeros that are neither read nor written
     const int i0 = blockIdx.x * D3F_SCAN_TILE + threadIdx.x * 4;
     int v[4], s = 0;
 #pragma unroll
@@ -202,9 +203,10 @@ struct D3fNoEpi {
 static inline size_t d3f_scan_base_ints(int n) { return (size_t)d3f_cdiv(n > 0 ? n : 1, D3F_SCAN_TILE) + 64; }
 
 template <class In, class Epi>
-static inline int d3f_scan_fold_launch(In in, int n, int* local, int* base, unsigned* counter, Epi epi, hipStream_t stream) {
+static inline int d3f_scan_fold_launch(In in, int n, const int* n_dev, int* local, int* base, unsigned* counter, Epi epi,
+                                       hipStream_t stream) {
     const int nb = d3f_cdiv(n > 0 ? n : 1, D3F_SCAN_TILE);
-    scan_fold_kernel<In, Epi><<<nb, 256, 0, stream>>>(in, n, local, base, counter, epi);
+    scan_fold_kernel<In, Epi><<<nb, 256, 0, stream>>>(in, n, n_dev, local, base, counter, epi);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

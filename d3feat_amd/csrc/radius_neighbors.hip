@@ -77,7 +77,8 @@ __device__ __forceinline__ void nb_prep(const unsigned* __restrict__ bbox, const
         base += (long long)e.dims[0] * e.dims[1] * e.dims[2];
         el[b] = e;
     }
-    *ncells_total = (int)base;
+    ncells_total[0] = (int)base;
+    ncells_total[1] = (int)base + 1;   // items of the cell scan: the searches also read the prefix one past the last cell
 }
 
 // epilogue of the bounding-box kernel: the last workgroup derives the grid geometry from the finished boxes
@@ -343,7 +344,7 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
         nb_count_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs, B, g.el, g.cell_of, g.cell_cnt);
         D3F_LAUNCH_CHECK();
     }
-    if ((rc = d3f_scan_fold_launch(D3fScanIn{g.cell_cnt}, (int)g.cells, g.cell_start, g.stmp, g.counters + 1, D3fNoEpi{},
+    if ((rc = d3f_scan_fold_launch(D3fScanIn{g.cell_cnt}, (int)g.cells, g.ncells + 1, g.cell_start, g.stmp, g.counters + 1, D3fNoEpi{},
                                    stream)) != D3F_OK) return rc;
     if (Ns > 0) {
         nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs + B, g.cell_of, g.cell_start, g.stmp,
