@@ -283,6 +283,80 @@ head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __res
     }
 }
 
+// C == 32 (the shipped descriptor width): 8 lanes x float4 per row, so one half-wave instruction fetches FOUR neighbour rows
+// (4 row slots x 8 lanes) instead of one; the per-row sum for the non-zero count is a 3-step shuffle per four rows instead
+// of a 5-step one per row.  Same arithmetic per element as head_kernel except y = v * (1 / den) (reciprocal multiply).
+__global__ void __launch_bounds__(256)
+head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict__ idx, int ld_idx, int K,
+              const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
+              float* __restrict__ score, const int* __restrict__ row_order) {
+    N = min(N, offs[B]);
+    const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
+    if ((int)((blockIdx.x * blockDim.x) >> 5) >= N) return;
+    const bool active = half < N;
+    const int n = active ? (row_order ? row_order[half] : half) : 0;
+    const int slot = l >> 3, c4 = (l & 7) << 2;     // row slot 0..3, first of this lane's 4 channels
+    const int b = d3f_find_elem(offs, B, n);
+    const float den = d3f_ord2f(mx[b]) + 1e-6f;
+    const float rden = 1.0f / den;
+    const float4 xv = *(const float4*)&x[(size_t)n * ldx + c4];
+    const float4 yv = make_float4(xv.x * rden, xv.y * rden, xv.z * rden, xv.w * rden);
+    float sq = xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    const int hbase = threadIdx.x & 32;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;   // 32 indices per half-wave load
+        const int kn = min(32, K - k0);
+        for (int kk = 0; kk < kn; kk += 8) {       // two loads (8 neighbour rows) in flight per lane
+            int id[2];
+            float4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kq = kk + u * 4 + slot;
+                id[u] = __shfl(mine, hbase + min(kq, 31), 64);
+                if (kq >= kn || id[u] < 0 || id[u] >= N) id[u] = -1;   // shadow row: zeros
+                v[u] = id[u] >= 0 ? *(const float4*)&x[(size_t)id[u] * ldx + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // neighbours of a point belong to the point's own cloud (the searches are per batch element): same den
+                const float4 y = make_float4(v[u].x * rden, v[u].y * rden, v[u].z * rden, v[u].w * rden);
+                sum.x += y.x; sum.y += y.y; sum.z += y.z; sum.w += y.w;
+                float rs = (y.x + y.y) + (y.z + y.w);
+                rs += __shfl_xor(rs, 1, 64); rs += __shfl_xor(rs, 2, 64); rs += __shfl_xor(rs, 4, 64);
+                cnt += (id[u] >= 0 && rs != 0.f) ? 1 : 0;
+            }
+        }
+    }
+    // combine the four row slots (lanes l, l^8, l^16, l^24 hold the same channels)
+    sum.x += __shfl_xor(sum.x, 8, 64); sum.y += __shfl_xor(sum.y, 8, 64); sum.z += __shfl_xor(sum.z, 8, 64); sum.w += __shfl_xor(sum.w, 8, 64);
+    sum.x += __shfl_xor(sum.x, 16, 64); sum.y += __shfl_xor(sum.y, 16, 64); sum.z += __shfl_xor(sum.z, 16, 64); sum.w += __shfl_xor(sum.w, 16, 64);
+    cnt += __shfl_xor(cnt, 8, 64);
+    cnt += __shfl_xor(cnt, 16, 64);
+    const float fc = (float)max(cnt, 1);
+    float ymax = fmaxf(fmaxf(yv.x, yv.y), fmaxf(yv.z, yv.w));
+    ymax = fmaxf(ymax, __shfl_xor(ymax, 1, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, 2, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, 4, 64));
+    const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, ss[4] = {sum.x, sum.y, sum.z, sum.w};
+    float best = -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = yy[j] - ss[j] / fc;
+        float sp;   // softplus as TF computes it: log1p(exp(d)) with the large/small-argument shortcuts
+        if (d > 15.f) sp = d;
+        else if (d < -15.f) sp = expf(d);
+        else sp = log1pf(expf(d));
+        best = fmaxf(best, sp * (yy[j] / (1e-6f + ymax)));
+    }
+    best = fmaxf(best, __shfl_xor(best, 1, 64)); best = fmaxf(best, __shfl_xor(best, 2, 64)); best = fmaxf(best, __shfl_xor(best, 4, 64));
+    if (active && slot == 0) {
+        const float inv = rsqrtf(fmaxf(sq, 1e-10f));
+        *(float4*)&desc[(size_t)n * ldd + c4] = make_float4(xv.x * inv, xv.y * inv, xv.z * inv, xv.w * inv);
+        if (l == 0) score[n] = best;
+    }
+}
+
 extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
                                const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
                                int* scratch_dev, const int* row_order, void* stream_) {
@@ -298,7 +372,9 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     if (chunks < 1) chunks = 1;
     head_max_kernel<<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
     const int blocks = d3f_cdiv((long long)N * 32, 256);
-    if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
+    const bool vec32 = C == 32 && ldx % 4 == 0 && ldd % 4 == 0 && (((uintptr_t)x | (uintptr_t)desc) & 15) == 0;
+    if (vec32) head32_kernel<<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
+    else if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     else if (C <= 64) head_kernel<2><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     else head_kernel<4><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     D3F_LAUNCH_CHECK();
