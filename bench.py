@@ -205,6 +205,10 @@ def main():
                 key = "kpconv_c1_fused_kernel"
                 nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], 1, info["Cout"]), 0.0
                 per_step_agg[-1].append((info, ms))
+            elif name == "kpconv_fused32":
+                key = "kpconv_fused32_kernel"
+                nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], 32, 32), 0.0
+                per_step_agg[-1].append((info, ms))
             elif name == "gemm_f32":
                 key = "gemm_f32_kernel"
                 nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])

@@ -126,20 +126,31 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
         __syncthreads();
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
         const int kend = min(KC, K - k0);
-        for (int kk = 0; kk < kend; ++kk) {
-            const int id = lidx[ql * KC + kk];
-            if (id < 0) continue;
-            const float4 fv = *(const float4*)&f[(size_t)id * ldf + 4 * cl];
-            const float4* src = (const float4*)&lw[ql * WS + kk * 16];
-            const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-            const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                 w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        // feature rows are requested in groups of up to eight before any is consumed: the gathers are independent, so their
+        // latencies overlap instead of adding up (the kernel is bound by these round trips, not by the FMAs)
+        constexpr int PF = KC < 8 ? KC : 8;
+        for (int kg = 0; kg < kend; kg += PF) {
+            float4 fv[PF];
+            int ids[PF];
 #pragma unroll
-            for (int p = 0; p < KP_MAXP - 1; ++p) {
-                acc[p][0] = fmaf(w[p], fv.x, acc[p][0]);
-                acc[p][1] = fmaf(w[p], fv.y, acc[p][1]);
-                acc[p][2] = fmaf(w[p], fv.z, acc[p][2]);
-                acc[p][3] = fmaf(w[p], fv.w, acc[p][3]);
+            for (int u = 0; u < PF; ++u) {
+                ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
+                fv[u] = ids[u] >= 0 ? *(const float4*)&f[(size_t)ids[u] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (ids[u] < 0) continue;   // shadow neighbour: influence 0, feature row 0
+                const float4* src = (const float4*)&lw[ql * WS + (kg + u) * 16];
+                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+                for (int p = 0; p < KP_MAXP - 1; ++p) {
+                    acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
+                    acc[p][1] = fmaf(w[p], fv[u].y, acc[p][1]);
+                    acc[p][2] = fmaf(w[p], fv[u].z, acc[p][2]);
+                    acc[p][3] = fmaf(w[p], fv[u].w, acc[p][3]);
+                }
             }
         }
         __syncthreads();
@@ -278,6 +289,179 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
     const long long waves = d3f_cdiv(Nq, C1_QPW);
     kpconv_c1_fused_kernel<<<d3f_cdiv(waves * 64, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E,
                                                                          out, ldo, Nq_dev, Ns_dev);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole KPConv_ops (kernels/convolution_ops.py:161-255) + inference epilogue for Cin = Cout = 32 -- the two level-0
+// convolutions, which own the largest aggregation tensor of the network (wf = 58 739 x 480 floats = 113 MB written and read
+// back).  A workgroup owns 32 queries: phases A / B are kpconv_agg_vec4<8>'s; the 32 x 480 tile of weighted features then
+// stays in LDS and is contracted with K_values [480, 32] on the matrix cores (v_mfma_f32_32x32x2_f32, the four wavefronts
+// split the 240 k-steps and their partial tiles are summed through LDS), followed by the neighbour-count division,
+// batch norm and LeakyReLU.  Only out [Nq, 32] reaches HBM.
+// ------------------------------------------------------------------------------------------------
+typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
+
+#define KF_TQ 32
+#define KF_LQ 8
+#define KF_WS (KF_LQ * 16 + 4)        // phase-A stride per query (floats)
+#define KF_TS (15 * 32 + 1)           // wf tile stride per query: odd, so the MFMA A-fragment column reads hit 32 banks
+
+__global__ void __launch_bounds__(256)
+kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                      int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                      KpParams P, const float* __restrict__ W, KpEpi E, float* __restrict__ out, int ldo,
+                      const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
+    if ((int)(blockIdx.x * KF_TQ) >= Nq) return;
+    extern __shared__ __attribute__((aligned(16))) float kf_smem[];
+    float* wft = kf_smem;                                   // [32][481]  weighted-feature tile (MFMA A operand)
+    float* lw = kf_smem + KF_TQ * KF_TS;                    // [32][132]  phase-A influences; later the 4 partial out tiles
+    int* lidx = (int*)(lw + KF_TQ * KF_WS);                 // [32][8]
+    int* lcnt = lidx + KF_TQ * KF_LQ;                       // [32]
+    int* lq = lcnt + KF_TQ;                                 // [32] global query index of each tile row
+    const int tid = threadIdx.x;
+    const int ql = tid / KF_LQ, cl = tid % KF_LQ;
+    const int qslot = blockIdx.x * KF_TQ + ql;
+    const int qg = (q_order && qslot < Nq) ? q_order[qslot] : qslot;
+    if (tid < KF_TQ) lcnt[tid] = 0;
+    if (cl == 0) lq[ql] = qslot < Nq ? qg : -1;
+    float acc[KP_MAXP - 1][4];
+#pragma unroll
+    for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (qslot < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += KF_LQ) {
+        {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
+            const int k = k0 + cl;
+            int id = Ns;
+            if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
+            float w[KP_MAXP];
+            if (id >= 0 && id < Ns) {
+                kp_influences(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
+                if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
+            } else {
+                id = -1;
+#pragma unroll
+                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
+            }
+            lidx[ql * KF_LQ + cl] = id;
+            float4* dst = (float4*)&lw[ql * KF_WS + cl * 16];
+            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
+            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
+            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
+        }
+        __syncthreads();
+        // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
+        // all eight feature rows of the chunk are requested before any is consumed: the gathers are independent, so their
+        // latencies overlap instead of adding up (the kernel is bound by these round trips, not by the FMAs)
+        float4 fv[KF_LQ];
+        int ids[KF_LQ];
+#pragma unroll
+        for (int kk = 0; kk < KF_LQ; ++kk) {
+            ids[kk] = lidx[ql * KF_LQ + kk];
+            fv[kk] = ids[kk] >= 0 ? *(const float4*)&f[(size_t)ids[kk] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KF_LQ; ++kk) {
+            if (ids[kk] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
+            const float4* src = (const float4*)&lw[ql * KF_WS + kk * 16];
+            const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                 w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+            for (int p = 0; p < KP_MAXP - 1; ++p) {
+                acc[p][0] = fmaf(w[p], fv[kk].x, acc[p][0]);
+                acc[p][1] = fmaf(w[p], fv[kk].y, acc[p][1]);
+                acc[p][2] = fmaf(w[p], fv[kk].z, acc[p][2]);
+                acc[p][3] = fmaf(w[p], fv[kk].w, acc[p][3]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- weighted features of this thread -> LDS tile: wft[ql][p*32 + 4*cl + j]  (k index = p*Cin + c, as K_values) ----
+#pragma unroll
+    for (int p = 0; p < KP_MAXP - 1; ++p) {
+        float* d = &wft[ql * KF_TS + p * 32 + 4 * cl];
+        d[0] = acc[p][0]; d[1] = acc[p][1]; d[2] = acc[p][2]; d[3] = acc[p][3];
+    }
+    __syncthreads();
+    // ---- contraction on the matrix cores: out[32 x 32] = wft[32 x 480] @ W[480 x 32]; wave w owns k-steps [60w, 60w+60) ----
+    const int lane = tid & 63, wave = tid >> 6;
+    kp_f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    const int ksteps = P.num_kp * 16;                 // k-steps of 2
+    const int per = (ksteps + 3) / 4;
+    const int kb = wave * per, ke = min(ksteps, kb + per);
+    const float* ap = &wft[(lane & 31) * KF_TS + (lane >> 5)];
+    const float* bp = W + (size_t)(lane >> 5) * 32 + (lane & 31);
+    for (int kk = kb; kk < ke; kk += 4) {
+        float a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k2 = min(kk + u, ke - 1) * 2;
+            a4[u] = ap[k2];
+            b4[u] = bp[(size_t)k2 * 32];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (kk + u < ke) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u], c, 0, 0, 0);
+    }
+    // partial tiles -> LDS (the phase-A region is free now), sum of the four in wave order, epilogue
+    float* red = lw;                                        // [4][32*32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[wave * 1024 + row * 32 + (lane & 31)] = c[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, row = e >> 5, o = e & 31;
+        const int gq = lq[row];
+        if (gq < 0) continue;
+        float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+        v *= 1.0f / fmaxf((float)lcnt[row], 1.0f);
+        if (E.col_scale) v *= E.col_scale[o];
+        if (E.col_shift) v += E.col_shift[o];
+        if (E.residual) v += E.residual[(size_t)gq * E.ldr + o];
+        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+        out[(size_t)gq * ldo + o] = v;
+    }
+}
+
+extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                                  const float* f, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                                  float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
+                                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out,
+                                  int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 32 || (ldf % 4) || num_kp < 1 || num_kp > KP_MAXP - 1 ||
+        influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || ldo < 32 ||
+        (residual && ldr < 32))
+        return D3F_ERR_ARG;
+    if (Nq == 0) return D3F_OK;
+    if (!q || !s || !idx || !f || !rowpos || !kp_host || !W || !out || (((uintptr_t)f) & 15)) return D3F_ERR_ARG;
+    KpParams P;
+    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
+    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
+    P.aggregation = aggregation;
+    KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
+    const size_t lds = (size_t)(KF_TQ * KF_TS + KF_TQ * KF_WS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kpconv_fused32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return D3F_ERR_HIP;
+        attr_set = true;
+    }
+    kpconv_fused32_kernel<<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, out,
+                                                                     ldo, Nq_dev, Ns_dev, q_order);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

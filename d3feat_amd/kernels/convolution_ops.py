@@ -55,6 +55,10 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
         # input layer: one fused kernel (gather + influences + 15-term contraction + epilogue)
         return ops.kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values,
                                    KP_extent, KP_influence, aggregation_mode, **(epilogue or {}))
+    if cin == 32 and cout == 32 and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0:
+        # level-0 convolutions: aggregation + contraction + epilogue in one kernel, the 113 MB wf tensor stays in LDS
+        return ops.kpconv_fused32(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
+                                  KP_influence, aggregation_mode, **(epilogue or {}))
     wf, inv_cnt = ops.kpconv_aggregate(query_points, support_points, neighbors_indices, features, K_points, KP_extent,
                                        KP_influence, aggregation_mode)
     return ops.gemm(wf, K_values.reshape(num_kp * cin, cout), row_scale=inv_cnt, **(epilogue or {}))

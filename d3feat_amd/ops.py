@@ -445,6 +445,45 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
     return _tag(wf, query_points), _tag(inv_cnt, query_points)
 
 
+def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
+                   KP_influence="linear", aggregation_mode="sum", col_scale=None, col_shift=None, residual=None,
+                   leaky=False, alpha=0.2):
+    """Whole KPConv (+ epilogue) for Cin = Cout = 32 in one kernel (the aggregation tile is contracted from LDS)."""
+    lib = _lib.load()
+    q = _req(query_points, torch.float32, "query_points", 2).contiguous()
+    s = _req(support_points, torch.float32, "support_points", 2).contiguous()
+    idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
+    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    kp = np.ascontiguousarray(K_points.detach().cpu().numpy() if isinstance(K_points, torch.Tensor) else K_points,
+                              dtype=np.float32)
+    num_kp, cin, cout = K_values.shape
+    if cin != 32 or cout != 32 or f.shape[1] != 32:
+        raise ValueError("kpconv_fused32 needs Cin == Cout == 32")
+    W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
+    Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
+    dev = q.device
+    out = torch.empty((Nq, cout), dtype=torch.float32, device=dev)
+    row_pos = torch.empty((max(Ns, 1),), dtype=torch.uint8, device=dev)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
+    st = _stream(dev)
+    nq_dev, ns_dev = _nd(query_points), _nd(support_points)
+    if ns_dev is None:
+        ns_dev = _nd(features)
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, 32, row_pos.data_ptr(), ns_dev, st), "row_positive")
+    with _timed("kpconv_fused32", dict(Nq=Nq, Ns=Ns, K=K, Cin=32, Cout=32), dev):
+        rc = lib.d3f_kpconv_fused32(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
+                                    row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
+                                    _AGGREGATION[aggregation_mode], W.data_ptr(),
+                                    col_scale.data_ptr() if col_scale is not None else None,
+                                    col_shift.data_ptr() if col_shift is not None else None,
+                                    residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
+                                    float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), st)
+    _lib.check(rc, "kpconv_fused32")
+    return _tag(out, query_points)
+
+
 def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
                     KP_influence="linear", aggregation_mode="sum", col_scale=None, col_shift=None, residual=None,
                     leaky=False, alpha=0.2):

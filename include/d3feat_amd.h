@@ -168,6 +168,17 @@ int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const in
                         const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
                         const int* Nq_dev, const int* Ns_dev, void* stream);
 
+/* Whole KPConv_ops + inference epilogue for Cin = Cout = 32 (the level-0 convolutions of the shipped architecture) in one
+ * launch: gather + influences + aggregation as d3f_kpconv_aggregate, then the 32 x (num_kp*32) tile of weighted features is
+ * contracted with K_values on the matrix cores straight from LDS -- the wf tensor (Nq x 480 floats) never reaches HBM.
+ *   W f32[num_kp*32, 32] (= K_values reshaped, contiguous);  out f32[Nq, 32] (ldo);  row_pos from d3f_row_positive(f)
+ *   out = act( (wf @ W) / max(count, 1) * col_scale + col_shift + residual ) */
+int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                       const float* f, int ldf, const unsigned char* row_pos, const float* kp_host, int num_kp,
+                       float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
+                       const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
+                       const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
  * Replaces kernels/convolution_ops.py:90-99 (unary_convolution = tf.matmul) and :243-253 (the
