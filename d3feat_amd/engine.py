@@ -24,20 +24,20 @@ from .datasets.common import FragmentDataset
 from .models.KPFCNN_model import KernelPointFCNN
 
 
-def level_caps(n0_cap, num_layers, ratio=0.4):
+def level_caps(n0_cap, num_layers, ratio=0.4, clouds=2):
     """Row capacities of the stacked self-pair pyramid: level 0 holds 2*n0_cap rows, every further level `ratio` of the
     previous.  Grid subsampling at a doubled cell size keeps ~0.25-0.27 of surface samples; a cloud that
     exceeds a capacity is flagged on the device and recomputed by the eager path, so the ratio trades memory / idle
     workgroups against fallbacks, never correctness."""
-    caps = [2 * int(n0_cap)]
+    caps = [clouds * int(n0_cap)]
     for _ in range(1, num_layers):
         caps.append(max(int(np.ceil(caps[-1] * ratio)), 256))
     return caps
 
 
-def level_hints(n0_hint, num_layers, ratio=0.26):
+def level_hints(n0_hint, num_layers, ratio=0.26, clouds=2):
     """Expected row counts per level (launch planning only, e.g. the K split of the skinny deep-layer contractions)."""
-    h = [2 * int(n0_hint)]
+    h = [clouds * int(n0_hint)]
     for _ in range(1, num_layers):
         h.append(max(int(h[-1] * ratio), 64))
     return h
@@ -49,38 +49,49 @@ class _Slot:
 
 class FragmentEngine:
     def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
-                 device=None, seed=42, n0_hint=None):
+                 device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None):
+        """mirror_self_pair=False: the stacked self-pair [cloud; cloud] is computed row by row, exactly the work of the
+        reference's test generators (datasets/ThreeDMatch.py:190-192).  True: the pair's two halves are identical by
+        construction (per-cloud searches, per-cloud head normalisation), so ONE copy is computed (stack of one cloud) and the
+        outputs are mirrored into the stacked layout -- same results to fp32 summation order, half the work."""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.device = config, device
         self.limits = np.asarray(neighborhood_limits, np.int32)
         self.raw_cap, self.n0_cap = int(raw_cap), int(n0_cap)
-        self.caps = level_caps(n0_cap, config.num_layers, level_ratio)
+        self.mirror = bool(mirror_self_pair)
+        clouds = 1 if self.mirror else 2
+        self.caps = level_caps(n0_cap, config.num_layers, level_ratio, clouds)
         self.n0_hint = int(n0_hint if n0_hint is not None else n0_cap / 1.3)
-        self.hints = level_hints(self.n0_hint, config.num_layers)
+        self.hints = level_hints(self.n0_hint, config.num_layers, clouds=clouds)
         self.model = KernelPointFCNN(None, config, weights=weights, seed=seed, device=device)
         # eager fallback path (also the warm-up that uploads the weights before any capture)
         self._eager_ds = FragmentDataset([], fast=True)
         self._eager_ds.device = device
         self._eager_ds.neighborhood_limits = self.limits
         self._eager_map = self._eager_ds.get_tf_mapping(config)
-        self.slots = [self._build_slot() for _ in range(int(slots))]
+        # one HIP stream per slot (pass `streams` to share them between engines: the runtime multiplexes every stream of the
+        # process onto a few hardware queues, so idle extra streams still cost concurrency)
+        self.slots = [self._build_slot(streams[i] if streams else None) for i in range(int(slots))]
         self.fallbacks = 0
 
     # ---- the fixed launch sequence -------------------------------------------------------------------------------
     def _sequence(self, sl):
         cfg = self.cfg
         sub, _, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.n0_cap,
-                                                     status=sl.status0, m_hint=self.n0_hint)
-        pts, lens = ops.stack_self_pair(sub)
+                                                     status=sl.status0, m_hint=self.n0_hint)   # _ = lens of the result
+        if self.mirror:
+            pts, lens = sub, _  # one cloud: lens = [m] as written by the subsampling
+        else:
+            pts, lens = ops.stack_self_pair(sub)
         flat = sl.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
         return pts, desc, score, sl.ds.static_status
 
-    def _build_slot(self):
+    def _build_slot(self, stream=None):
         dev = self.device
         sl = _Slot()
-        sl.stream = torch.cuda.Stream(device=dev)
+        sl.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         sl.raw = torch.zeros((self.raw_cap, 3), dtype=torch.float32, device=dev)
         sl.raw_len = torch.zeros((1,), dtype=torch.int32, device=dev)
         sl.status0 = torch.zeros((2,), dtype=torch.int32, device=dev)
@@ -128,9 +139,11 @@ class FragmentEngine:
             return
         sl.oversize = False
         sl.host_n[0] = n
+        cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(sl.stream):
-            if raw.is_cuda:
-                sl.stream.wait_stream(torch.cuda.default_stream(self.device))   # `raw` may have been produced there
+            # `raw` may have been produced on the caller's stream, and (mirror mode) the previous result of this slot may
+            # still be being copied out there
+            sl.stream.wait_stream(cur)
             sl.raw[:n].copy_(raw, non_blocking=True)
             sl.raw_len.copy_(sl.host_n, non_blocking=True)
             sl.graph.replay()
@@ -153,6 +166,9 @@ class FragmentEngine:
             flags = int(st[2]) | (int(np.bitwise_or.reduce(st[4::2])) if sl.nstat > 3 else 0)
             n = int(st[0])
             if flags == 0:
+                if self.mirror:   # stacked layout of the reference: both halves hold the cloud
+                    return (torch.cat([sl.pts[:n], sl.pts[:n]]), torch.cat([sl.desc[:n], sl.desc[:n]]),
+                            torch.cat([sl.score[:n], sl.score[:n]]))
                 return sl.pts[:n], sl.desc[:n], sl.score[:n]
         # capacity exceeded / large ordering budget needed / degenerate cloud: the eager path decides (and raises the
         # reference-level errors where they apply)

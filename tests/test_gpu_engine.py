@@ -110,3 +110,21 @@ def test_capacity_mode_ops_match_sync_ops(device, coracle):
     k = min(37, wn.shape[1])
     assert np.array_equal(got[:, :k], wn[:, :k])
     assert status.tolist()[0] == wn.shape[1]
+
+
+def test_engine_mirror_mode_equals_stacked_pair(device, setup):
+    """mirror_self_pair=True computes the cloud once and mirrors it into the stacked layout: same points bit for bit, same
+    descriptors / scores up to fp32 summation order (the K split of the contractions depends on the row count)."""
+    from d3feat_amd.engine import FragmentEngine
+    cfg, W, limits = setup
+    eng = FragmentEngine(cfg, W, limits, raw_cap=60000, n0_cap=14000, slots=2, device=device, mirror_self_pair=True)
+    for seed, n in ((31, 40000), (32, 25000)):
+        raw = torch.from_numpy(_frag(seed, n)).to(device)
+        pts, d, s = eng.run(raw, slot=seed % 2)
+        ep, ed, es = eng.run_eager(raw)
+        assert eng.fallbacks == 0
+        assert pts.shape == ep.shape and torch.equal(pts, ep)
+        _close(d, ed, 5e-6)
+        _close(s, es, 5e-6)
+        m = pts.shape[0] // 2
+        assert torch.equal(d[:m], d[m:]) and torch.equal(s[:m], s[m:])
