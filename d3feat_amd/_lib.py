@@ -35,7 +35,7 @@ SIGNATURES = {
     "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
     "d3f_kpconv_fused_c1": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
-                                 _f, _vp, _i, _vp, _vp, _vp]),
+                                 _f, _vp, _i, _vp, _vp, _vp, _vp]),
     "d3f_kpconv_fused32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp,
                                 _i, _vp, _vp, _vp, _vp]),
     "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -269,11 +269,96 @@ kpconv_c1_fused_kernel(const float* __restrict__ q, int Nq, const float* __restr
     }
 }
 
+// Second form of the Cin = 1 kernel, used for aggregation 'sum': lanes = (query, kernel point) instead of (neighbour).
+// A wavefront owns 4 queries x 16 lanes; lane p of a query walks that query's neighbours and accumulates the influence of ITS
+// kernel point only (lane 15 counts the positive neighbours), so no cross-lane reduction of 15 sums per query is needed
+// (the neighbour-lane form spends 90 shuffles per query on it).  The 15-term contraction with K_values[:,0,:] then runs over
+// an LDS copy of the 16 x 16 sums with lanes = output channels.
+__global__ void __launch_bounds__(256)
+kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                    int ld_idx, int K, const float* __restrict__ f, int ldf, KpParams P, const float* __restrict__ W,
+                    int Cout, KpEpi E, float* __restrict__ out, int ldo, const int* __restrict__ Nq_dev,
+                    const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
+    if ((int)(blockIdx.x * 16) >= Nq) return;
+    __shared__ float skp[KP_MAXP * 3];
+    __shared__ float sacc[16][17];
+    __shared__ int sq[16];
+    const int tid = threadIdx.x, p = tid & 15, ql = tid >> 4;
+    if (tid < KP_MAXP * 3) skp[tid] = P.kp[tid];
+    const int qslot = blockIdx.x * 16 + ql;
+    const bool live = qslot < Nq;
+    const int qi = live ? (q_order ? q_order[qslot] : qslot) : 0;
+    if (p == 0) sq[ql] = live ? qi : -1;
+    __syncthreads();
+    const float kx = skp[3 * p], ky = skp[3 * p + 1], kz = skp[3 * p + 2];
+    const bool kp_lane = p < P.num_kp;
+    const float qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
+    const int* row = idx + (size_t)qi * ld_idx;
+    float acc = 0.f;       // lanes 0..14: sum_k h_p * f;  lane 15: number of neighbours with f > 0
+    const float sig = P.extent * 0.3f, gden = 2.0f * sig * sig + 1e-9f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int mine = (live && k0 + p < K) ? row[k0 + p] : -1;      // 16 indices per group load
+        const int kn = min(16, K - k0);
+        for (int kk = 0; kk < kn; kk += 4) {                           // 4 neighbours in flight
+            int id[4];
+            float px[4], py[4], pz[4], fv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                id[u] = __shfl(mine, min(kk + u, 15), 16);
+                const bool ok = kk + u < kn && id[u] >= 0 && id[u] < Ns;
+                if (!ok) id[u] = -1;
+                const size_t o3 = 3 * (size_t)(ok ? id[u] : 0);
+                px[u] = s[o3]; py[u] = s[o3 + 1]; pz[u] = s[o3 + 2];
+                fv[u] = ok ? f[(size_t)id[u] * ldf] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (id[u] < 0) continue;
+                if (p == 15) { acc += (fv[u] > 0.f) ? 1.f : 0.f; continue; }
+                const float dx = (px[u] - qx) - kx, dy = (py[u] - qy) - ky, dz = (pz[u] - qz) - kz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                float h;
+                if (P.influence == 1) h = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2 + 1e-10f) * P.inv_2extent, 0.0f);
+                else if (P.influence == 0) h = 1.0f;
+                else h = expf(-d2 / gden);
+                acc = fmaf(h, fv[u], acc);
+            }
+        }
+    }
+    sacc[ql][p] = (kp_lane || p == 15) ? acc : 0.f;
+    __syncthreads();
+    // contraction + epilogue: thread -> output channel o = tid % 64 (+64 per pass), queries tid/64 + 4*i
+    for (int o0 = 0; o0 < Cout; o0 += 64) {
+        const int o = o0 + (tid & 63);
+        float wreg[KP_MAXP - 1];
+#pragma unroll
+        for (int pp = 0; pp < KP_MAXP - 1; ++pp) wreg[pp] = (pp < P.num_kp && o < Cout) ? W[(size_t)pp * Cout + o] : 0.f;
+        const float cs = (E.col_scale && o < Cout) ? E.col_scale[o] : 1.f;
+        const float ch = (E.col_shift && o < Cout) ? E.col_shift[o] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qq = (tid >> 6) + 4 * i;
+            const int gq = sq[qq];
+            if (gq < 0 || o >= Cout) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < KP_MAXP - 1; ++pp) v = fmaf(sacc[qq][pp], wreg[pp], v);
+            v = v * (1.0f / fmaxf(sacc[qq][15], 1.0f)) * cs + ch;
+            if (E.residual) v += E.residual[(size_t)gq * E.ldr + o];
+            if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+            out[(size_t)gq * ldo + o] = v;
+        }
+    }
+}
+
 extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                                    const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
                                    int aggregation, const float* W, int Cout, const float* col_scale,
                                    const float* col_shift, const float* residual, int ldr, int leaky, float alpha,
-                                   float* out, int ldo, const int* Nq_dev, const int* Ns_dev, void* stream_) {
+                                   float* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                                   void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 1 || num_kp < 1 || num_kp > KP_MAXP - 1 || influence < 0 ||
         influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || Cout < 1 || ldo < Cout ||
@@ -286,9 +371,14 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
     P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
     P.aggregation = aggregation;
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
-    const long long waves = d3f_cdiv(Nq, C1_QPW);
-    kpconv_c1_fused_kernel<<<d3f_cdiv(waves * 64, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E,
-                                                                         out, ldo, Nq_dev, Ns_dev);
+    if (aggregation == 0 && num_kp <= 15) {
+        kpconv_c1_kp_kernel<<<d3f_cdiv(Nq, 16), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E, out, ldo,
+                                                                  Nq_dev, Ns_dev, q_order);
+    } else {   // 'closest' needs the arg-min over the kernel points of every neighbour: lanes = neighbours
+        const long long waves = d3f_cdiv(Nq, C1_QPW);
+        kpconv_c1_fused_kernel<<<d3f_cdiv(waves * 64, 256), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout,
+                                                                             E, out, ldo, Nq_dev, Ns_dev);
+    }
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

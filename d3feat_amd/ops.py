@@ -513,7 +513,7 @@ def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K
                                      col_shift.data_ptr() if col_shift is not None else None,
                                      residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
                                      float(alpha), out.data_ptr(), cout, _nd(query_points), _nd(support_points),
-                                     _stream(dev))
+                                     _order(query_points), _stream(dev))
     _lib.check(rc, "kpconv_fused_c1")
     return _tag(out, query_points)
 

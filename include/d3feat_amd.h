@@ -166,7 +166,7 @@ int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const in
                         const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
                         int aggregation, const float* W, int Cout, const float* col_scale, const float* col_shift,
                         const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
-                        const int* Nq_dev, const int* Ns_dev, void* stream);
+                        const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
 
 /* Whole KPConv_ops + inference epilogue for Cin = Cout = 32 (the level-0 convolutions of the shipped architecture) in one
  * launch: gather + influences + aggregation as d3f_kpconv_aggregate, then the 32 x (num_kp*32) tile of weighted features is
