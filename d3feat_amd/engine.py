@@ -49,18 +49,23 @@ class _Slot:
 
 class FragmentEngine:
     def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
-                 device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None):
+                 device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None, two_clouds=False):
         """mirror_self_pair=False: the stacked self-pair [cloud; cloud] is computed row by row, exactly the work of the
         reference's test generators (datasets/ThreeDMatch.py:190-192).  True: the pair's two halves are identical by
         construction (per-cloud searches, per-cloud head normalisation), so ONE copy is computed (stack of one cloud) and the
-        outputs are mirrored into the stacked layout -- same results to fp32 summation order, half the work."""
+        outputs are mirrored into the stacked layout -- same results to fp32 summation order, half the work.
+        two_clouds=True: every fragment is a pair of DIFFERENT clouds (the KITTI test generator, datasets/KITTI.py:94-106):
+        submit(slot, (raw_a, raw_b)); raw_cap / n0_cap then bound the SUM over the two clouds."""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.device = config, device
         self.limits = np.asarray(neighborhood_limits, np.int32)
         self.raw_cap, self.n0_cap = int(raw_cap), int(n0_cap)
         self.mirror = bool(mirror_self_pair)
-        clouds = 1 if self.mirror else 2
+        self.two = bool(two_clouds)
+        if self.two and self.mirror:
+            raise ValueError("mirror_self_pair and two_clouds exclude each other")
+        clouds = 1 if (self.mirror or self.two) else 2
         self.caps = level_caps(n0_cap, config.num_layers, level_ratio, clouds)
         self.n0_hint = int(n0_hint if n0_hint is not None else n0_cap / 1.3)
         self.hints = level_hints(self.n0_hint, config.num_layers, clouds=clouds)
@@ -80,8 +85,8 @@ class FragmentEngine:
         cfg = self.cfg
         sub, _, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.n0_cap,
                                                      status=sl.status0, m_hint=self.n0_hint)   # _ = lens of the result
-        if self.mirror:
-            pts, lens = sub, _  # one cloud: lens = [m] as written by the subsampling
+        if self.mirror or self.two:
+            pts, lens = sub, _  # the stack as subsampled: lens = [m] (mirror) or [m_a, m_b] (two clouds), on the device
         else:
             pts, lens = ops.stack_self_pair(sub)
         flat = sl.map(pts, None, None, None, lens, ("a", "a"), pts)
@@ -93,9 +98,10 @@ class FragmentEngine:
         sl = _Slot()
         sl.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         sl.raw = torch.zeros((self.raw_cap, 3), dtype=torch.float32, device=dev)
-        sl.raw_len = torch.zeros((1,), dtype=torch.int32, device=dev)
+        nb = 2 if self.two else 1
+        sl.raw_len = torch.zeros((nb,), dtype=torch.int32, device=dev)
         sl.status0 = torch.zeros((2,), dtype=torch.int32, device=dev)
-        sl.host_n = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        sl.host_n = torch.zeros((nb,), dtype=torch.int32).pin_memory()
         sl.ds = FragmentDataset([], fast=True)
         sl.ds.device = dev
         sl.ds.neighborhood_limits = self.limits
@@ -110,7 +116,7 @@ class FragmentEngine:
             g = torch.Generator(device="cpu").manual_seed(0)
             warm = torch.rand((4096, 3), generator=g) * torch.tensor([1.0, 1.0, 0.05])
             sl.raw[:4096].copy_(warm.to(dev))
-            sl.raw_len.fill_(4096)
+            sl.raw_len.fill_(4096 // nb)
             with ops.private_workspace():
                 self._sequence(sl)
         sl.stream.synchronize()
@@ -131,20 +137,27 @@ class FragmentEngine:
         """Start fragment `raw` (float32 [n,3], on the device or the host) on slot `slot`; returns immediately."""
         sl = self.slots[slot]
         assert not sl.busy, "slot %d still holds an unfetched fragment" % slot
-        n = int(raw.shape[0])
+        parts = list(raw) if self.two else [raw]
+        if self.two and len(parts) != 2:
+            raise ValueError("two_clouds engine: submit(slot, (raw_a, raw_b))")
+        n = sum(int(p.shape[0]) for p in parts)
         sl.n_raw, sl.raw_src = n, raw
         sl.busy = True
-        if n > self.raw_cap:
+        if n > self.raw_cap or min(int(p.shape[0]) for p in parts) == 0:
             sl.oversize = True
             return
         sl.oversize = False
-        sl.host_n[0] = n
+        for i, p in enumerate(parts):
+            sl.host_n[i] = int(p.shape[0])
         cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(sl.stream):
             # `raw` may have been produced on the caller's stream, and (mirror mode) the previous result of this slot may
             # still be being copied out there
             sl.stream.wait_stream(cur)
-            sl.raw[:n].copy_(raw, non_blocking=True)
+            o = 0
+            for p in parts:
+                sl.raw[o:o + p.shape[0]].copy_(p, non_blocking=True)
+                o += int(p.shape[0])
             sl.raw_len.copy_(sl.host_n, non_blocking=True)
             sl.graph.replay()
             # pack [n_total | status0 | statuses] and bring it back with one small copy
@@ -176,11 +189,16 @@ class FragmentEngine:
         return self.run_eager(sl.raw_src)
 
     def run_eager(self, raw):
-        raw = raw if raw.is_cuda else raw.to(self.device)
-        sub = tfo.grid_subsampling(raw, self.cfg.first_subsampling_dl)
-        n = sub.shape[0]
-        pts = torch.cat([sub, sub], 0)
-        lens = ops.as_lens([n, n], self.device)
+        if self.two:
+            subs = [tfo.grid_subsampling(p if p.is_cuda else p.to(self.device), self.cfg.first_subsampling_dl) for p in raw]
+            pts = torch.cat(subs, 0)
+            lens = ops.as_lens([int(x.shape[0]) for x in subs], self.device)
+        else:
+            raw = raw if raw.is_cuda else raw.to(self.device)
+            sub = tfo.grid_subsampling(raw, self.cfg.first_subsampling_dl)
+            n = sub.shape[0]
+            pts = torch.cat([sub, sub], 0)
+            lens = ops.as_lens([n, n], self.device)
         flat = self._eager_map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
         return pts, desc, score
