@@ -19,8 +19,10 @@
 //     "buckets by DEscending first-insertion position, inside a bucket by DEscending position", and a
 //     rehash re-inserts the current list order.  So the order is ~log2(M) rounds of
 //     {bucket first-position (atomicMin), bucket sizes, reverse scan, rank inside bucket chain}, each fully
-//     parallel; one 1024-thread workgroup per batch element runs all rounds inside one launch (total work
-//     ~2M element-steps), batch elements in parallel.
+//     parallel: rounds up to 1109 buckets run in ONE 1024-thread workgroup per batch element, larger rounds grid-wide
+//     (insert / tile scan + tile sums in its last workgroup / place);
+//   * 9 + 3*rounds launches per call (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
+//     (d3f_batch_grid_subsample_async) all sizes stay on the device and an overflowing call reports an empty result.
 #include "prims.h"
 
 #define GS_EMPTY 0xFFFFFFFFFFFFFFFFull

@@ -1,21 +1,26 @@
-// KPConv phase 1 on gfx950: neighbour gather + kernel-point influences + weighted aggregation.
+// KPConv on gfx950: neighbour gather + kernel-point influences + weighted aggregation (+ fused contraction / epilogue).
 //
 // Reference: kernels/convolution_ops.py:161-255 (KPConv_ops).  The TF graph materialises
 // [n, K, 15, 3] differences and an [n, K, Cin] gather in memory (:200-205, :237); here both stay on chip:
 //   wf[n,p,c]  = sum_k h(|| (s[idx[n,k]] - q[n]) - KP[p] ||) * f[idx[n,k], c]          (:194-240)
 //   inv_cnt[n] = 1 / max(#{k : sum_c f[idx[n,k], c] > 0}, 1)                          (:250-252)
-// The dense contraction wf[n, 15*Cin] x K_values[15*Cin, Cout] (:243-247) and the division (:253) run on the
-// matrix cores in gemm_f32.hip (row_scale = inv_cnt).
+//   out[n,o]   = (sum_{p,c} wf[n,p,c] * K_values[p,c,o]) * inv_cnt[n]                 (:243-253)
 //
-// MI355X mapping (bandwidth/VALU bound; the feature rows live in L2 / Infinity Cache after the first touch):
-//  * kpconv_agg_vec4 (Cin % 4 == 0): a 256-thread workgroup owns TQ = 256/LQ queries, LQ = Cin/4 lanes per
+// Kernels (VALU / gather-latency bound; the feature rows live in L2 / Infinity Cache after the first touch):
+//  * kpconv_agg_vec4<LQ> (Cin % 4 == 0): a 256-thread workgroup owns TQ = 256/LQ queries, LQ = Cin/4 lanes per
 //    query, each lane owns 4 channels x 15 kernel points (60 accumulators in VGPRs).  Neighbours are processed
 //    in chunks of KC = LQ: first every thread computes the 15 influences of ONE (query, neighbour) pair and
 //    parks them in LDS (64 B per pair) together with the neighbour index; then each lane walks its query's
-//    chunk: one coalesced 16-byte feature load per neighbour (the LQ lanes of a query read one contiguous
-//    Cin*4-byte row), 4 LDS b128 broadcasts for the influences, 60 FMAs.  Shadow neighbours (idx >= Ns) are
-//    skipped: their influence is exactly 0 in the reference (shadow point at 1e6) and their feature row is 0.
-//  * kpconv_agg_scalar (any Cin, used for the Cin = 1 input layer): one thread per (query, channel).
+//    chunk: coalesced 16-byte feature loads (the LQ lanes of a query read one contiguous Cin*4-byte row), eight
+//    requested before any is consumed, 4 LDS b128 broadcasts for the influences, 60 FMAs.  Shadow neighbours
+//    (idx >= Ns) are skipped: their influence is exactly 0 in the reference (shadow point at 1e6), their row is 0.
+//    Writes wf / inv_cnt; the contraction runs on the matrix cores in gemm_f32.hip (row_scale = inv_cnt).
+//  * kpconv_fused32_kernel (Cin = Cout = 32, the level-0 convolutions): the same phases, then the 32 x 480 wf tile is
+//    contracted from LDS with v_mfma_f32_32x32x2_f32 and the BN / LeakyReLU epilogue applied: wf never reaches HBM.
+//  * kpconv_c1_kp_kernel (Cin = 1, the input layer, aggregation 'sum'): lanes = (query, kernel point), no cross-lane
+//    reduction; kpconv_c1_fused_kernel (lanes = neighbours) serves aggregation 'closest'.
+//  * kpconv_agg_scalar: any other Cin, one thread per (query, channel).
+// Queries are visited in the cell-sorted order of the neighbour grid when the caller passes it (q_order).
 #include "common.h"
 
 #define KP_MAXP D3F_NUM_KP_MAX  // 16 slots, 15 used by the reference

@@ -1,4 +1,4 @@
-// Fixed-radius neighbour search on gfx950: uniform cell grid + one wavefront per query.
+// Fixed-radius neighbour search on gfx950: uniform cell grid + 32 lanes (half a wavefront) per query.
 //
 // Reference: tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:211-332 (batch_nanoflann_neighbors, the active
 // path: KD-tree radiusSearch, rows sorted by d2) and :125-208 (batch_ordered_neighbors: brute force, stable).
@@ -9,15 +9,18 @@
 //   batch_ordered_neighbors and equals the nanoflann path except inside runs of bit-equal d2, whose order
 //   nanoflann leaves to an unstable sort; pad value = total number of supports.
 //
-// MI355X design (HBM/L2-bound gather work):
-//   build:  supports -> cell id (fp64 index arithmetic, cell edge slightly > radius so the 27-cell stencil is
-//           a guaranteed superset) -> counting sort by cell (atomic histogram, exclusive scan, scatter) into a
-//           float4 {x,y,z,index-bits} array: one 16-byte load per candidate, x-adjacent cells are contiguous,
-//           so the 27-cell stencil is 9 contiguous runs;
-//   search: one 64-lane wavefront per query streams the 9 runs, 64 candidates per step; hits are compacted
-//           into the wave's LDS segment with a ballot + popcount prefix (variable-length lists); the <=K hits
-//           are ordered by rank counting (each lane counts how many hits precede its own -- keys are unique so
-//           ranks are a permutation) and the first `width` ranks are stored straight into the output row.
+// MI355X design (bound by dependent L2 round trips, not by bytes: SQ counters show 75 % of wave cycles in s_waitcnt):
+//   build (5 launches): reset -> bounding boxes, the LAST workgroup derives the grid geometry (cell edge slightly > radius
+//           so the 27-cell stencil is a guaranteed superset; fp64 index arithmetic) -> atomic histogram -> one-launch
+//           scan -> scatter into a float4 {x,y,z,index-bits} array: one 16-byte load per candidate, x-adjacent cells are
+//           contiguous, so the 27-cell stencil is 9 contiguous runs.  The sorted index array doubles as a spatially
+//           coherent visiting order for every per-point kernel of the level;
+//   search (1 launch): LPQ = 32 lanes per query (two queries per wavefront) walk the 9 runs as one virtual list, two
+//           candidate loads in flight per lane; hits are compacted into the group's LDS segment with a ballot + popcount
+//           prefix (variable-length lists); the <= cap hits are ordered by rank counting (each lane counts how many hits
+//           precede its own, four per 128-bit LDS read -- keys are unique so ranks are a permutation) and the first `width`
+//           ranks are stored straight into the output row.  first_only keeps a running (d2, index) minimum instead.
+//   Sizes come from the device lens arrays (capacity mode): Nq / Ns only bound grids and buffers.
 #include "prims.h"
 #include <cstdlib>
 
