@@ -358,7 +358,9 @@ def cpu_baseline(cfg, W, limits, raws_host):
         net.append(b)
     tot = float(np.sum(pre) + np.sum(net))
     return {"value": round(len(raws_host) / tot, 4), "unit": "fragments/s", "cores": nthreads,
-            "kind": "reference" if use_ref else "port",
+            # geometry = the reference's own C++ (oracle/_ref) when available; the network half has no runnable reference
+            # (TensorFlow 1 is not installable here), it is the torch-CPU restatement -> "port" for the sum
+            "kind": "port", "geometry_kind": "reference" if use_ref else "port",
             "sample": "%d fragment(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
                       "thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads: %.3f s/fragment"
                       % (len(raws_host), "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
