@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-fragments", type=int, default=2)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
     ap.add_argument("--slots", type=int, default=4, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="fragments stacked into one graph replay (FragmentEngine(batch=F)); a step is still ONE fragment")
     ap.add_argument("--eager", action="store_true", help="op-by-op eager path instead of the graph engine")
     ap.add_argument("--mirror", action="store_true",
                     help="headline run with the self-pair computed once and mirrored (default: the full stacked pair)")
@@ -141,7 +143,8 @@ def main():
         raw_cap = int(max(r.shape[0] for r in raws) * 1.05) + 1024
         n0_cap = (int(max(len(x) for x in subs) * 1.3) + 1023) // 1024 * 1024
         engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, slots=args.slots, device=device,
-                                n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror)
+                                n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
+                                batch=args.batch)
 
     def run(nsteps, engine=engine):
         """nsteps fragments through the hot path; returns the last fragment's (pts, desc, score)."""
@@ -150,22 +153,27 @@ def main():
             for i in range(nsteps):
                 out = step(raws[i % len(raws)])
             return out
-        S = len(engine.slots)
+        S, F = len(engine.slots), engine.F
         busy = [False] * S
-        for i in range(nsteps):
-            sl = i % S
-            if busy[sl]:
-                out = engine.fetch(sl)
-            engine.submit(sl, raws[i % len(raws)])
-            busy[sl] = True
-        for k in range(nsteps, nsteps + S):      # drain in submission order
+        i = k = 0
+        while i < nsteps:                        # replays of up to F fragments each, round-robin over the slots
             sl = k % S
             if busy[sl]:
-                out = engine.fetch(sl)
+                out = engine.fetch(sl)[-1]
+            nb = min(F, nsteps - i)
+            engine.submit(sl, [raws[(i + j) % len(raws)] for j in range(nb)])
+            busy[sl] = True
+            i += nb
+            k += 1
+        for kk in range(k, k + S):               # drain in submission order
+            sl = kk % S
+            if busy[sl]:
+                out = engine.fetch(sl)[-1]
                 busy[sl] = False
         return out
 
-    out = run(args.warmup)
+    # at least W untimed steps; with the engine, enough of them to replay every slot's graph once
+    out = run(max(args.warmup, (args.slots * args.batch) if engine is not None else 0))
     if world > 1 and out is not None:
         parallel.gather_descriptors(*out)
     sync()
@@ -185,7 +193,7 @@ def main():
     if rank == 0 and world == 1 and engine is not None and not args.mirror and not args.no_mirror_extra:
         from d3feat_amd.engine import FragmentEngine as _FE
         eng2 = _FE(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, slots=args.slots, device=device,
-                   n0_hint=engine.n0_hint, mirror_self_pair=True, streams=[sl.stream for sl in engine.slots])
+                   n0_hint=engine.n0_hint, mirror_self_pair=True, streams=[sl.stream for sl in engine.slots], batch=args.batch)
         run(args.warmup, eng2)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
@@ -310,8 +318,10 @@ def main():
                        "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
                        "final_gather_ranks": len(gathered),
                        "execution": ("eager op-by-op launches" if engine is None else
-                                     "HIP-graph replay per fragment, device-resident sizes, %d fragments in flight%s"
-                                     % (len(engine.slots), "; self-pair computed once and mirrored" if args.mirror else "")),
+                                     "HIP-graph replay of %d stacked fragment(s), device-resident sizes, %d replays in flight%s"
+                                     % (engine.F, len(engine.slots),
+                                        "; self-pair computed once and mirrored" if args.mirror else "")),
+                       "fragments_per_replay": (engine.F if engine is not None else 1),
                        "engine_fallbacks": (engine.fallbacks if engine is not None else None)},
             "roofline": roof, "kpconv_layers_ms": layers, "cpu_baseline": cpu, "mirror_self_pair": mirror_extra,
         }

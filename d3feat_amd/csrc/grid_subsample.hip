@@ -690,25 +690,47 @@ extern "C" int d3f_batch_grid_subsample_async(const float* points, int N_cap, co
 }
 
 // np.concatenate([pts, pts]) of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:
-// 72-79: every fragment is fed stacked with itself) with the row count read from HBM: out[0:m] = out[m:2m] = pts[0:m],
-// lens_out = [m, m], total = 2m.
-__global__ void __launch_bounds__(256) gs_stack_pair_kernel(const float* __restrict__ pts, int M_cap, const int* __restrict__ m_dev,
-                                                            float* __restrict__ out, int* __restrict__ lens_out,
+// 72-79: every fragment is fed stacked with itself), for B clouds at once and with the row counts read from HBM:
+// cloud b (rows [o_b, o_b + m_b) of pts) becomes rows [2 o_b, 2 o_b + m_b) and [2 o_b + m_b, 2 o_b + 2 m_b) of out,
+// lens_out = [m_0, m_0, m_1, m_1, ...], total = 2 sum m_b.  B = 1 is the single self-pair.
+__global__ void __launch_bounds__(256) gs_stack_pair_kernel(const float* __restrict__ pts, int M_cap, const int* __restrict__ lens_in,
+                                                            int B, float* __restrict__ out, int* __restrict__ lens_out,
                                                             int* __restrict__ total) {
-    const int m = min(*m_dev, M_cap);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { lens_out[0] = m; lens_out[1] = m; *total = 2 * m; }
-    if (i >= 3 * m) return;
+    int tot = 0;
+    for (int b = 0; b < B; ++b) tot += lens_in[b];
+    tot = min(tot, M_cap);
+    if (i == 0) {
+        int room = M_cap;
+        for (int b = 0; b < B; ++b) {
+            const int m = min(lens_in[b], room);
+            room -= m;
+            lens_out[2 * b] = m;
+            lens_out[2 * b + 1] = m;
+        }
+        *total = 2 * tot;
+    }
+    if (i >= 3 * tot) return;
+    const int pi = i / 3, c = i - 3 * pi;
+    int start = 0, m = 0;
+    for (int b = 0; b < B; ++b) {        // cloud of point pi (B is small)
+        m = lens_in[b];
+        if (pi < start + m || b == B - 1) break;
+        start += m;
+    }
+    m = min(m, tot - start);
     const float v = pts[i];
-    out[i] = v;
-    out[(size_t)3 * m + i] = v;
+    const size_t row = 2 * (size_t)start + (size_t)(pi - start);
+    out[3 * row + c] = v;
+    out[3 * (row + m) + c] = v;
 }
 
-extern "C" int d3f_stack_self_pair(const float* pts, int M_cap, const int* m_dev, float* out, int* lens_out_dev,
+extern "C" int d3f_stack_self_pair(const float* pts, int M_cap, const int* lens_in_dev, int B, float* out, int* lens_out_dev,
                                    int* total_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (M_cap < 1 || !pts || !m_dev || !out || !lens_out_dev || !total_dev) return D3F_ERR_ARG;
-    gs_stack_pair_kernel<<<d3f_cdiv(3ll * M_cap, 256), 256, 0, stream>>>(pts, M_cap, m_dev, out, lens_out_dev, total_dev);
+    if (M_cap < 1 || B < 1 || 2 * B > D3F_MAX_BATCH || !pts || !lens_in_dev || !out || !lens_out_dev || !total_dev)
+        return D3F_ERR_ARG;
+    gs_stack_pair_kernel<<<d3f_cdiv(3ll * M_cap, 256), 256, 0, stream>>>(pts, M_cap, lens_in_dev, B, out, lens_out_dev, total_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -49,8 +49,15 @@ class _Slot:
 
 class FragmentEngine:
     def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
-                 device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None, two_clouds=False):
-        """mirror_self_pair=False: the stacked self-pair [cloud; cloud] is computed row by row, exactly the work of the
+                 device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None, two_clouds=False, batch=1):
+        """raw_cap / n0_cap: raw points / voxels per FRAGMENT that a slot can take (a fragment beyond them is recomputed by
+        the eager path).
+        batch: fragments per graph replay.  The per-fragment cost of this path is dominated by the ~270 dependent launches
+        of one replay, not by bytes or flops, so F independent fragments are stacked into ONE pyramid / network pass
+        ([c_1; c_1; c_2; c_2; ...], lens on the device -- the reference's own stacking mechanism, datasets/common.py:453-496,
+        with batch_num = F): every per-cloud result is unchanged (searches, subsampling and the head's normalisation are per
+        batch element) while the launch chain is paid once per F fragments.
+        mirror_self_pair=False: the stacked self-pair [cloud; cloud] is computed row by row, exactly the work of the
         reference's test generators (datasets/ThreeDMatch.py:190-192).  True: the pair's two halves are identical by
         construction (per-cloud searches, per-cloud head normalisation), so ONE copy is computed (stack of one cloud) and the
         outputs are mirrored into the stacked layout -- same results to fp32 summation order, half the work.
@@ -63,9 +70,13 @@ class FragmentEngine:
         self.raw_cap, self.n0_cap = int(raw_cap), int(n0_cap)
         self.mirror = bool(mirror_self_pair)
         self.two = bool(two_clouds)
+        self.F = int(batch)
         if self.two and self.mirror:
             raise ValueError("mirror_self_pair and two_clouds exclude each other")
-        clouds = 1 if (self.mirror or self.two) else 2
+        if self.F < 1 or 2 * self.F * (2 if self.two else 1) > _lib.MAX_BATCH:
+            raise ValueError("batch out of range")
+        self.nin = self.F * (2 if self.two else 1)            # clouds handed to the stage-0 subsampling per replay
+        clouds = self.F * (1 if (self.mirror or self.two) else 2)
         self.caps = level_caps(n0_cap, config.num_layers, level_ratio, clouds)
         self.n0_hint = int(n0_hint if n0_hint is not None else n0_cap / 1.3)
         self.hints = level_hints(self.n0_hint, config.num_layers, clouds=clouds)
@@ -75,6 +86,9 @@ class FragmentEngine:
         self._eager_ds.device = device
         self._eager_ds.neighborhood_limits = self.limits
         self._eager_map = self._eager_ds.get_tf_mapping(config)
+        # stand-in for the missing fragments of a partial batch: a tiny cloud (a handful of voxels, no flags raised)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        self._dummy = (torch.rand((256, 3), generator=g) * (6.0 * config.first_subsampling_dl)).to(device)
         # one HIP stream per slot (pass `streams` to share them between engines: the runtime multiplexes every stream of the
         # process onto a few hardware queues, so idle extra streams still cost concurrency)
         self.slots = [self._build_slot(streams[i] if streams else None) for i in range(int(slots))]
@@ -83,25 +97,24 @@ class FragmentEngine:
     # ---- the fixed launch sequence -------------------------------------------------------------------------------
     def _sequence(self, sl):
         cfg = self.cfg
-        sub, _, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.n0_cap,
-                                                     status=sl.status0, m_hint=self.n0_hint)   # _ = lens of the result
+        sub, sub_l, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.F * self.n0_cap,
+                                                         status=sl.status0, m_hint=self.F * self.n0_hint)
         if self.mirror or self.two:
-            pts, lens = sub, _  # the stack as subsampled: lens = [m] (mirror) or [m_a, m_b] (two clouds), on the device
+            pts, lens = sub, sub_l     # the stack as subsampled: lens = [m_1 .. m_F] (mirror) or [m_a1, m_b1, ...] (two clouds)
         else:
-            pts, lens = ops.stack_self_pair(sub)
+            pts, lens = ops.stack_self_pair(sub, sub_l)        # [c_1; c_1; c_2; c_2; ...]
         flat = sl.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
-        return pts, desc, score, sl.ds.static_status
+        return pts, desc, score, sl.ds.static_status, lens
 
     def _build_slot(self, stream=None):
         dev = self.device
         sl = _Slot()
         sl.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
-        sl.raw = torch.zeros((self.raw_cap, 3), dtype=torch.float32, device=dev)
-        nb = 2 if self.two else 1
-        sl.raw_len = torch.zeros((nb,), dtype=torch.int32, device=dev)
+        sl.raw = torch.zeros((self.F * self.raw_cap, 3), dtype=torch.float32, device=dev)
+        sl.raw_len = torch.zeros((self.nin,), dtype=torch.int32, device=dev)
         sl.status0 = torch.zeros((2,), dtype=torch.int32, device=dev)
-        sl.host_n = torch.zeros((nb,), dtype=torch.int32).pin_memory()
+        sl.host_n = torch.zeros((self.nin,), dtype=torch.int32).pin_memory()
         sl.ds = FragmentDataset([], fast=True)
         sl.ds.device = dev
         sl.ds.neighborhood_limits = self.limits
@@ -109,44 +122,55 @@ class FragmentEngine:
         sl.ds.hints = self.hints
         sl.map = sl.ds.get_tf_mapping(self.cfg)
         sl.busy = False
-        sl.n_raw = 0
         sl.raw_src = None
-        # warm-up on a tiny synthetic cloud (uploads weights, sizes the allocator), then capture
+        # warm-up on tiny synthetic clouds (uploads weights, sizes the allocator), then capture
         with torch.cuda.stream(sl.stream):
             g = torch.Generator(device="cpu").manual_seed(0)
-            warm = torch.rand((4096, 3), generator=g) * torch.tensor([1.0, 1.0, 0.05])
-            sl.raw[:4096].copy_(warm.to(dev))
-            sl.raw_len.fill_(4096 // nb)
+            per = 2048
+            warm = (torch.rand((per * self.nin, 3), generator=g) * torch.tensor([1.0, 1.0, 0.05])).to(dev)
+            sl.raw[: per * self.nin].copy_(warm)
+            sl.raw_len.fill_(per)
             with ops.private_workspace():
                 self._sequence(sl)
         sl.stream.synchronize()
         sl.graph = torch.cuda.CUDAGraph()
         with ops.private_workspace() as pw:
             with torch.cuda.graph(sl.graph, stream=sl.stream):
-                sl.pts, sl.desc, sl.score, sl.status = self._sequence(sl)
+                sl.pts, sl.desc, sl.score, sl.status, sl.lens = self._sequence(sl)
         sl.keep = pw.kept          # scratch buffers referenced by the graph
-        # one packed read-back per fragment: [n_total, status0(2), status(k,2)...]
+        # one packed read-back per replay: [n_total, status0(2), status(k,2)..., lens(nb)]
+        sl.nl = sl.lens.numel()
         sl.nstat = 1 + 2 + 2 * sl.status.shape[0]
-        sl.host_stat = torch.zeros((sl.nstat,), dtype=torch.int32).pin_memory()
-        sl.dev_stat = torch.zeros((sl.nstat,), dtype=torch.int32, device=dev)
+        sl.host_stat = torch.zeros((sl.nstat + sl.nl,), dtype=torch.int32).pin_memory()
+        sl.dev_stat = torch.zeros((sl.nstat + sl.nl,), dtype=torch.int32, device=dev)
         sl.done = torch.cuda.Event()
         return sl
 
     # ---- per-fragment API -------------------------------------------------------------------------------------------
     def submit(self, slot, raw):
-        """Start fragment `raw` (float32 [n,3], on the device or the host) on slot `slot`; returns immediately."""
+        """Start a replay on slot `slot`; returns immediately.  `raw`: one fragment (float32 [n,3] on the device or the host;
+        a pair (raw_a, raw_b) with two_clouds), or -- batch > 1 -- a list of up to `batch` fragments."""
         sl = self.slots[slot]
         assert not sl.busy, "slot %d still holds an unfetched fragment" % slot
-        parts = list(raw) if self.two else [raw]
-        if self.two and len(parts) != 2:
-            raise ValueError("two_clouds engine: submit(slot, (raw_a, raw_b))")
-        n = sum(int(p.shape[0]) for p in parts)
-        sl.n_raw, sl.raw_src = n, raw
+        single = not isinstance(raw, list)
+        frags = [raw] if single else list(raw)
+        if not 1 <= len(frags) <= self.F:
+            raise ValueError("submit: %d fragments for a batch-%d engine" % (len(frags), self.F))
+        sl.single, sl.raw_src, sl.nfrag = single, frags, len(frags)
         sl.busy = True
-        if n > self.raw_cap or min(int(p.shape[0]) for p in parts) == 0:
+        parts = []
+        for fr in frags:
+            p = list(fr) if self.two else [fr]
+            if self.two and len(p) != 2:
+                raise ValueError("two_clouds engine: a fragment is a pair (raw_a, raw_b)")
+            parts += p
+        per_frag = 2 if self.two else 1
+        sizes = [sum(int(x.shape[0]) for x in parts[i * per_frag:(i + 1) * per_frag]) for i in range(len(frags))]
+        if max(sizes) > self.raw_cap or min(int(x.shape[0]) for x in parts) == 0:
             sl.oversize = True
             return
         sl.oversize = False
+        parts += [self._dummy] * (self.nin - len(parts))        # partial batch: stand-ins, dropped again in fetch
         for i, p in enumerate(parts):
             sl.host_n[i] = int(p.shape[0])
         cur = torch.cuda.current_stream(self.device)
@@ -160,33 +184,43 @@ class FragmentEngine:
                 o += int(p.shape[0])
             sl.raw_len.copy_(sl.host_n, non_blocking=True)
             sl.graph.replay()
-            # pack [n_total | status0 | statuses] and bring it back with one small copy
+            # pack [n_total | status0 | statuses | lens] and bring it back with one small copy
             sl.dev_stat[0:1].copy_(sl.pts.n_dev)
             sl.dev_stat[1:3].copy_(sl.status0)
-            sl.dev_stat[3:].copy_(sl.status.reshape(-1))
+            sl.dev_stat[3:sl.nstat].copy_(sl.status.reshape(-1))
+            sl.dev_stat[sl.nstat:].copy_(sl.lens)
             sl.host_stat.copy_(sl.dev_stat, non_blocking=True)
             sl.done.record(sl.stream)
 
     def fetch(self, slot):
-        """Wait for slot `slot`; -> (points f32[2n,3], descriptors f32[2n,32], scores f32[2n,1]) device tensors
-        (views into the slot's buffers: valid until the slot is submitted again)."""
+        """Wait for slot `slot`; -> (points f32[2n,3], descriptors f32[2n,32], scores f32[2n,1]) device tensors of the stacked
+        pair (views into the slot's buffers: valid until the slot is submitted again); a list of such tuples when the
+        submit was given a list."""
         sl = self.slots[slot]
         assert sl.busy, "slot %d is empty" % slot
         sl.busy = False
+        outs = None
         if not sl.oversize:
             sl.done.synchronize()
             st = sl.host_stat.numpy()
-            flags = int(st[2]) | (int(np.bitwise_or.reduce(st[4::2])) if sl.nstat > 3 else 0)
-            n = int(st[0])
+            flags = int(st[2]) | (int(np.bitwise_or.reduce(st[4:sl.nstat:2])) if sl.nstat > 3 else 0)
             if flags == 0:
-                if self.mirror:   # stacked layout of the reference: both halves hold the cloud
-                    return (torch.cat([sl.pts[:n], sl.pts[:n]]), torch.cat([sl.desc[:n], sl.desc[:n]]),
-                            torch.cat([sl.score[:n], sl.score[:n]]))
-                return sl.pts[:n], sl.desc[:n], sl.score[:n]
-        # capacity exceeded / large ordering budget needed / degenerate cloud: the eager path decides (and raises the
-        # reference-level errors where they apply)
-        self.fallbacks += 1
-        return self.run_eager(sl.raw_src)
+                lens = [int(x) for x in st[sl.nstat:]]
+                per = 1 if self.mirror else 2                   # stack entries per fragment
+                outs, o = [], 0
+                for i in range(sl.nfrag):
+                    n = sum(lens[i * per:(i + 1) * per])
+                    p, d, s = sl.pts[o:o + n], sl.desc[o:o + n], sl.score[o:o + n]
+                    if self.mirror:   # stacked layout of the reference: both halves hold the cloud
+                        p, d, s = torch.cat([p, p]), torch.cat([d, d]), torch.cat([s, s])
+                    outs.append((p, d, s))
+                    o += n
+        if outs is None:
+            # capacity exceeded / large ordering budget needed / degenerate cloud: the eager path decides (and raises the
+            # reference-level errors where they apply)
+            self.fallbacks += sl.nfrag
+            outs = [self.run_eager(fr) for fr in sl.raw_src]
+        return outs[0] if sl.single else outs
 
     def run_eager(self, raw):
         if self.two:

@@ -217,24 +217,28 @@ def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0):
     return sub_p, sub_l, status
 
 
-def stack_self_pair(pts):
-    """np.concatenate([pts, pts]) with a device-side row count (pts.n_dev): -> (out f32[2*cap,3] tagged, lens i32[2])."""
+def stack_self_pair(pts, lens=None):
+    """np.concatenate([c, c]) for every cloud c of a stack whose row counts live on the device:
+    pts f32[cap,3] holding B clouds (lens i32[B] on the device; default: one cloud of pts.n_dev rows)
+    -> (out f32[2*cap,3] = [c_0; c_0; c_1; c_1; ...] tagged with n_dev, lens_out i32[2B])."""
     lib = _lib.load()
     pts = _req(pts, torch.float32, "pts", 2).contiguous()
     dev = pts.device
     cap = pts.shape[0]
-    m_dev = getattr(pts, "n_dev", None)
-    if m_dev is None:
-        m_dev = torch.full((1,), cap, dtype=torch.int32, device=dev)
+    if lens is None:
+        lens = getattr(pts, "n_dev", None)
+        if lens is None:
+            lens = torch.full((1,), cap, dtype=torch.int32, device=dev)
+    B = lens.numel()
     out = torch.empty((2 * cap, 3), dtype=torch.float32, device=dev)
-    lens = torch.empty((2,), dtype=torch.int32, device=dev)
+    lens_out = torch.empty((2 * B,), dtype=torch.int32, device=dev)
     total = torch.empty((1,), dtype=torch.int32, device=dev)
-    rc = lib.d3f_stack_self_pair(pts.data_ptr(), cap, m_dev.data_ptr(), out.data_ptr(), lens.data_ptr(), total.data_ptr(),
-                                 _stream(dev))
+    rc = lib.d3f_stack_self_pair(pts.data_ptr(), cap, lens.data_ptr(), B, out.data_ptr(), lens_out.data_ptr(),
+                                 total.data_ptr(), _stream(dev))
     _lib.check(rc, "stack_self_pair")
     out.n_dev = total
     out.n_hint = 2 * int(getattr(pts, "n_hint", 0) or 0)
-    return out, lens
+    return out, lens_out
 
 
 class NeighborGrid:

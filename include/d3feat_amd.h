@@ -77,10 +77,11 @@ int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* le
                                    float* sub_points, int M_cap, int* sub_lens_dev, int* status_dev,
                                    void* workspace, size_t workspace_bytes, void* stream);
 /* The self-pair stacking of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:72-79:
- * np.concatenate([pts, pts])) with the row count m read from HBM: out f32[2*M_cap,3] rows [0,m) and [m,2m) = pts[0,m);
- * lens_out_dev i32[2] = [m, m]; total_dev i32[1] = 2m. */
-int d3f_stack_self_pair(const float* pts, int M_cap, const int* m_dev, float* out, int* lens_out_dev, int* total_dev,
-                        void* stream);
+ * np.concatenate([pts, pts])) for B stacked clouds whose row counts live in HBM (lens_in_dev i32[B]): cloud b is written
+ * twice in a row -- out f32[2*M_cap,3] = [c_0; c_0; c_1; c_1; ...], lens_out_dev i32[2B] = [m_0, m_0, m_1, m_1, ...],
+ * total_dev i32[1] = 2 * sum m_b.  B = 1: the single self-pair; B > 1: several fragments in one stack. */
+int d3f_stack_self_pair(const float* pts, int M_cap, const int* lens_in_dev, int B, float* out, int* lens_out_dev,
+                        int* total_dev, void* stream);
 int d3f_batch_grid_subsample(const float* points, int N, const int* lens_dev, int B, float dl,
                              const float* features, int fdim, const int* classes, int ldim,
                              float* sub_points, float* sub_features, int* sub_classes, int* sub_lens_dev,

@@ -180,3 +180,25 @@ def test_engine_four_slots_stay_correct_under_load(device, setup):
     for k in range(4):
         bad += 0 if check(inflight[k], eng.fetch(k)) else 1
     assert bad == 0 and eng.fallbacks == 0
+
+
+@pytest.mark.parametrize("mirror", [False, True])
+def test_engine_batched_fragments(device, setup, mirror):
+    """batch=3: three fragments stacked into one replay (and a partial batch of two): every fragment's result equals its own
+    eager run -- per-cloud searches / subsampling / head normalisation make stack mates invisible to each other."""
+    from d3feat_amd.engine import FragmentEngine
+    cfg, W, limits = setup
+    eng = FragmentEngine(cfg, W, limits, raw_cap=45000, n0_cap=14000, slots=2, device=device, batch=3, mirror_self_pair=mirror)
+    raws = [torch.from_numpy(_frag(80 + i, n)).to(device) for i, n in enumerate((30000, 40000, 25000, 35000, 20000))]
+    refs = [tuple(t.clone() for t in eng.run_eager(r)) for r in raws]
+    eng.submit(0, raws[:3])
+    eng.submit(1, raws[3:])                      # partial batch
+    outs = [tuple(t.clone() for t in o) for o in eng.fetch(0)] + [tuple(t.clone() for t in o) for o in eng.fetch(1)]
+    assert len(outs) == 5 and eng.fallbacks == 0
+    for (p, d, s), (rp, rd, rs) in zip(outs, refs):
+        assert p.shape == rp.shape and torch.equal(p, rp)
+        _close(d, rd, 5e-6)
+        _close(s, rs, 5e-6)
+    # single-fragment call on a batched engine keeps the single-tuple API
+    p, d, s = eng.run(raws[1])
+    assert torch.equal(p, refs[1][0])
