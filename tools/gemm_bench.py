@@ -11,7 +11,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from d3feat_amd import ops  # noqa: E402
 
-N0, N1, N2, N3, N4 = 58739, 14580, 3632, 905, 197
+SCALE = int(os.environ.get("D3F_GEMM_BENCH_SCALE", "1"))   # fragments per stack (FragmentEngine batch)
+N0, N1, N2, N3, N4 = (SCALE * n for n in (58739, 14580, 3632, 905, 197))
 SHAPES = [  # (M, K, N, count)
     (N0, 64, 32, 1), (N0, 480, 32, 1), (N0, 32, 128, 1), (N0, 64, 128, 1), (N0, 128, 32, 1), (N1, 480, 32, 1), (N1, 32, 128, 1),
     (N1, 128, 64, 1), (N1, 960, 64, 1), (N1, 64, 256, 1), (N1, 128, 256, 1), (N1, 256, 64, 1), (N2, 960, 64, 1), (N2, 64, 256, 1),
