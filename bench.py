@@ -69,13 +69,14 @@ class Step:
         self.map = self.ds.get_tf_mapping(cfg)
 
     def __call__(self, raw_dev):
+        """raw_dev: one raw cloud, or a list of F raw clouds stacked [c_1; c_1; c_2; c_2; ...] like FragmentEngine(batch=F)."""
         import torch
         from d3feat_amd import tf_custom_ops as tfo
         from d3feat_amd.ops import as_lens as ops_as_lens
-        sub = tfo.grid_subsampling(raw_dev, self.cfg.first_subsampling_dl)          # stage 0
-        n = sub.shape[0]
-        pts = torch.cat([sub, sub], 0)                                               # self-pair (device copy)
-        lens = ops_as_lens([n, n], self.device)
+        raws = raw_dev if isinstance(raw_dev, list) else [raw_dev]
+        subs = [tfo.grid_subsampling(r, self.cfg.first_subsampling_dl) for r in raws]       # stage 0
+        pts = torch.cat([x for s in subs for x in (s, s)], 0)                                # self-pairs (device copies)
+        lens = ops_as_lens([int(s.shape[0]) for s in subs for _ in (0, 1)], self.device)
         flat = self.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
         return pts, desc, score
@@ -210,11 +211,15 @@ def main():
     # ---- instrumented pass (untimed): per-launch HIP events on the launch stream --------------------------------
     layers, roof = None, None
     if rank == 0 and not args.no_instrument:
-        nprof = max(3, min(args.steps, 8))
+        # same stack shape as the timed region: F fragments per pass (op by op instead of a replayed graph, because HIP
+        # events cannot be placed between the nodes of a graph)
+        Fp = engine.F if engine is not None else 1
+        npass = max(2, min(args.steps, 8) // Fp)
+        nprof = npass * Fp                      # fragments covered
         ops.PROFILE = []
-        for i in range(nprof):
+        for i in range(npass):
             ops.PROFILE.append(("step", {}, None, None))
-            step(raws[i % len(raws)])
+            step([raws[(i * Fp + j) % len(raws)] for j in range(Fp)] if Fp > 1 else raws[i % len(raws)])
         torch.cuda.synchronize(device)
         recs, ops.PROFILE = ops.PROFILE, None
         fam = {}      # kernel family -> totals over the instrumented pass
@@ -267,6 +272,7 @@ def main():
                         alg_bytes_per_launch=int(dom["bytes"] / dom["launches"]))
         roof["avg_launch_us"] = round(avg_ms * 1e3, 2)
         roof["launches_per_step"] = round(dom["launches"] / nprof, 2)
+        roof["fragments_per_launch"] = Fp
         roof["timed_kernels_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in sorted(fam.items())}
         # HBM traffic per launch of the dominant kernel: from the newest committed pair of `rocprofv3 --pmc FETCH_SIZE` /
         # `--pmc WRITE_SIZE` passes of this same command (tools/gpu_round.sh -> tools/pmc_summary.py, corrections of
@@ -299,7 +305,9 @@ def main():
             layers.append(dict(layer=li, Nq=int(np.mean([d["Nq"] for d in infos])), Ns=int(np.mean([d["Ns"] for d in infos])),
                                K=infos[0]["K"], Cin=infos[0]["Cin"], agg_ms=round(agg_ms, 4),
                                gemm_ms=round(float(np.mean(gem)), 4) if gem else None,
-                               total_ms=round(agg_ms + (float(np.mean(gem)) if gem else 0.0), 4)))
+                               total_ms=round(agg_ms + (float(np.mean(gem)) if gem else 0.0), 4),
+                               fragments_per_launch=Fp,
+                               total_ms_per_fragment=round((agg_ms + (float(np.mean(gem)) if gem else 0.0)) / Fp, 4)))
 
     # ---- CPU baseline (rank 0, N=1) -------------------------------------------------------------------------------
     cpu = None
