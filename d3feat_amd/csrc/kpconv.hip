@@ -401,7 +401,8 @@ typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
 #define KF_TQ 32
 #define KF_LQ 8
 #define KF_WS (KF_LQ * 16 + 4)        // phase-A stride per query (floats)
-#define KF_TS (15 * 32 + 1)           // wf tile stride per query: odd, so the MFMA A-fragment column reads hit 32 banks
+#define KF_HP 8                        // kernel points per contraction pass (the wf tile goes through LDS in two passes)
+#define KF_TS (KF_HP * 32 + 1)        // wf tile stride per query: odd, so the MFMA A-fragment column reads hit 32 banks
 
 __global__ void __launch_bounds__(256)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
@@ -411,10 +412,13 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
     if ((int)(blockIdx.x * KF_TQ) >= Nq) return;
+    // One LDS region serves three lives: phase-A influences [32][132] during the neighbour loop, then the weighted-feature
+    // tile [32][257] (8 kernel points at a time: MFMA A operand), then the four partial out tiles.  34 KB per workgroup
+    // instead of 80 KB: the kernel is bound by dependent gathers, so resident workgroups per CU are what it needs.
     extern __shared__ __attribute__((aligned(16))) float kf_smem[];
-    float* wft = kf_smem;                                   // [32][481]  weighted-feature tile (MFMA A operand)
-    float* lw = kf_smem + KF_TQ * KF_TS;                    // [32][132]  phase-A influences; later the 4 partial out tiles
-    int* lidx = (int*)(lw + KF_TQ * KF_WS);                 // [32][8]
+    float* wft = kf_smem;
+    float* lw = kf_smem;
+    int* lidx = (int*)(kf_smem + KF_TQ * KF_TS);            // [32][8]
     int* lcnt = lidx + KF_TQ * KF_LQ;                       // [32]
     int* lq = lcnt + KF_TQ;                                 // [32] global query index of each tile row
     const int tid = threadIdx.x;
@@ -478,37 +482,49 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
         }
         __syncthreads();
     }
-    // ---- weighted features of this thread -> LDS tile: wft[ql][p*32 + 4*cl + j]  (k index = p*Cin + c, as K_values) ----
-#pragma unroll
-    for (int p = 0; p < KP_MAXP - 1; ++p) {
-        float* d = &wft[ql * KF_TS + p * 32 + 4 * cl];
-        d[0] = acc[p][0]; d[1] = acc[p][1]; d[2] = acc[p][2]; d[3] = acc[p][3];
-    }
-    __syncthreads();
-    // ---- contraction on the matrix cores: out[32 x 32] = wft[32 x 480] @ W[480 x 32]; wave w owns k-steps [60w, 60w+60) ----
+    // ---- contraction on the matrix cores: out[32 x 32] = wf[32 x 480] @ W[480 x 32], in two passes of 8 / 7 kernel points:
+    //      this thread's weighted features -> LDS tile wft[ql][(p - p0)*32 + 4*cl + j] (k index = p*Cin + c, as K_values),
+    //      then every wavefront multiplies its quarter of the pass's k-steps ----
     const int lane = tid & 63, wave = tid >> 6;
     kp_f32x16 c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[r] = 0.f;
-    const int ksteps = P.num_kp * 16;                 // k-steps of 2
-    const int per = (ksteps + 3) / 4;
-    const int kb = wave * per, ke = min(ksteps, kb + per);
-    const float* ap = &wft[(lane & 31) * KF_TS + (lane >> 5)];
-    const float* bp = W + (size_t)(lane >> 5) * 32 + (lane & 31);
-    for (int kk = kb; kk < ke; kk += 4) {
-        float a4[4], b4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k2 = min(kk + u, ke - 1) * 2;
-            a4[u] = ap[k2];
-            b4[u] = bp[(size_t)k2 * 32];
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p0 = pass * KF_HP;
+        const int np = min(P.num_kp - p0, KF_HP);
+        if (pass) __syncthreads();                      // the previous pass's tile has been consumed
+#pragma unroll
+        for (int pp = 0; pp < KF_HP; ++pp) {
+            const int p = p0 + pp;
+            if (p < KP_MAXP - 1 && pp < np) {
+                float* d = &wft[ql * KF_TS + pp * 32 + 4 * cl];
+                d[0] = acc[p][0]; d[1] = acc[p][1]; d[2] = acc[p][2]; d[3] = acc[p][3];
+            }
         }
+        __syncthreads();
+        if (np <= 0) continue;
+        const int ksteps = np * 16;                     // k-steps of 2
+        const int per = (ksteps + 3) / 4;
+        const int kb = wave * per, ke = min(ksteps, kb + per);
+        const float* ap = &wft[(lane & 31) * KF_TS + (lane >> 5)];
+        const float* bp = W + ((size_t)p0 * 32 + (lane >> 5)) * 32 + (lane & 31);
+        for (int kk = kb; kk < ke; kk += 4) {
+            float a4[4], b4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (kk + u < ke) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u], c, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const int k2 = min(kk + u, ke - 1) * 2;
+                a4[u] = ap[k2];
+                b4[u] = bp[(size_t)k2 * 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (kk + u < ke) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u], c, 0, 0, 0);
+        }
     }
-    // partial tiles -> LDS (the phase-A region is free now), sum of the four in wave order, epilogue
-    float* red = lw;                                        // [4][32*32]
+    __syncthreads();
+    // partial tiles -> LDS (the tile region is free now), sum of the four in wave order, epilogue
+    float* red = kf_smem;                                   // [4][32*32]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -547,7 +563,8 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
     P.aggregation = aggregation;
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
-    const size_t lds = (size_t)(KF_TQ * KF_TS + KF_TQ * KF_WS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
+    const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
+    static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kpconv_fused32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
