@@ -217,6 +217,294 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The production tile kernel: same tiling as gemm_f32_kernel above, written so that the compiler has nothing to serialise.
+//  * operands are float4-addressable (K, N, leading dimensions multiples of 4, 16-byte aligned bases: every shape of the
+//    network), so a tile load is straight-line code: clamped address, one global_load_dwordx4, a select to zero -- no
+//    branch between the loads and therefore no s_waitcnt before the multiply they are meant to overlap with;
+//  * the contraction may visit k in any order as long as A and B agree: within a 32-deep tile lane (r, h) owns
+//    k = 16h .. 16h+15, which are CONSECUTIVE in an LDS row, so a wavefront fetches its A and B fragments for the whole
+//    tile with four ds_read_b128 each (B is stored transposed, [n][k]) instead of 32 ds_read_b32 followed by a wait apiece;
+//    the second half of the fragments lands while the first eight MFMAs run.
+// Row stride 36 floats: 16-byte aligned rows, and 36r mod 64 spreads eight consecutive rows over all banks for b128 reads.
+// ------------------------------------------------------------------------------------------------
+#define GF_S 36
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256)
+gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                 int M, int N, int K, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
+                 const int* __restrict__ M_dev, GemmGather G) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int A_F4 = BM * GM_BK / 4 / 256, B_F4 = GM_BK * BN / 4 / 256;
+    static_assert(WM * WN == 4 && A_F4 >= 1 && B_F4 >= 1, "tile shape");
+    const int Mcap = M;
+    M = d3f_dyn(M, M_dev);
+    if ((int)(blockIdx.z * BM) >= M) return;
+    extern __shared__ __attribute__((aligned(16))) float gf_smem[];
+    float* As = gf_smem;                          // [2][BM][GF_S]
+    float* Bt = gf_smem + 2 * BM * GF_S;          // [2][BN][GF_S]   B tile transposed: Bt[n][k]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.z * BM, n0 = blockIdx.x * BN;
+    const int nt_all = (K + GM_BK - 1) / GM_BK;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_end = min(nt_all, t_begin + tiles_per_split);
+
+    // per-thread staging slots: A slot i = row (tid + 256 i) / 8, k offset 4 * ((tid + 256 i) % 8)
+    const float* arow[A_F4];      // source row in A (gathered or in place); A itself when the row reads as zero
+    const float* a2row[A_F4];     // source row in the second operand
+    bool aok[A_F4], a2ok[A_F4];
+    const int ak = (tid & 7) << 2;
+    {
+        const int n1 = d3f_dyn(G.N1, G.N1_dev);
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int gm = m0 + ((tid + i * 256) >> 3);
+            const bool in = gm < M;
+            int sr = in ? gm : 0;
+            bool ok = in;
+            if (G.gidx) {
+                sr = G.gidx[(size_t)(in ? gm : 0) * G.ld_gidx];
+                ok = in && sr >= 0 && sr < n1;       // shadow neighbour: zero row
+                sr = ok ? sr : 0;
+            }
+            arow[i] = A + (size_t)sr * lda;
+            aok[i] = ok;
+            a2row[i] = G.A2 ? G.A2 + (size_t)(in ? gm : 0) * G.lda2 : A;
+            a2ok[i] = in && G.A2 != nullptr;
+        }
+    }
+    const int kend1 = G.A2 ? G.K1 : K;             // columns [0, kend1) come from A, [kend1, K) from the second operand
+    const int bk = tid / (BN / 4), bn = (tid % (BN / 4)) << 2;   // B slot i = k row bk + i * (1024 / BN), columns n0 + bn ..
+    const bool bnok = n0 + bn < N;
+
+    float4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](int t) {
+        const int k = t * GM_BK + ak;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const bool second = k >= kend1;
+            const bool ok = (second ? a2ok[i] : aok[i]) && k < K;
+            const float* p = second ? a2row[i] + (k - kend1) : arow[i] + k;
+            const float4 v = *(const float4*)(ok ? p : A);
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int gk = t * GM_BK + bk + i * (1024 / BN);
+            const bool ok = bnok && gk < K;
+            const float4 v = *(const float4*)(ok ? B + (size_t)gk * ldb + n0 + bn : B);
+            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BM * GF_S;
+        float* bt = Bt + buf * BN * GF_S;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) *(float4*)&as[((tid + i * 256) >> 3) * GF_S + ak] = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            float* d = &bt[bn * GF_S + bk + i * (1024 / BN)];
+            d[0] = rb[i].x; d[GF_S] = rb[i].y; d[2 * GF_S] = rb[i].z; d[3 * GF_S] = rb[i].w;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int afrag = (wm * TM * 32 + (lane & 31)) * GF_S + (lane >> 5) * 16;
+    const int bfrag = (wn * TN * 32 + (lane & 31)) * GF_S + (lane >> 5) * 16;
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        if (more) load_tile(t + 1);               // global -> registers, in flight while this tile is multiplied
+        const float* as = As + cur * BM * GF_S + afrag;
+        const float* bt = Bt + cur * BN * GF_S + bfrag;
+        float4 fa[TM][4], fb[TN][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][q] = *(const float4*)&as[i * 32 * GF_S + 4 * q];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j][q] = *(const float4*)&bt[j * 32 * GF_S + 4 * q];
+        }
+        __builtin_amdgcn_sched_barrier(0);        // every fragment read is issued before the first MFMA waits on one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float a = e == 0 ? fa[i][q].x : e == 1 ? fa[i][q].y : e == 2 ? fa[i][q].z : fa[i][q].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float b = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // The per-column epilogue terms are fetched once per tile column, not once per element.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool nok = gn < N;
+        const float cs = (!slab && E.col_scale && nok) ? E.col_scale[gn] : 1.f;
+        const float ch = (!slab && E.col_shift && nok) ? E.col_shift[gn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gm < M && nok) {
+                    float v = acc[i][j][r];
+                    if (slab) slab[((size_t)blockIdx.y * Mcap + gm) * N + gn] = v;
+                    else {
+                        if (E.row_scale) v *= E.row_scale[gm];
+                        v = v * cs + ch;
+                        if (E.residual) v += E.residual[(size_t)gm * E.ldr + gn];
+                        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+                        C[(size_t)gm * ldc + gn] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming variant for the wide, shallow layers (many rows, K <= 256: the unary / shortcut / decoder contractions of the
+// two finest levels, which are HBM bound on A and C).  The whole B column slab [K x 32*NT] is staged in LDS once per
+// workgroup; every wavefront then walks 32-row groups on its own -- no barrier after the prologue -- with the A rows going
+// global -> registers directly (the MFMA A fragment is one value per lane and k-step, and the contraction does not care
+// in which order k is visited: lane (row r, half h) loads float4 A[r][8j + 4h ..] and feeds element t to k-step (j, t),
+// where the B fragment reads row 8j + 4h + t) and the next 64-column chunk prefetched while the current one is multiplied.
+// Against the tiled kernel: B is read once per ~14 row groups instead of once per 2, A never passes through LDS, and the
+// row count only enters through the loop bound, so a capacity-sized launch costs nothing.
+// ------------------------------------------------------------------------------------------------
+#define GS_KC 64                       // k columns per register chunk (8 float4 per lane)
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+gemm_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                   int M, int N, int K, GemmEpi E, const int* __restrict__ M_dev, GemmGather G) {
+    constexpr int NTILE = 32 * NT, SB = NTILE + 8;   // +8: rows k and k+4 (the two lane halves) land on different banks
+    extern __shared__ __attribute__((aligned(16))) float gs_lB[];
+    M = d3f_dyn(M, M_dev);
+    const int groups = (M + 31) >> 5;
+    if ((int)(blockIdx.x * 4) >= groups) return;    // whole workgroup idle (capacity-sized grid)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * NTILE;
+    for (int e = tid; e < K * (NTILE / 4); e += 256) {
+        const int k = e / (NTILE / 4), n4 = (e % (NTILE / 4)) << 2;
+        *(float4*)&gs_lB[k * SB + n4] = *(const float4*)&B[(size_t)k * ldb + n0 + n4];
+    }
+    __syncthreads();
+    int g = blockIdx.x * 4 + wave;
+    if (g >= groups) return;
+    const int gstride = gridDim.x * 4;
+    const int n1 = d3f_dyn(G.N1, G.N1_dev);
+    const int nchunk = (K + GS_KC - 1) / GS_KC;
+
+    auto row_source = [&](int grp) -> int {      // row of A feeding tile row r of group grp: -1 = zero row
+        const int gm = grp * 32 + r;
+        if (gm >= M) return -1;
+        if (!G.gidx) return gm;
+        const int sr = G.gidx[(size_t)gm * G.ld_gidx];
+        return (sr < 0 || sr >= n1) ? -1 : sr;
+    };
+    auto load_chunk = [&](float4 (&dst)[8], int grp, int c, int srow) {
+        const int gm = grp * 32 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = c * GS_KC + 8 * j + 4 * h;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K && gm < M) {
+                if (G.A2 && k >= G.K1) v = *(const float4*)(G.A2 + (size_t)gm * G.lda2 + (k - G.K1));
+                else if (srow >= 0) v = *(const float4*)(A + (size_t)srow * lda + k);
+            }
+            dst[j] = v;
+        }
+    };
+
+    float cs[NT], ch[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        cs[t] = E.col_scale ? E.col_scale[n0 + t * 32 + r] : 1.f;
+        ch[t] = E.col_shift ? E.col_shift[n0 + t * 32 + r] : 0.f;
+    }
+
+    float4 cur[8], nxt[8];
+    int srow = row_source(g);
+    load_chunk(cur, g, 0, srow);
+    for (;;) {
+        const int gn = g + gstride;
+        const int srow_n = gn < groups ? row_source(gn) : -1;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) load_chunk(nxt, g, c + 1, srow);
+            else if (gn < groups) load_chunk(nxt, gn, 0, srow_n);
+            const float* bp = &gs_lB[(c * GS_KC + 4 * h) * SB + r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (c * GS_KC + 8 * j < K) {
+                    const float a4[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], bp[(8 * j + t) * SB + u * 32], acc[u], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+        }
+        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int gcol = n0 + u * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gm = g * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (gm < M) {
+                    float v = acc[u][i];
+                    if (E.row_scale) v *= E.row_scale[gm];
+                    v = v * cs[u] + ch[u];
+                    if (E.residual) v += E.residual[(size_t)gm * E.ldr + gcol];
+                    if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+                    C[(size_t)gm * ldc + gcol] = v;
+                }
+            }
+        }
+        if (gn >= groups) break;
+        g = gn;
+        srow = srow_n;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E,
                           const int* __restrict__ M_dev) {
@@ -308,8 +596,49 @@ extern "C" int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1
     return gemm_run(x, ldx, W, ldb, C, ldc, M, N, C1 + C2, E, G, workspace, workspace_bytes, M_dev, M_hint, (hipStream_t)stream_);
 }
 
+// The streaming kernel takes the shapes it was written for: shallow K (whole B slab in LDS), many rows, 16-byte aligned
+// float4-addressable operands.  D3F_GEMM_STREAM=0 disables it, D3F_GEMM_STREAM_BLOCKS sets the persistent grid (tuning knobs).
+static int gemm_stream_blocks() {
+    static int v = [] { const char* e = getenv("D3F_GEMM_STREAM_BLOCKS"); int b = e ? atoi(e) : 0; return b > 0 ? b : 512; }();
+    return v;
+}
+static bool gemm_stream_ok(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const GemmGather& G,
+                           int M_hint) {
+    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 1; }();
+    if (!on) return false;
+    const int mexp = (M_hint > 0 && M_hint < M) ? M_hint : M;
+    if (K < 8 || K > 256 || K % 8 != 0 || N % 32 != 0 || mexp < 4096) return false;
+    if (lda % 4 != 0 || ldb % 4 != 0 || (((uintptr_t)A | (uintptr_t)B) & 15) != 0) return false;
+    if (G.A2 && (G.K1 % 4 != 0 || G.lda2 % 4 != 0 || ((uintptr_t)G.A2 & 15) != 0)) return false;
+    return true;
+}
+
 static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, GemmEpi E,
                     GemmGather G, void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, hipStream_t stream) {
+    if (gemm_stream_ok(A, lda, B, ldb, M, N, K, G, M_hint)) {
+        // column slab per workgroup: as wide as 72 KB of LDS allows (two workgroups per CU)
+        int nt = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1);
+        while (nt > 1 && (size_t)K * (32 * nt + 8) * sizeof(float) > 73728) nt >>= 1;
+        const size_t lds = (size_t)K * (32 * nt + 8) * sizeof(float);
+        const int mplan = M;
+        int bx = d3f_cdiv(d3f_cdiv(mplan, 32), 4);
+        const int bx_max = gemm_stream_blocks();
+        if (bx > bx_max) bx = bx_max;
+        dim3 grid(bx, N / (32 * nt));
+        static bool attr_set = false;
+        if (!attr_set) {   // slabs above 64 KB need the opt-in
+            if (hipFuncSetAttribute((const void*)gemm_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess)
+                return D3F_ERR_HIP;
+            attr_set = true;
+        }
+        if (nt == 4) gemm_stream_kernel<4><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G);
+        else if (nt == 2) gemm_stream_kernel<2><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G);
+        else gemm_stream_kernel<1><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G);
+        D3F_LAUNCH_CHECK();
+        return D3F_OK;
+    }
     int bm, bn, S, tps;
     gemm_plan(M, N, K > 0 ? K : 1, M_hint, bm, bn, S, tps);
     float* slab = nullptr;
@@ -322,14 +651,35 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
     const int vecB = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
     if (d3f_cdiv(M, bm) > 65535) return D3F_ERR_ARG;
     dim3 grid(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm));
+    // float4-addressable operands (every shape of the network): the straight-line kernel; anything else: the generic one
+    static int fast_on = [] { const char* e = getenv("D3F_GEMM_FAST"); return e ? atoi(e) : 1; }();
+    const bool fast = fast_on && vecA && vecB && K % 4 == 0 && N % 4 == 0 &&
+                      (!G.A2 || (G.K1 % 4 == 0 && G.lda2 % 4 == 0 && ((uintptr_t)G.A2 & 15) == 0));
+    if (fast) {
+        const size_t lds = (size_t)2 * (bm + bn) * GF_S * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {   // the 128 x 128 tile needs 72 KB
+            if (hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess)
+                return D3F_ERR_HIP;
+            attr_set = true;
+        }
+#define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \
+    gemm_fast_kernel<WM_, WN_, TM_, TN_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, M_dev, G)
+        if (bn == 32) D3F_GEMM(4, 1, 1, 1);
+        else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2);
+        else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1);
+        else D3F_GEMM(2, 2, 1, 1);
+#undef D3F_GEMM
+    } else {
+        if (bn != 32) { bm = 64; bn = 64; grid = dim3(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm)); }
 #define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \
     gemm_f32_kernel<WM_, WN_, TM_, TN_><<<grid, 256, 0, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, vecA, vecB, tps, slab, E, \
                                                                   M_dev, G)
-    if (bn == 32) D3F_GEMM(4, 1, 1, 1);
-    else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2);
-    else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1);
-    else D3F_GEMM(2, 2, 1, 1);
+        if (bn == 32) D3F_GEMM(4, 1, 1, 1);
+        else D3F_GEMM(2, 2, 1, 1);
 #undef D3F_GEMM
+    }
     if (S > 1)
         gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
     D3F_LAUNCH_CHECK();

@@ -22,8 +22,12 @@ SHAPES = [  # (M, K, N, count)
     (N3, 3072, 512, 1), (N2, 1024, 256, 1), (N1, 512, 128, 1), (N0, 256, 64, 1), (N0, 64, 32, 1)]
 
 
+REPS = int(os.environ.get("D3F_GEMM_BENCH_REPS", "0"))
+
+
 def time_one(A, B, reps=20):
-    for _ in range(3):
+    reps = REPS or reps
+    for _ in range(1 if REPS else 3):
         ops.gemm(A, B, leaky=True)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -38,7 +42,10 @@ def main():
     dev = torch.device("cuda", 0)
     sweep = len(sys.argv) > 1 and sys.argv[1] == "sweep"
     tot_us, tot_fl = 0.0, 0.0
+    maxk = int(os.environ.get("D3F_GEMM_BENCH_MAXK", "0"))
     for (M, K, N, cnt) in SHAPES:
+        if maxk and K > maxk:
+            continue
         A = torch.randn(M, K, device=dev)
         B = torch.randn(K, N, device=dev)
         fl = 2.0 * M * K * N
