@@ -230,7 +230,7 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 #define GF_S 36
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NACC>   // NACC: independent accumulator chains per MFMA tile (1 or 2)
 __global__ void __launch_bounds__(256)
 gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                  int M, int N, int K, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
@@ -277,8 +277,16 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
         }
     }
     const int kend1 = G.A2 ? G.K1 : K;             // columns [0, kend1) come from A, [kend1, K) from the second operand
-    const int bk = tid / (BN / 4), bn = (tid % (BN / 4)) << 2;   // B slot i = k row bk + i * (1024 / BN), columns n0 + bn ..
-    const bool bnok = n0 + bn < N;
+    // B slot i of this thread: 16-row unit u = 16 i + tid / 16 of the [2][BN / 4] grid of (k half, float4 column) units,
+    // row tid % 16 of it.  A 32-lane store group then covers 16 consecutive k of two neighbouring float4 columns, which
+    // the transposed LDS rows (stride 36 = 4 mod 32) map to 32 different banks.
+    int bk[B_F4], bn[B_F4];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int u = 16 * i + (tid >> 4);
+        bk[i] = 16 * (u / (BN / 4)) + (tid & 15);
+        bn[i] = (u % (BN / 4)) << 2;
+    }
 
     float4 ra[A_F4], rb[B_F4];
     auto load_tile = [&](int t) {
@@ -293,9 +301,9 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            const int gk = t * GM_BK + bk + i * (1024 / BN);
-            const bool ok = bnok && gk < K;
-            const float4 v = *(const float4*)(ok ? B + (size_t)gk * ldb + n0 + bn : B);
+            const int gk = t * GM_BK + bk[i];
+            const bool ok = n0 + bn[i] < N && gk < K;
+            const float4 v = *(const float4*)(ok ? B + (size_t)gk * ldb + n0 + bn[i] : B);
             rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -306,18 +314,20 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
         for (int i = 0; i < A_F4; ++i) *(float4*)&as[((tid + i * 256) >> 3) * GF_S + ak] = ra[i];
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            float* d = &bt[bn * GF_S + bk + i * (1024 / BN)];
+            float* d = &bt[bn[i] * GF_S + bk[i]];
             d[0] = rb[i].x; d[GF_S] = rb[i].y; d[2 * GF_S] = rb[i].z; d[3 * GF_S] = rb[i].w;
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN][NACC];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int c = 0; c < NACC; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][c][r] = 0.f;
 
     if (t_begin < t_end) {
         load_tile(t_begin);
@@ -351,7 +361,7 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const float b = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                        acc[i][j][e % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j][e % NACC], 0, 0, 0);
                     }
                 }
             }
@@ -375,7 +385,8 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (gm < M && nok) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][0][r];
+                    if (NACC == 2) v += acc[i][j][NACC - 1][r];
                     if (slab) slab[((size_t)blockIdx.y * Mcap + gm) * N + gn] = v;
                     else {
                         if (E.row_scale) v *= E.row_scale[gm];
@@ -604,7 +615,7 @@ static int gemm_stream_blocks() {
 }
 static bool gemm_stream_ok(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const GemmGather& G,
                            int M_hint) {
-    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 1; }();
+    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 0; }();   // experimental: off
     if (!on) return false;
     const int mexp = (M_hint > 0 && M_hint < M) ? M_hint : M;
     if (K < 8 || K > 256 || K % 8 != 0 || N % 32 != 0 || mexp < 4096) return false;
@@ -659,17 +670,19 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
         const size_t lds = (size_t)2 * (bm + bn) * GF_S * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {   // the 128 x 128 tile needs 72 KB
-            if (hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess)
                 return D3F_ERR_HIP;
             attr_set = true;
         }
-#define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \
-    gemm_fast_kernel<WM_, WN_, TM_, TN_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, M_dev, G)
-        if (bn == 32) D3F_GEMM(4, 1, 1, 1);
-        else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2);
-        else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1);
-        else D3F_GEMM(2, 2, 1, 1);
+        static int nacc = [] { const char* e = getenv("D3F_GEMM_NACC"); return e ? atoi(e) : 1; }();   // measured: no gain from 2 chains
+#define D3F_GEMM(WM_, WN_, TM_, TN_, NA_)                                                                              \
+    gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, \
+                                                                          M_dev, G)
+        if (bn == 32) { if (nacc == 2) D3F_GEMM(4, 1, 1, 1, 2); else D3F_GEMM(4, 1, 1, 1, 1); }
+        else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2, 1);
+        else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1, 1);
+        else { if (nacc == 2) D3F_GEMM(2, 2, 1, 1, 2); else D3F_GEMM(2, 2, 1, 1, 1); }
 #undef D3F_GEMM
     } else {
         if (bn != 32) { bm = 64; bn = 64; grid = dim3(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm)); }

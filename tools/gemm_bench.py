@@ -22,7 +22,13 @@ SHAPES = [  # (M, K, N, count)
     (N3, 3072, 512, 1), (N2, 1024, 256, 1), (N1, 512, 128, 1), (N0, 256, 64, 1), (N0, 64, 32, 1)]
 
 
+ONLY = [tuple(int(v) for v in t.split(",")) for t in os.environ.get("D3F_GEMM_BENCH_ONLY", "").split(";") if t]   # "M,K,N;..."
 REPS = int(os.environ.get("D3F_GEMM_BENCH_REPS", "0"))
+
+
+EXTRA = [tuple(int(v) for v in t.split(",")) + (1,) for t in os.environ.get("D3F_GEMM_BENCH_EXTRA", "").split(";") if t]
+if EXTRA:
+    SHAPES = EXTRA
 
 
 def time_one(A, B, reps=20):
@@ -45,6 +51,8 @@ def main():
     maxk = int(os.environ.get("D3F_GEMM_BENCH_MAXK", "0"))
     for (M, K, N, cnt) in SHAPES:
         if maxk and K > maxk:
+            continue
+        if ONLY and (M // SCALE, K, N) not in ONLY and (M, K, N) not in ONLY:
             continue
         A = torch.randn(M, K, device=dev)
         B = torch.randn(K, N, device=dev)
