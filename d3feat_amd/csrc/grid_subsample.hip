@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restr
 struct GsMoffsEpi {
     const int* offs; int B; const int* vscan; const int* vbase; int* meta; int* moffs; int* sub_lens; int* status_dev;
     int out_cap;
+    int elem_cap;   // capacity mode: no element may hold more voxels than this (the order rounds are launched for it)
     __device__ __forceinline__ void operator()(int M) const {
         if (threadIdx.x != 0) return;   // B <= 255: one thread
         meta[0] = M;
@@ -162,7 +163,8 @@ struct GsMoffsEpi {
         for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : d3f_scan_at(vscan, vbase, offs[b]);
         // More voxels than the caller's output rows (capacity mode): flag it and report an EMPTY result, so that every
         // downstream stage of a captured launch sequence runs on zero rows instead of on partially written ones.
-        const bool over = M > out_cap;
+        bool over = M > out_cap;
+        for (int b = 0; b < B; ++b) over = over || (moffs[b + 1] - moffs[b] > elem_cap);
         if (over) atomicOr(&meta[1], D3F_ST_OUT_OVERFLOW);
         for (int b = 0; b < B; ++b) {
             const int l = over ? 0 : moffs[b + 1] - moffs[b];
@@ -556,9 +558,9 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
 // capacities, the real sizes live in HBM (lens_dev -> offs[B]; M -> status_dev[0]) and every kernel bounds itself by them,
 // so the call can be captured in a HIP graph and replayed for clouds of any size up to the capacity.
 static int gs_run(const float* points, int N, const int* lens_dev, int B, float dl, const float* features, int fdim,
-                  const int* classes, int ldim, float* sub_points, int M_cap, float* sub_features, int* sub_classes,
-                  int* sub_lens_dev, int* status_host, int* status_dev, void* workspace, size_t workspace_bytes,
-                  hipStream_t stream) {
+                  const int* classes, int ldim, float* sub_points, int M_cap, int elem_cap, float* sub_features,
+                  int* sub_classes, int* sub_lens_dev, int* status_host, int* status_dev, void* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
     const bool async = status_dev != nullptr;
     GsLayout L = gs_layout(N, B);
     D3fArena ar(workspace, workspace_bytes);
@@ -598,7 +600,9 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     int* sbase = ar.take<int>(d3f_scan_base_ints(N));   // ... of the voxel-start scan
     if (!ar.ok) return D3F_ERR_WORKSPACE;
     A.vkey = vkey; A.moffs = moffs; A.offs = offs; A.el = el;
-    A.max_m = async ? (N < M_cap ? N : M_cap) : 0x7fffffff;
+    if (elem_cap <= 0 || elem_cap > M_cap) elem_cap = M_cap;
+    if (elem_cap > N) elem_cap = N;
+    A.max_m = async ? elem_cap : 0x7fffffff;
 
     // 9 + 3 * rounds launches (was 27 + 4 * rounds): reset -> boxes (+ grid geometry) -> keys / hash insert ->
     // voxel-id scan (first-occurrence flags fused in, per-element offsets / lengths / status in its last workgroup) ->
@@ -616,7 +620,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
                                                slot, meta);
     D3F_LAUNCH_CHECK();
-    GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap};
+    GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap, async ? elem_cap : 0x7fffffff};
     if ((rc = d3f_scan_fold_launch(GsMarkIn{offs + B, slot, tfirst}, N, offs + B, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
         return rc;
     int M, maxM;       // sizes of the voxel-indexed launches
@@ -632,7 +636,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         for (int b = 0; b < B; ++b) maxM = status_host[2 + b] > maxM ? status_host[2 + b] : maxM;
     } else {
         M = N < M_cap ? N : M_cap;   // upper bound: voxels <= points, and the caller promises <= M_cap (checked on device)
-        maxM = M;
+        maxM = elem_cap;             // ... and <= elem_cap in any one element: the order rounds are launched for that
     }
 
     gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, vbase, pvid, vkey, vhead, vcnt, pnext, offs + B);
@@ -675,18 +679,19 @@ extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* l
     if ((fdim > 0 && (!features || !sub_features)) || (ldim > 0 && (!classes || !sub_classes))) return D3F_ERR_ARG;
     for (int i = 0; i < B + 2; ++i) status_host[i] = 0;
     if (N == 0) return d3f_fill_u32(sub_lens_dev, B, 0u, stream);
-    return gs_run(points, N, lens_dev, B, dl, features, fdim, classes, ldim, sub_points, N, sub_features, sub_classes,
+    return gs_run(points, N, lens_dev, B, dl, features, fdim, classes, ldim, sub_points, N, N, sub_features, sub_classes,
                   sub_lens_dev, status_host, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* lens_dev, int B, float dl,
-                                              float* sub_points, int M_cap, int* sub_lens_dev, int* status_dev,
-                                              void* workspace, size_t workspace_bytes, void* stream_) {
+                                              float* sub_points, int M_cap, int elem_cap, int* sub_lens_dev,
+                                              int* status_dev, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (N_cap < 1 || N_cap > (1 << 30) || M_cap < 1 || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f)) return D3F_ERR_ARG;
+    if (N_cap < 1 || N_cap > (1 << 30) || M_cap < 1 || elem_cap < 0 || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f))
+        return D3F_ERR_ARG;
     if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
-    return gs_run(points, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, nullptr, nullptr, sub_lens_dev,
-                  nullptr, status_dev, workspace, workspace_bytes, stream);
+    return gs_run(points, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, elem_cap, nullptr, nullptr,
+                  sub_lens_dev, nullptr, status_dev, workspace, workspace_bytes, stream);
 }
 
 // np.concatenate([pts, pts]) of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:

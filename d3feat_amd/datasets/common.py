@@ -159,9 +159,13 @@ class Dataset:
                 dl = 2 * r_normal / (config.KP_extent * 2.5)
                 if caps is not None:
                     hints = getattr(self, 'hints', None)
+                    # one cloud of the stack holds at most its share of the level's capacity (the iteration-order rounds of
+                    # the subsampler are launched for that size, not for the whole stack)
+                    units = max(int(getattr(self, 'cap_units', 1)), 1)
                     pool_p, pool_b, _ = ops.batch_grid_subsample_async(stacked_points, stacked_lengths, dl, caps[layer + 1],
                                                                        status=status_all[len(pending)],
-                                                                       m_hint=hints[layer + 1] if hints else 0)
+                                                                       m_hint=hints[layer + 1] if hints else 0,
+                                                                       elem_cap=-(-caps[layer + 1] // units))
                     pending.append(status_all[len(pending)])
                 else:
                     pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)

@@ -78,6 +78,7 @@ class FragmentEngine:
         self.nin = self.F * (2 if self.two else 1)            # clouds handed to the stage-0 subsampling per replay
         clouds = self.F * (1 if (self.mirror or self.two) else 2)
         self.caps = level_caps(n0_cap, config.num_layers, level_ratio, clouds)
+        self.cap_units = clouds                                # a level's capacity is `clouds` per-fragment capacities
         self.n0_hint = int(n0_hint if n0_hint is not None else n0_cap / 1.3)
         self.hints = level_hints(self.n0_hint, config.num_layers, clouds=clouds)
         self.model = KernelPointFCNN(None, config, weights=weights, seed=seed, device=device)
@@ -98,7 +99,8 @@ class FragmentEngine:
     def _sequence(self, sl):
         cfg = self.cfg
         sub, sub_l, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.F * self.n0_cap,
-                                                         status=sl.status0, m_hint=self.F * self.n0_hint)
+                                                         status=sl.status0, m_hint=self.F * self.n0_hint,
+                                                         elem_cap=self.n0_cap)
         if self.mirror or self.two:
             pts, lens = sub, sub_l     # the stack as subsampled: lens = [m_1 .. m_F] (mirror) or [m_a1, m_b1, ...] (two clouds)
         else:
@@ -120,6 +122,7 @@ class FragmentEngine:
         sl.ds.neighborhood_limits = self.limits
         sl.ds.caps = self.caps
         sl.ds.hints = self.hints
+        sl.ds.cap_units = self.cap_units
         sl.map = sl.ds.get_tf_mapping(self.cfg)
         sl.busy = False
         sl.raw_src = None

@@ -99,6 +99,21 @@ def test_capacity_mode_ops_match_sync_ops(device, coracle):
     guard = torch.full((100 + 8, 3), 7.0, device=device)
     sub2, _, st2 = ops.batch_grid_subsample_async(buf, lens, 0.03, 100)
     assert st2.tolist()[1] & 16
+    # per-cloud capacity of a two-cloud stack: the stack fits, one cloud does not -> flagged, empty result; with a
+    # sufficient per-cloud capacity the stack matches the oracle cloud by cloud (bit-exact, order included)
+    raw_b = _frag(22, 9000)
+    nb_ = len(raw_b)
+    buf2 = torch.zeros((cap + 12000, 3), dtype=torch.float32, device=device)
+    buf2[:n] = torch.from_numpy(raw).to(device)
+    buf2[n:n + nb_] = torch.from_numpy(raw_b).to(device)
+    lens2 = torch.tensor([n, nb_], dtype=torch.int32, device=device)
+    want_b = coracle.grid_subsampling(raw_b, 0.03)
+    _, sl3, st3 = ops.batch_grid_subsample_async(buf2, lens2, 0.03, 24000, elem_cap=len(want) - 1)
+    assert st3.tolist()[1] & 16 and st3.tolist()[0] == 0 and sl3.tolist() == [0, 0]
+    sub4, sl4, st4 = ops.batch_grid_subsample_async(buf2, lens2, 0.03, 24000, elem_cap=len(want))
+    assert st4.tolist() == [len(want) + len(want_b), 0] and sl4.tolist() == [len(want), len(want_b)]
+    assert np.array_equal(sub4[:len(want) + len(want_b)].cpu().numpy().view(np.uint32),
+                          np.concatenate([want, want_b]).view(np.uint32))
     pair, plens = ops.stack_self_pair(sub)
     assert plens.tolist() == [m, m] and int(pair.n_dev.item()) == 2 * m
     assert torch.equal(pair[:m], sub[:m]) and torch.equal(pair[m:2 * m], sub[:m])
