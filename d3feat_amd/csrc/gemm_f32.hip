@@ -230,7 +230,7 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 #define GF_S 36
 
-template <int WM, int WN, int TM, int TN, int NACC>   // NACC: independent accumulator chains per MFMA tile (1 or 2)
+template <int WM, int WN, int TM, int TN, int NACC, bool ROWS>   // NACC: accumulator chains per MFMA tile; ROWS: per-row scale
 __global__ void __launch_bounds__(256)
 gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                  int M, int N, int K, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
@@ -361,7 +361,9 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const float b = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
-                        acc[i][j][e % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j][e % NACC], 0, 0, 0);
+                        // operands swapped: the accumulator holds the TRANSPOSED tile, i.e. a lane owns one output row
+                        // and four consecutive columns per register quad -> 16-byte stores in the epilogue
+                        acc[i][j][e % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[i][j][e % NACC], 0, 0, 0);
                     }
                 }
             }
@@ -371,31 +373,59 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
         cur ^= 1;
     }
 
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    // The per-column epilogue terms are fetched once per tile column, not once per element.
+    // Accumulator layout (operands swapped, so D = tile^T): lane l owns output row (l & 31) of its 32-row tile and, in
+    // register quad q, the four consecutive columns 8q + 4(l >> 5) .. +3 of the 32-column tile: one global_store_dwordx4 per
+    // quad (the store path is issue bound: 4 wide stores per tile instead of 16 dword stores).
+    // No load may sit between two stores: a conditional load inside the store loop makes the compiler drain the memory
+    // counter (s_waitcnt vmcnt(0)) before every store, i.e. one HBM round trip per element.  So the per-column terms are
+    // fetched up front, the per-row scale (ROWS: the KPConv neighbour-count division) once per tile row, every output value
+    // is finished (and pinned) before the first predicated store, and a residual operand (unused by the network since the
+    // shortcut moved into the contraction) is left to the generic kernel.
+    float4 cs4[TN][4], ch4[TN][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
-        const bool nok = gn < N;
-        const float cs = (!slab && E.col_scale && nok) ? E.col_scale[gn] : 1.f;
-        const float ch = (!slab && E.col_shift && nok) ? E.col_shift[gn] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int q = 0; q < 4; ++q) {
+            const int gn = n0 + (wn * TN + j) * 32 + 8 * q + 4 * (lane >> 5);
+            const bool nok = gn < N;
+            cs4[j][q] = (!slab && E.col_scale && nok) ? *(const float4*)&E.col_scale[gn] : make_float4(1.f, 1.f, 1.f, 1.f);
+            ch4[j][q] = (!slab && E.col_shift && nok) ? *(const float4*)&E.col_shift[gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gm < M && nok) {
-                    float v = acc[i][j][0][r];
-                    if (NACC == 2) v += acc[i][j][NACC - 1][r];
-                    if (slab) slab[((size_t)blockIdx.y * Mcap + gm) * N + gn] = v;
-                    else {
-                        if (E.row_scale) v *= E.row_scale[gm];
-                        v = v * cs + ch;
-                        if (E.residual) v += E.residual[(size_t)gm * E.ldr + gn];
-                        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
-                        C[(size_t)gm * ldc + gn] = v;
+    for (int i = 0; i < TM; ++i) {
+        const int gm = m0 + (wm * TM + i) * 32 + (lane & 31);
+        const bool mok = gm < M;
+        float rs = 1.f;
+        if (ROWS && !slab) rs = E.row_scale[mok ? gm : M - 1];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][0][4 * q + e];
+                    if (NACC == 2) v[e] += acc[i][j][NACC - 1][4 * q + e];
+                }
+                if (!slab) {
+                    const float c[4] = {cs4[j][q].x, cs4[j][q].y, cs4[j][q].z, cs4[j][q].w};
+                    const float h4[4] = {ch4[j][q].x, ch4[j][q].y, ch4[j][q].z, ch4[j][q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = (ROWS ? v[e] * rs : v[e]) * c[e] + h4[e];
+                        v[e] = (E.leaky && !(t > 0.f)) ? t * E.alpha : t;
                     }
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));
+                o[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            float* dst = slab ? slab + ((size_t)blockIdx.y * Mcap + (mok ? gm : 0)) * N : C + (size_t)(mok ? gm : 0) * ldc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + (wn * TN + j) * 32 + 8 * q + 4 * (lane >> 5);
+                if (mok && gn < N) *(float4*)&dst[gn] = o[q];
             }
         }
     }
@@ -403,31 +433,47 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Streaming variant for the wide, shallow layers (many rows, K <= 256: the unary / shortcut / decoder contractions of the
-// two finest levels, which are HBM bound on A and C).  The whole B column slab [K x 32*NT] is staged in LDS once per
-// workgroup; every wavefront then walks 32-row groups on its own -- no barrier after the prologue -- with the A rows going
-// global -> registers directly (the MFMA A fragment is one value per lane and k-step, and the contraction does not care
-// in which order k is visited: lane (row r, half h) loads float4 A[r][8j + 4h ..] and feeds element t to k-step (j, t),
-// where the B fragment reads row 8j + 4h + t) and the next 64-column chunk prefetched while the current one is multiplied.
-// Against the tiled kernel: B is read once per ~14 row groups instead of once per 2, A never passes through LDS, and the
-// row count only enters through the loop bound, so a capacity-sized launch costs nothing.
+// two finest levels, which are bound by the HBM traffic of A and C, not by the multiply).
+//  * the B column slab [K x 32*NT] is staged ONCE per workgroup, transposed ([n][k], row stride K + 4), and stays in LDS;
+//  * every wavefront then walks 32-row groups on its own -- no barrier after the prologue.  A goes global -> registers
+//    directly: the MFMA A fragment is one value per lane and k-step and the contraction may visit k in any order, so lane
+//    (row r, half h) loads the float4 pairs A[r][16j + 8h .. +7] and feeds element t to k-step (j, t), where the B fragment
+//    (two ds_read_b128 per eight k-steps) reads the same k from its transposed row;
+//  * rows are clamped instead of predicated (a row past M only feeds output rows that are never stored), so the loads are
+//    straight-line code; the next 64-column chunk (of this or the next row group) is in flight while the current one is
+//    multiplied, and the B fragments of the next 16 columns are fetched before the current MFMAs issue.
+// Against the tile kernel: B is read once per ~14 row groups instead of once per 2, A never passes through LDS, and the
+// real row count only enters through the loop bound, so a capacity-sized launch costs nothing.
 // ------------------------------------------------------------------------------------------------
 #define GS_KC 64                       // k columns per register chunk (8 float4 per lane)
 
-template <int NT>
+template <int NT, bool GATHER>
 __global__ void __launch_bounds__(256)
 gemm_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                    int M, int N, int K, GemmEpi E, const int* __restrict__ M_dev, GemmGather G) {
-    constexpr int NTILE = 32 * NT, SB = NTILE + 8;   // +8: rows k and k+4 (the two lane halves) land on different banks
-    extern __shared__ __attribute__((aligned(16))) float gs_lB[];
+    constexpr int NTILE = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float gs_bt[];     // [NTILE][SK], then col_scale | col_shift [2][NTILE]
+    const int SK = K + 4;
+    float* lcs = gs_bt + NTILE * SK;
     M = d3f_dyn(M, M_dev);
     const int groups = (M + 31) >> 5;
     if ((int)(blockIdx.x * 4) >= groups) return;    // whole workgroup idle (capacity-sized grid)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * NTILE;
-    for (int e = tid; e < K * (NTILE / 4); e += 256) {
-        const int k = e / (NTILE / 4), n4 = (e % (NTILE / 4)) << 2;
-        *(float4*)&gs_lB[k * SB + n4] = *(const float4*)&B[(size_t)k * ldb + n0 + n4];
+    {   // 16-row units of (k, float4 column): a 32-lane store group covers 16 consecutive k of two neighbouring float4
+        // columns, which land on 32 different banks (SK = 4 mod 32 for K a multiple of 32)
+        const int units = (K >> 4) * (NTILE / 4);
+        for (int u = tid >> 4; u < units; u += 16) {
+            const int k = 16 * (u / (NTILE / 4)) + (tid & 15), n4 = (u % (NTILE / 4)) << 2;
+            const float4 v = *(const float4*)&B[(size_t)k * ldb + n0 + n4];
+            float* d = &gs_bt[n4 * SK + k];
+            d[0] = v.x; d[SK] = v.y; d[2 * SK] = v.z; d[3 * SK] = v.w;
+        }
+    }
+    if (tid < NTILE) {
+        lcs[tid] = E.col_scale ? E.col_scale[n0 + tid] : 1.f;
+        lcs[NTILE + tid] = E.col_shift ? E.col_shift[n0 + tid] : 0.f;
     }
     __syncthreads();
     int g = blockIdx.x * 4 + wave;
@@ -435,84 +481,127 @@ gemm_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict
     const int gstride = gridDim.x * 4;
     const int n1 = d3f_dyn(G.N1, G.N1_dev);
     const int nchunk = (K + GS_KC - 1) / GS_KC;
+    const int kend1 = G.A2 ? G.K1 : K;              // columns [0, kend1) from A, the rest from the second operand
 
-    auto row_source = [&](int grp) -> int {      // row of A feeding tile row r of group grp: -1 = zero row
-        const int gm = grp * 32 + r;
-        if (gm >= M) return -1;
-        if (!G.gidx) return gm;
-        const int sr = G.gidx[(size_t)gm * G.ld_gidx];
-        return (sr < 0 || sr >= n1) ? -1 : sr;
+    // source rows of tile row r of a group: clamped into range (rows >= M are never stored); a shadow gather index reads
+    // as a zero row
+    auto sources = [&](int grp, const float*& pa, const float*& pa2, bool& zero) {
+        int gm = grp * 32 + r;
+        gm = gm < M ? gm : M - 1;
+        int sr = gm;
+        zero = false;
+        if (GATHER) {
+            sr = G.gidx[(size_t)gm * G.ld_gidx];
+            zero = sr < 0 || sr >= n1;
+            sr = zero ? 0 : sr;
+        }
+        pa = A + (size_t)sr * lda + 8 * h;
+        pa2 = G.A2 ? G.A2 + (size_t)gm * G.lda2 + 8 * h - kend1 : pa;
     };
-    auto load_chunk = [&](float4 (&dst)[8], int grp, int c, int srow) {
-        const int gm = grp * 32 + r;
+    // straight-line: a column block past K is clamped back into the row (loaded, never multiplied), so that no branch --
+    // and with it no conservative s_waitcnt -- separates these loads from the multiply they overlap with
+    auto load_chunk = [&](float4 (&dst)[8], int c, const float* pa, const float* pa2, bool zero) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = c * GS_KC + 8 * j + 4 * h;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < K && gm < M) {
-                if (G.A2 && k >= G.K1) v = *(const float4*)(G.A2 + (size_t)gm * G.lda2 + (k - G.K1));
-                else if (srow >= 0) v = *(const float4*)(A + (size_t)srow * lda + k);
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(c * GS_KC + 16 * j, K - 16);      // wave-uniform
+            const bool second = k >= kend1;
+            const float* p = (second ? pa2 : pa) + k;
+            float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
+            if (GATHER) {
+                const bool z = zero && !second;
+                v0.x = z ? 0.f : v0.x; v0.y = z ? 0.f : v0.y; v0.z = z ? 0.f : v0.z; v0.w = z ? 0.f : v0.w;
+                v1.x = z ? 0.f : v1.x; v1.y = z ? 0.f : v1.y; v1.z = z ? 0.f : v1.z; v1.w = z ? 0.f : v1.w;
             }
-            dst[j] = v;
+            dst[2 * j] = v0;
+            dst[2 * j + 1] = v1;
         }
     };
 
-    float cs[NT], ch[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        cs[t] = E.col_scale ? E.col_scale[n0 + t * 32 + r] : 1.f;
-        ch[t] = E.col_shift ? E.col_shift[n0 + t * 32 + r] : 0.f;
-    }
+    const float* bt = gs_bt + r * SK + 8 * h;       // this lane's column of tile 0, its half of every 16-k block
 
     float4 cur[8], nxt[8];
-    int srow = row_source(g);
-    load_chunk(cur, g, 0, srow);
+    const float *pa, *pa2;
+    bool zero;
+    sources(g, pa, pa2, zero);
+    load_chunk(cur, 0, pa, pa2, zero);
     for (;;) {
         const int gn = g + gstride;
-        const int srow_n = gn < groups ? row_source(gn) : -1;
+        const float *pan, *pa2n;
+        bool zeron;
+        sources(gn < groups ? gn : g, pan, pa2n, zeron);
         f32x16 acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
         for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk) load_chunk(nxt, g, c + 1, srow);
-            else if (gn < groups) load_chunk(nxt, gn, 0, srow_n);
-            const float* bp = &gs_lB[(c * GS_KC + 4 * h) * SB + r];
+            {   // next chunk of this group, else the first chunk of the next group (or a harmless re-load at the very end)
+                const bool same = c + 1 < nchunk;
+                load_chunk(nxt, same ? c + 1 : 0, same ? pa : pan, same ? pa2 : pa2n, same ? zero : zeron);
+            }
+            float4 fb[2][NT][2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (c * GS_KC + 8 * j < K) {
-                    const float a4[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+            for (int u = 0; u < NT; ++u) {
+                fb[0][u][0] = *(const float4*)&bt[u * 32 * SK + c * GS_KC];
+                fb[0][u][1] = *(const float4*)&bt[u * 32 * SK + c * GS_KC + 4];
+            }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+            for (int j = 0; j < 4; ++j) {
+                if (c * GS_KC + 16 * j < K) {
+                    if (j < 3 && c * GS_KC + 16 * (j + 1) < K) {
 #pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], bp[(8 * j + t) * SB + u * 32], acc[u], 0, 0, 0);
+                        for (int u = 0; u < NT; ++u) {
+                            fb[(j + 1) & 1][u][0] = *(const float4*)&bt[u * 32 * SK + c * GS_KC + 16 * (j + 1)];
+                            fb[(j + 1) & 1][u][1] = *(const float4*)&bt[u * 32 * SK + c * GS_KC + 16 * (j + 1) + 4];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float4 av = cur[2 * j + (t >> 2)];
+                        const float a = (t & 3) == 0 ? av.x : (t & 3) == 1 ? av.y : (t & 3) == 2 ? av.z : av.w;
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) {
+                            const float4 bv = fb[j & 1][u][t >> 2];
+                            const float b = (t & 3) == 0 ? bv.x : (t & 3) == 1 ? bv.y : (t & 3) == 2 ? bv.z : bv.w;
+                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[u], 0, 0, 0);   // transposed tile
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
         }
-        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+        // transposed accumulators: lane = output row r of the group, register quad q = columns 8q + 4h .. +3 of a 32-column
+        // tile: 16-byte stores; the per-column terms come from LDS, every value is finished before the first store (see
+        // gemm_fast_kernel)
+        {
+            const int gm = g * 32 + r;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int gcol = n0 + u * 32 + r;
+            for (int u = 0; u < NT; ++u) {
+                float4 o[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int gm = g * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (gm < M) {
-                    float v = acc[u][i];
-                    if (E.row_scale) v *= E.row_scale[gm];
-                    v = v * cs[u] + ch[u];
-                    if (E.residual) v += E.residual[(size_t)gm * E.ldr + gcol];
-                    if (E.leaky) v = v > 0.f ? v : v * E.alpha;
-                    C[(size_t)gm * ldc + gcol] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 c4 = *(const float4*)&lcs[u * 32 + 8 * q + 4 * h];
+                    const float4 h4 = *(const float4*)&lcs[NTILE + u * 32 + 8 * q + 4 * h];
+                    float v[4] = {acc[u][4 * q] * c4.x + h4.x, acc[u][4 * q + 1] * c4.y + h4.y,
+                                  acc[u][4 * q + 2] * c4.z + h4.z, acc[u][4 * q + 3] * c4.w + h4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (E.leaky && !(v[e] > 0.f)) ? v[e] * E.alpha : v[e];
+                        asm volatile("" : "+v"(v[e]));
+                    }
+                    o[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
+                float* dst = C + (size_t)(gm < M ? gm : 0) * ldc + n0 + u * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (gm < M) *(float4*)&dst[8 * q] = o[q];
             }
         }
         if (gn >= groups) break;
         g = gn;
-        srow = srow_n;
+        pa = pan; pa2 = pa2n; zero = zeron;
     }
 }
 
@@ -615,38 +704,41 @@ static int gemm_stream_blocks() {
 }
 static bool gemm_stream_ok(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const GemmGather& G,
                            int M_hint) {
-    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 0; }();   // experimental: off
+    // D3F_GEMM_STREAM: 0 never, 2 wherever it can run (tests), default 1 = where it was measured ahead of the tile kernel
+    // (tools/gemm_bench.py, MI355X): the finest level's contractions -- >= 64 k rows, K <= 128
+    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     if (!on) return false;
     const int mexp = (M_hint > 0 && M_hint < M) ? M_hint : M;
-    if (K < 8 || K > 256 || K % 8 != 0 || N % 32 != 0 || mexp < 4096) return false;
+    if (K < 16 || K > 256 || K % 16 != 0 || N % 32 != 0) return false;
+    if (on == 1 ? (mexp < 65536 || K > 128) : (mexp < 256)) return false;
     if (lda % 4 != 0 || ldb % 4 != 0 || (((uintptr_t)A | (uintptr_t)B) & 15) != 0) return false;
-    if (G.A2 && (G.K1 % 4 != 0 || G.lda2 % 4 != 0 || ((uintptr_t)G.A2 & 15) != 0)) return false;
+    if ((size_t)64 * (K + 6) * sizeof(float) > 73728) return false;
+    if (G.A2 && (G.K1 % 16 != 0 || G.lda2 % 4 != 0 || ((uintptr_t)G.A2 & 15) != 0)) return false;
     return true;
 }
 
 static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, GemmEpi E,
                     GemmGather G, void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, hipStream_t stream) {
-    if (gemm_stream_ok(A, lda, B, ldb, M, N, K, G, M_hint)) {
+    if (!E.residual && !E.row_scale && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && gemm_stream_ok(A, lda, B, ldb, M, N, K, G, M_hint)) {
         // column slab per workgroup: as wide as 72 KB of LDS allows (two workgroups per CU)
-        int nt = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1);
-        while (nt > 1 && (size_t)K * (32 * nt + 8) * sizeof(float) > 73728) nt >>= 1;
-        const size_t lds = (size_t)K * (32 * nt + 8) * sizeof(float);
-        const int mplan = M;
-        int bx = d3f_cdiv(d3f_cdiv(mplan, 32), 4);
+        int nt = N % 64 == 0 ? 2 : 1;     // (four column tiles per wave would leave one wave per SIMD: nothing overlaps)
+        const size_t lds = (size_t)(32 * nt) * (K + 4 + 2) * sizeof(float);
+        int bx = d3f_cdiv(d3f_cdiv(M, 32), 4);
         const int bx_max = gemm_stream_blocks();
         if (bx > bx_max) bx = bx_max;
         dim3 grid(bx, N / (32 * nt));
         static bool attr_set = false;
         if (!attr_set) {   // slabs above 64 KB need the opt-in
-            if (hipFuncSetAttribute((const void*)gemm_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess ||
-                hipFuncSetAttribute((const void*)gemm_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess ||
-                hipFuncSetAttribute((const void*)gemm_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess)
-                return D3F_ERR_HIP;
+            const void* fns[4] = {(const void*)gemm_stream_kernel<2, false>, (const void*)gemm_stream_kernel<1, false>,
+                                  (const void*)gemm_stream_kernel<2, true>, (const void*)gemm_stream_kernel<1, true>};
+            for (int i = 0; i < 4; ++i)
+                if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess) return D3F_ERR_HIP;
             attr_set = true;
         }
-        if (nt == 4) gemm_stream_kernel<4><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G);
-        else if (nt == 2) gemm_stream_kernel<2><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G);
-        else gemm_stream_kernel<1><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G);
+#define D3F_STREAM(NT_, GA_) gemm_stream_kernel<NT_, GA_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G)
+        if (G.gidx) { if (nt == 2) D3F_STREAM(2, true); else D3F_STREAM(1, true); }
+        else { if (nt == 2) D3F_STREAM(2, false); else D3F_STREAM(1, false); }
+#undef D3F_STREAM
         D3F_LAUNCH_CHECK();
         return D3F_OK;
     }
@@ -664,25 +756,33 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
     dim3 grid(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm));
     // float4-addressable operands (every shape of the network): the straight-line kernel; anything else: the generic one
     static int fast_on = [] { const char* e = getenv("D3F_GEMM_FAST"); return e ? atoi(e) : 1; }();
-    const bool fast = fast_on && vecA && vecB && K % 4 == 0 && N % 4 == 0 &&
+    const bool fast = fast_on && !E.residual && vecA && vecB && K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 &&
+                      (((uintptr_t)C | (uintptr_t)E.col_scale | (uintptr_t)E.col_shift) & 15) == 0 &&
                       (!G.A2 || (G.K1 % 4 == 0 && G.lda2 % 4 == 0 && ((uintptr_t)G.A2 & 15) == 0));
     if (fast) {
         const size_t lds = (size_t)2 * (bm + bn) * GF_S * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {   // the 128 x 128 tile needs 72 KB
-            if (hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess)
                 return D3F_ERR_HIP;
             attr_set = true;
         }
-        static int nacc = [] { const char* e = getenv("D3F_GEMM_NACC"); return e ? atoi(e) : 1; }();   // measured: no gain from 2 chains
 #define D3F_GEMM(WM_, WN_, TM_, TN_, NA_)                                                                              \
-    gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, \
-                                                                          M_dev, G)
-        if (bn == 32) { if (nacc == 2) D3F_GEMM(4, 1, 1, 1, 2); else D3F_GEMM(4, 1, 1, 1, 1); }
+    do {                                                                                                               \
+        if (E.row_scale)                                                                                               \
+            gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, true><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, \
+                                                                                        slab, E, M_dev, G);           \
+        else                                                                                                           \
+            gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, false><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, \
+                                                                                         slab, E, M_dev, G);          \
+    } while (0)
+        if (bn == 32) D3F_GEMM(4, 1, 1, 1, 1);
         else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2, 1);
         else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1, 1);
-        else { if (nacc == 2) D3F_GEMM(2, 2, 1, 1, 2); else D3F_GEMM(2, 2, 1, 1, 1); }
+        else D3F_GEMM(2, 2, 1, 1, 1);
 #undef D3F_GEMM
     } else {
         if (bn != 32) { bm = 64; bn = 64; grid = dim3(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm)); }

@@ -24,7 +24,7 @@ def _close(got, want, tol=TOL):
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 32), (777, 15, 64), (4097, 128, 256), (390, 7680, 512), (200, 1024, 2048),
-                                   (64, 3072, 512), (5, 3, 7)])
+                                   (64, 3072, 512), (5, 3, 7), (70001, 96, 128), (66000, 64, 32)])
 def test_gemm_epilogues(device, M, K, N):
     from d3feat_amd import ops
     rng = np.random.default_rng(M + K + N)
@@ -41,6 +41,20 @@ def test_gemm_epilogues(device, M, K, N):
     full = np.where(full > 0, full, 0.2 * full)
     got = ops.gemm(_t(A, device), _t(B, device), _t(rs, device), _t(cs, device), _t(ch, device), _t(res, device), True, 0.2)
     _close(got.cpu().numpy(), full, 2e-5)
+
+
+def test_gemm_streaming_kernel_everywhere(device):
+    """The shallow-K streaming kernel only takes the finest level's shapes by default; D3F_GEMM_STREAM=2 sends every eligible
+    shape through it (the switch is read once per process, hence the child process): the contraction / decoder tests must
+    pass unchanged."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, D3F_GEMM_STREAM="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "test_gemm_epilogues or test_gemm_upsample_cat or test_gemm_strided"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_gemm_strided_views(device):
