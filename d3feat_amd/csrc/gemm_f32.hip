@@ -630,12 +630,13 @@ static void gemm_plan(int M, int N, int K, int M_hint, int& bm, int& bn, int& S,
     else { bm = 64; bn = 64; }
     const long long blocks = blocks_of(bm, bn);
     const int nt = d3f_cdiv(K, GM_BK);
-    // Skinny problems are latency bound per k-tile (global -> LDS -> MFMA): give every CU ~4 co-resident workgroups by
-    // splitting K, as long as each split keeps >= 4 k-tiles.
+    // Skinny problems with a long K are latency bound per k-tile (global -> LDS -> MFMA): give every CU ~6 co-resident
+    // workgroups by splitting K, as long as each split keeps >= 8 k-tiles.  Up to 16 k-tiles (K <= 512) a split never paid
+    // for its slab traffic and reduce launch (tools/gemm_bench.py sweep).
     S = 1;
-    if (blocks < 768 && nt >= 8) {
-        long long want = (1024 + blocks - 1) / blocks;
-        long long maxs = nt / 4;
+    if (blocks < 768 && nt > 16) {
+        long long want = (1536 + blocks - 1) / blocks;
+        long long maxs = nt / 8;
         S = (int)(want < maxs ? want : maxs);
         if (S > 64) S = 64;
         if (S < 1) S = 1;

@@ -6,14 +6,24 @@
 // ------------------------------------------------------------------------------------------------
 // ind_max_pool -- models/network_blocks.py:51-66.  x' = x with one extra row holding the per-channel minimum
 // of x (the "shadow" row); out[n,c] = max_k x'[idx[n,k], c].
+//
+// The shadow row can only win where a row has NO valid neighbour at all (a column minimum is <= every real entry), which
+// a pooled barycentre never is -- its own voxel's points lie inside the pooling radius.  So the full pass over x that the
+// column minima cost (the whole feature matrix of the finer level, read only for them) is made lazy: the pooling kernel
+// takes the maximum over the valid neighbours and raises a flag for a row without any; the column-minimum kernels and the
+// patch kernel run in every call (fixed launch sequence) but leave at once unless that flag is up.  Result: bit-identical
+// to the eager formulation in all cases.
+// col_min_dev: u32[C + 4]: [0, C) ordered-uint column minima (valid only when the flag was raised), [C] the flag.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) colmin_init_kernel(unsigned* __restrict__ cm, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) cm[c] = 0xFFFFFFFFu;
+    if (c == C) cm[C] = 0u;       // the flag
 }
 
 __global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x, int N1, const int* __restrict__ N1_dev,
                                                      int ldx, int C, unsigned* __restrict__ cm) {
+    if (cm[C] == 0u) return;      // no row needs the shadow row
     N1 = d3f_dyn(N1, N1_dev);
     // thread = channel (coalesced across a row); each block strides over rows
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -23,15 +33,32 @@ __global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x
     atomicMin(&cm[c], m);
 }
 
-__global__ void __launch_bounds__(256) colmin_decode_kernel(unsigned* __restrict__ cm, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) ((float*)cm)[c] = d3f_ord2f(cm[c]);
+// rows without a valid neighbour (or K == 0) take the shadow row
+__global__ void __launch_bounds__(256) maxpool_patch_kernel(const unsigned* __restrict__ cm, int C, int N1,
+                                                            const int* __restrict__ idx, int N2, int ld_idx, int K,
+                                                            float* __restrict__ out, int ldo, const int* __restrict__ N1_dev,
+                                                            const int* __restrict__ N2_dev) {
+    if (cm[C] == 0u) return;
+    N1 = d3f_dyn(N1, N1_dev);
+    N2 = d3f_dyn(N2, N2_dev);
+    // one wavefront per row, grid-stride
+    const int lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; n < N2; n += nw) {
+        bool any = false;
+        for (int k = lane; k < K; k += 64) {
+            const int id = idx[(size_t)n * ld_idx + k];
+            any = any || (id >= 0 && id < N1);
+        }
+        if (__any(any)) continue;
+        for (int c = lane; c < C; c += 64) out[(size_t)n * ldo + c] = d3f_ord2f(cm[c]);
+    }
 }
 
 template <int VEC>  // channels per thread (4: 16-byte loads; 1: generic)
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
-                                                      const float* __restrict__ colmin, float* __restrict__ out, int ldo,
+                                                      unsigned* __restrict__ flag, float* __restrict__ out, int ldo,
                                                       const int* __restrict__ N1_dev, const int* __restrict__ N2_dev,
                                                       const int* __restrict__ row_order) {
     N1 = d3f_dyn(N1, N1_dev);
@@ -41,10 +68,11 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
     if (t >= (long long)N2 * CV) return;
     const int slot = (int)(t / CV), c = (int)(t % CV) * VEC;
     const int n = row_order ? row_order[slot] : slot;   // spatially coherent visiting order (see kpconv.hip)
-    float sh[VEC], m[VEC];
+    float m[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { sh[v] = colmin[c + v]; m[v] = -3.402823466e38f; }
+    for (int v = 0; v < VEC; ++v) m[v] = -3.402823466e38f;
     const int* row = idx + (size_t)n * ld_idx;
+    int nvalid = 0;
     for (int k0 = 0; k0 < K; k0 += 4) {
         int id[4];
         float val[4][VEC];
@@ -52,7 +80,9 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
         for (int j = 0; j < 4; ++j) id[j] = (k0 + j < K) ? row[k0 + j] : -2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (id[j] >= 0 && id[j] < N1) {
+            const bool ok = id[j] >= 0 && id[j] < N1;
+            nvalid += ok ? 1 : 0;
+            if (ok) {
                 if (VEC == 4) {
                     const float4 f = *(const float4*)&x[(size_t)id[j] * ldx + c];
                     val[j][0] = f.x; val[j][1 % VEC] = f.y; val[j][2 % VEC] = f.z; val[j][3 % VEC] = f.w;
@@ -62,7 +92,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
                 }
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) val[j][v] = (id[j] == -2) ? -3.402823466e38f : sh[v];  // shadow -> column min
+                for (int v = 0; v < VEC; ++v) val[j][v] = -3.402823466e38f;  // shadow (<= every real entry) or beyond K
             }
         }
 #pragma unroll
@@ -70,8 +100,9 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
 #pragma unroll
             for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], val[j][v]);
     }
+    if (nvalid == 0 && c == 0) atomicOr(flag, 1u);   // this row is the shadow row: patched after the column minima exist
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) out[(size_t)n * ldo + c + v] = (K > 0) ? m[v] : sh[v];
+    for (int v = 0; v < VEC; ++v) out[(size_t)n * ldo + c + v] = m[v];
 }
 
 extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
@@ -82,20 +113,22 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
     if (N2 == 0) return D3F_OK;
     if (!x || !idx || !out || !col_min_dev) return D3F_ERR_ARG;
     unsigned* cm = (unsigned*)col_min_dev;
-    colmin_init_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
-    if (N1 > 0) {
-        int rows = d3f_cdiv(N1, 32);
-        if (rows > 1024) rows = 1024;
-        colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, N1_dev, ldx, C, cm);
-    }
-    colmin_decode_kernel<<<d3f_cdiv(C, 256), 256, 0, stream>>>(cm, C);
+    colmin_init_kernel<<<d3f_cdiv(C + 1, 256), 256, 0, stream>>>(cm, C);
     if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
         maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
-                                                                                      col_min_dev, out, ldo, N1_dev, N2_dev,
+                                                                                      cm + C, out, ldo, N1_dev, N2_dev,
                                                                                       row_order);
     else
-        maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, col_min_dev,
+        maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, cm + C,
                                                                                out, ldo, N1_dev, N2_dev, row_order);
+    if (N1 > 0) {
+        int rows = d3f_cdiv(N1, 32);
+        if (rows > 256) rows = 256;
+        colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, N1_dev, ldx, C, cm);
+    }
+    int pb = d3f_cdiv(N2, 4);
+    if (pb > 256) pb = 256;
+    maxpool_patch_kernel<<<pb, 256, 0, stream>>>(cm, C, N1, idx, N2, ld_idx, K, out, ldo, N1_dev, N2_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -161,6 +161,10 @@ __global__ void __launch_bounds__(256) scan_fold_kernel(In in, int n, const int*
                                                         int* __restrict__ base, unsigned* __restrict__ counter, Epi epi) {
     __shared__ int lds[4];
     n = d3f_dyn(n, n_dev);   // items beyond the device-side count are zeros that are neither read nor written
+    // capacity-sized launch: only the tiles that hold items take part (and take a ticket); tile 0 always does, so that the
+    // epilogue runs for an empty input too
+    const int live = max(1, (n + D3F_SCAN_TILE - 1) / D3F_SCAN_TILE);
+    if ((int)blockIdx.x >= live) return;
     const int i0 = blockIdx.x * D3F_SCAN_TILE + threadIdx.x * 4;
     int v[4], s = 0;
 #pragma unroll
@@ -176,8 +180,8 @@ __global__ void __launch_bounds__(256) scan_fold_kernel(In in, int n, const int*
         ex += v[k];
     }
     if (threadIdx.x == 0) base[blockIdx.x] = tot;
-    if (!d3f_last_block(counter, gridDim.x)) return;
-    const int nblocks = gridDim.x;
+    if (!d3f_last_block(counter, (unsigned)live)) return;
+    const int nblocks = live;
     int carry = 0;
     for (int c = 0; c < nblocks; c += 256) {
         const int i = c + threadIdx.x;

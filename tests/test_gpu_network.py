@@ -136,6 +136,15 @@ def test_pools_vs_oracle(device, coracle):
     want = onp.ind_max_pool(torch.from_numpy(x), pool_i).numpy()
     got = ops.ind_max_pool(_t(x, device), _t(pool_i.astype(np.int32), device)).cpu().numpy()
     assert np.array_equal(got, want)
+    assert not (pool_i >= len(s0)).all(1).any()      # every row has a valid neighbour: the column minima are never computed
+    # a radius below the voxel size leaves pooled points without any neighbour: those rows ARE the shadow row (column
+    # minima, computed lazily); also the degenerate all-shadow index matrix
+    pool_s = coracle.batch_neighbors(sub, s0, l1, l0, np.float32(0.02))[:, :7]
+    assert (pool_s >= len(s0)).all(1).sum() > 50
+    for inds in (pool_s, np.full((9, 3), len(s0), np.int32)):
+        want = onp.ind_max_pool(torch.from_numpy(x), inds).numpy()
+        got = ops.ind_max_pool(_t(x, device), _t(inds.astype(np.int32), device)).cpu().numpy()
+        assert np.array_equal(got, want)
     want = torch.cat([onp.closest_pool(torch.from_numpy(y), up_i), torch.from_numpy(x)], 1).numpy()
     got = ops.closest_pool_cat(_t(y, device), _t(up_i.astype(np.int32), device), _t(x, device)).cpu().numpy()
     assert np.array_equal(got, want)
