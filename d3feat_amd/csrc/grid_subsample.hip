@@ -381,7 +381,9 @@ __device__ __forceinline__ void gs_order_scan_sums(const GsOrderArgs& A, int j, 
 }
 
 // tile-local reverse exclusive scan of c[t] = (t first of its bucket) ? bucket size : 0, over u = hi-1-t; the last
-// workgroup of the launch then scans every element's tile sums (gs_order_place adds them)
+// workgroup of EACH ELEMENT then scans that element's tile sums (gs_order_place adds them).  Tickets are per element and
+// only the tiles that hold items take one: the elements finish independently instead of queueing behind one workgroup,
+// and the idle tiles of a capacity-sized launch do not serialise on the counter.
 __global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A, int j, int B, unsigned* __restrict__ counter) {
     __shared__ int wsum[4];
     const int b = blockIdx.y;
@@ -389,7 +391,8 @@ __global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A,
     bool last;
     const int tile = blockIdx.x;
     const bool active = gs_round(A, b, j, M, lo, hi, nb, last) && tile * GS_TILE < hi;   // workgroup-uniform
-    if (active) {
+    if (!active) return;
+    {
         const int o = A.offs[b];
         const long long bbase = A.el[b].bbase;
         const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -428,11 +431,8 @@ __global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A,
         }
         if (tid == 0) A.tsum[o / GS_TILE + b + tile] = tot;
     }
-    if (!d3f_last_block(counter, gridDim.x * gridDim.y)) return;
-    for (int e = 0; e < B; ++e) {
-        __syncthreads();
-        gs_order_scan_sums(A, j, e, wsum);
-    }
+    if (!d3f_last_block(counter + b, (unsigned)((hi + GS_TILE - 1) / GS_TILE))) return;
+    gs_order_scan_sums(A, j, b, wsum);
 }
 
 __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int j) {
@@ -549,7 +549,7 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     bytes += 14 * d3f_align(n * sizeof(int));               // slot vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx cd bkt
     bytes += 6 * d3f_align((size_t)L.bucket_total * sizeof(int));
     bytes += d3f_align((n / GS_TILE + B + 8) * sizeof(int));
-    bytes += 2 * d3f_align(d3f_scan_base_ints(N) * sizeof(int)) + d3f_align(64 * sizeof(unsigned));
+    bytes += 2 * d3f_align(d3f_scan_base_ints(N) * sizeof(int)) + d3f_align((4 + D3F_NCHAIN * (size_t)B) * sizeof(unsigned));
     return bytes + 4096;
 }
 
@@ -569,7 +569,9 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     int* moffs = ar.take<int>(B + 1);
     unsigned* bbox = ar.take<unsigned>(B * 6);
     GsElem* el = ar.take<GsElem>(B);
-    unsigned* counters = ar.take<unsigned>(64);   // ticket counters: [0] boxes, [1] voxel-id scan, [2] start scan, [4 + j] round j
+    // ticket counters: [0] boxes, [1] voxel-id scan, [2] start scan, [4 + j * B + b] iteration-order round j of element b
+    const int ncounters = 4 + D3F_NCHAIN * B;
+    unsigned* counters = ar.take<unsigned>(ncounters);
     // [tkey | tfirst | vhead] are reset to 0xFFFFFFFF and [meta | vcnt] to 0 by ONE launch: keep each group contiguous
     unsigned long long* tkey = ar.take<unsigned long long>(L.cap);
     unsigned* tfirst = ar.take<unsigned>(L.cap);
@@ -612,7 +614,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     const D3fFill none{nullptr, 0ull, 0u};
     const unsigned long long ones_words = (unsigned long long)((char*)(vhead + n) - (char*)tkey) / 4ull;
     const unsigned long long zero_words = (unsigned long long)((char*)(vcnt + n) - (char*)meta) / 4ull;
-    if ((rc = d3f_begin_launch(lens_dev, B, offs, bbox, counters, 64, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
+    if ((rc = d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
                                D3fFill{(unsigned*)meta, zero_words, 0u}, none, none, stream)) != D3F_OK) return rc;
     GsPrepEpi prep{bbox, offs, B, dl, el, meta};
     if ((rc = d3f_bbox_launch_t(points, offs, B, N, bbox, counters, prep, stream)) != D3F_OK) return rc;
@@ -655,7 +657,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         const int hi = (int)((long long)maxM < nbj ? (long long)maxM : nbj);
         dim3 g(d3f_cdiv(hi, 256), B), gt(d3f_cdiv(hi, GS_TILE), B);
         gs_order_insert_kernel<<<g, 256, 0, stream>>>(A, j);
-        gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j);
+        gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j * B);
         gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
     }
     gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,

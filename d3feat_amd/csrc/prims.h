@@ -120,8 +120,11 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pts
 template <class Epi>
 static inline int d3f_bbox_launch_t(const float* pts, const int* offs, int B, int N, unsigned* bbox, unsigned* counter, Epi epi,
                                     hipStream_t stream) {
+    // about one workgroup per CU over all elements: every workgroup ends with a ticket on ONE counter, and same-address
+    // atomics serialise at ~12 ns each, so thousands of (mostly idle) workgroups cost more than the boxes themselves
     int chunks = d3f_cdiv(N > 0 ? N : 1, 256 * 4);
-    if (chunks > 128) chunks = 128;
+    const int per_elem = 256 / B > 1 ? 256 / B : 1;
+    if (chunks > per_elem) chunks = per_elem;
     bbox_kernel<Epi><<<dim3(chunks, B), 256, 0, stream>>>(pts, offs, B, bbox, counter, epi);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
