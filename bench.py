@@ -40,8 +40,8 @@ MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-fragments", type=int, default=2)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
@@ -245,7 +245,7 @@ def main():
                 nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], 32, 32), 0.0
                 per_step_agg[-1].append((info, ms))
             elif name == "gemm_f32":
-                key = "gemm_f32_kernel"
+                key = "gemm_fast_kernel"       # the contraction family: tile kernel (+ streaming / split-K reduce kernels)
                 nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
                 flops = 2.0 * info["M"] * info["N"] * info["K"]
                 per_step_gemm[-1].append((info, ms))
@@ -282,8 +282,9 @@ def main():
         if cands:
             try:
                 tj = json.load(open(cands[-1]))
-                fam_name = dom_name.split("<")[0]
-                ent = [v for k, v in tj.items() if k.split("<")[0] == fam_name and "traffic_bytes_per_launch" in v]
+                fam_names = (("gemm_fast_kernel", "gemm_stream_kernel", "gemm_f32_kernel") if dom_name.startswith("gemm")
+                             else (dom_name.split("<")[0],))
+                ent = [v for k, v in tj.items() if k.split("<")[0] in fam_names and "traffic_bytes_per_launch" in v]
                 nl = sum(e["launches"] for e in ent)
                 if nl:
                     roof["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl)

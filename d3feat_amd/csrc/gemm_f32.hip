@@ -230,7 +230,8 @@ gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 #define GF_S 36
 
-template <int WM, int WN, int TM, int TN, int NACC, bool ROWS>   // NACC: accumulator chains per MFMA tile; ROWS: per-row scale
+// NACC: accumulator chains per MFMA tile; EPI bit 0: per-row scale, bit 1: residual operand
+template <int WM, int WN, int TM, int TN, int NACC, int EPI>
 __global__ void __launch_bounds__(256)
 gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                  int M, int N, int K, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
@@ -239,6 +240,7 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
     constexpr int A_F4 = BM * GM_BK / 4 / 256, B_F4 = GM_BK * BN / 4 / 256;
     static_assert(WM * WN == 4 && A_F4 >= 1 && B_F4 >= 1, "tile shape");
     const int Mcap = M;
+    constexpr bool ROWS = (EPI & 1) != 0, RES = (EPI & 2) != 0;
     M = d3f_dyn(M, M_dev);
     if ((int)(blockIdx.z * BM) >= M) return;
     extern __shared__ __attribute__((aligned(16))) float gf_smem[];
@@ -379,8 +381,8 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
     // No load may sit between two stores: a conditional load inside the store loop makes the compiler drain the memory
     // counter (s_waitcnt vmcnt(0)) before every store, i.e. one HBM round trip per element.  So the per-column terms are
     // fetched up front, the per-row scale (ROWS: the KPConv neighbour-count division) once per tile row, every output value
-    // is finished (and pinned) before the first predicated store, and a residual operand (unused by the network since the
-    // shortcut moved into the contraction) is left to the generic kernel.
+    // is finished (and pinned) before the first predicated store; a residual operand (RES: the identity shortcut of the
+    // strided resnet blocks) is fetched as the four 16-byte pieces of a tile row before that tile's stores.
     float4 cs4[TN][4], ch4[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -399,7 +401,14 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
         if (ROWS && !slab) rs = E.row_scale[mok ? gm : M - 1];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float4 o[4];
+            float4 o[4], res[4];
+            if (RES && !slab) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gn = n0 + (wn * TN + j) * 32 + 8 * q + 4 * (lane >> 5);
+                    res[q] = (mok && gn < N) ? *(const float4*)&E.residual[(size_t)gm * E.ldr + gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4];
@@ -411,9 +420,11 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
                 if (!slab) {
                     const float c[4] = {cs4[j][q].x, cs4[j][q].y, cs4[j][q].z, cs4[j][q].w};
                     const float h4[4] = {ch4[j][q].x, ch4[j][q].y, ch4[j][q].z, ch4[j][q].w};
+                    const float r4[4] = {RES ? res[q].x : 0.f, RES ? res[q].y : 0.f, RES ? res[q].z : 0.f, RES ? res[q].w : 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = (ROWS ? v[e] * rs : v[e]) * c[e] + h4[e];
+                        if (RES) t += r4[e];
                         v[e] = (E.leaky && !(t > 0.f)) ? t * E.alpha : t;
                     }
                 }
@@ -757,34 +768,39 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
     dim3 grid(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm));
     // float4-addressable operands (every shape of the network): the straight-line kernel; anything else: the generic one
     static int fast_on = [] { const char* e = getenv("D3F_GEMM_FAST"); return e ? atoi(e) : 1; }();
-    const bool fast = fast_on && !E.residual && vecA && vecB && K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 &&
+    const bool fast = fast_on && (!E.residual || (E.ldr % 4 == 0 && ((uintptr_t)E.residual & 15) == 0)) && vecA && vecB &&
+                      K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 &&
                       (((uintptr_t)C | (uintptr_t)E.col_scale | (uintptr_t)E.col_shift) & 15) == 0 &&
                       (!G.A2 || (G.K1 % 4 == 0 && G.lda2 % 4 == 0 && ((uintptr_t)G.A2 & 15) == 0));
     if (fast) {
         const size_t lds = (size_t)2 * (bm + bn) * GF_S * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {   // the 128 x 128 tile needs 72 KB
-            if (hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)gemm_fast_kernel<2, 2, 2, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess)
-                return D3F_ERR_HIP;
+            const void* big[4] = {(const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 0>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 1>,
+                                  (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 2>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 3>};
+            for (int i = 0; i < 4; ++i)
+                if (hipFuncSetAttribute(big[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess)
+                    return D3F_ERR_HIP;
             attr_set = true;
         }
+#define D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, EPI_)                                                                     \
+    gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, EPI_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, \
+                                                                                M_dev, G)
 #define D3F_GEMM(WM_, WN_, TM_, TN_, NA_)                                                                              \
     do {                                                                                                               \
-        if (E.row_scale)                                                                                               \
-            gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, true><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, \
-                                                                                        slab, E, M_dev, G);           \
-        else                                                                                                           \
-            gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, false><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, \
-                                                                                         slab, E, M_dev, G);          \
+        const int epi = (E.row_scale ? 1 : 0) | (E.residual ? 2 : 0);                                                  \
+        if (epi == 0) D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, 0);                                                          \
+        else if (epi == 1) D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, 1);                                                     \
+        else if (epi == 2) D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, 2);                                                     \
+        else D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, 3);                                                                   \
     } while (0)
         if (bn == 32) D3F_GEMM(4, 1, 1, 1, 1);
         else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2, 1);
         else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1, 1);
         else D3F_GEMM(2, 2, 1, 1, 1);
 #undef D3F_GEMM
+#undef D3F_GEMM_E
     } else {
         if (bn != 32) { bm = 64; bn = 64; grid = dim3(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm)); }
 #define D3F_GEMM(WM_, WN_, TM_, TN_)                                                                                   \

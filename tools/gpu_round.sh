@@ -20,11 +20,11 @@ if [ "$TESTS" = "tests" ]; then
   tail -2 $OUT/smoke.log
 fi
 
-timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; tail -3 $OUT/bench.err
 
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 64 --warmup 8 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
 DB=$(ls $OUT/prof/*/*_results.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then python $REPO/tools/rocpd_summary.py $DB > $OUT/kernel_stats.csv; head -25 $OUT/kernel_stats.csv; fi
 
