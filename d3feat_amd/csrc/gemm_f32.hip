@@ -716,9 +716,11 @@ static int gemm_stream_blocks() {
 }
 static bool gemm_stream_ok(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const GemmGather& G,
                            int M_hint) {
-    // D3F_GEMM_STREAM: 0 never, 2 wherever it can run (tests), default 1 = where it was measured ahead of the tile kernel
-    // (tools/gemm_bench.py, MI355X): the finest level's contractions -- >= 64 k rows, K <= 128
-    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 1; }();
+    // D3F_GEMM_STREAM: 1 = where it was measured ahead of the tile kernel in isolation (tools/gemm_bench.py, MI355X: the
+    // finest level's contractions, >= 64 k rows, K <= 128: up to 30 % on 235 k x 32 x 128), 2 = wherever it can run (tests),
+    // default 0: end to end, with four replays in flight, the two kernels measured the same (1134 vs 1116 fragments/s), so
+    // production keeps the single tile kernel.
+    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 0; }();
     if (!on) return false;
     const int mexp = (M_hint > 0 && M_hint < M) ? M_hint : M;
     if (K < 16 || K > 256 || K % 16 != 0 || N % 32 != 0) return false;
