@@ -6,13 +6,17 @@
 // the resnet blocks (:368, :612):
 //   C[m,n] = act( acc[m,n] * row_scale[m] * col_scale[n] + col_shift[n] + residual[m,n] ),  acc = A @ B
 //
-// v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, 64 cycles, exact fp32: bitwise an fmaf chain in k order) --
-// the 1e-4 parity bar is an fp32 bar, so the contraction stays in fp32 on the MFMA pipe (157 TF peak).
-// 256-thread workgroup = 4 wavefronts, each owning TM x TN 32x32 accumulator tiles; workgroup tiles 128x128 (2x2 waves x
-// 2x2 tiles), 128x64, 64x64 or 128x32 (4x1 waves, for Cout <= 32), chosen per shape; BK = 32.  A and B tiles are staged through LDS (A rows padded to 33 floats:
-// the MFMA A fragment reads a column of the tile, 33 is odd so the 32 lanes hit 32 banks), next tile prefetched
-// into registers while the current one is multiplied.  Skinny problems (few output tiles, long K: the deep
-// KPConv layers) are split along K into slabs that a second kernel reduces in a fixed order (deterministic).
+// v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, 64 cycles per SIMD, exact fp32 products and sums) -- the 1e-4 parity bar
+// is an fp32 bar, so the contraction stays in fp32 on the MFMA pipe (157 TF peak).
+// Three kernels, one launcher (gemm_run):
+//   gemm_fast_kernel    the production tile kernel for float4-addressable operands (every shape of the network): 256-thread
+//                       workgroup = 4 wavefronts x (TM x TN) 32x32 accumulator tiles, BK = 32, double-buffered LDS, k-permuted
+//                       fragments read with ds_read_b128, transposed accumulators -> 16-byte stores, straight-line staging;
+//                       workgroup tile 64x64 (default), 128x32 (Cout <= 32), 128x64 / 128x128 (large problems, D3F_GEMM_FORCE);
+//   gemm_stream_kernel  opt-in (D3F_GEMM_STREAM) for many rows x shallow K: B slab resident in LDS, A global -> registers;
+//   gemm_f32_kernel     generic fallback (odd K / N / leading dimensions, unaligned bases): scalar tail handling.
+// Skinny problems (few output tiles, long K: the deep KPConv layers) are split along K into slabs that a second kernel
+// reduces in a fixed order (deterministic).
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
