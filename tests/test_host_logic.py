@@ -172,3 +172,31 @@ def test_stack_batch_inds_host_logic():
     assert a.shape == (2, 4) and a[0, -1] == 6 and a[1, 0] == 3
     b = onp.stack_batch_inds([4, 2])
     assert b.shape == (2, 4) and list(b[1]) == [4, 5, 6, 6]
+
+
+def test_kitti_bin_reader_and_result_files(tmp_path):
+    """Formats either side of the path: velodyne .bin in (datasets/KITTI.py:131), the tester's three .npy files out
+    (utils/tester.py:208-229: first cloud of the self-pair, ascending score)."""
+    from d3feat_amd.utils.results import read_kitti_bin, save_3dmatch_results, select_first_cloud
+    rng = np.random.default_rng(3)
+    sweep = rng.standard_normal((1000, 4)).astype(np.float32)
+    p = tmp_path / "000000.bin"
+    sweep.tofile(p)
+    xyz = read_kitti_bin(str(p))
+    assert xyz.dtype == np.float32 and xyz.flags["C_CONTIGUOUS"] and np.array_equal(xyz, sweep[:, :3])
+    (tmp_path / "bad.bin").write_bytes(b"\0" * 20)
+    with pytest.raises(ValueError):
+        read_kitti_bin(str(tmp_path / "bad.bin"))
+    n = 57
+    pts = rng.standard_normal((2 * n, 3)).astype(np.float32)
+    desc = rng.standard_normal((2 * n, 32)).astype(np.float32)
+    score = rng.random((2 * n, 1)).astype(np.float32)
+    kp, ft, sc = select_first_cloud(pts, desc, score, n)
+    order = np.argsort(score[:n], axis=0).squeeze()                     # the reference's own expression (tester.py:209)
+    assert np.array_equal(sc, score[order]) and np.array_equal(kp, pts[order]) and np.array_equal(ft, desc[order])
+    assert np.all(np.diff(sc[:, 0]) >= 0)
+    paths = save_3dmatch_results(str(tmp_path / "out"), b"7-scenes-redkitchen/seq-01/cloud_bin_12.ply", pts, desc, score, n)
+    assert [os.path.relpath(q, str(tmp_path / "out")) for q in paths] == [
+        "descriptors/7-scenes-redkitchen/cloud_bin_12.D3Feat.npy", "keypoints/7-scenes-redkitchen/cloud_bin_12.npy",
+        "scores/7-scenes-redkitchen/cloud_bin_12.npy"]
+    assert np.array_equal(np.load(paths[0]), ft) and np.array_equal(np.load(paths[1]), kp) and np.array_equal(np.load(paths[2]), sc)
