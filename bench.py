@@ -328,7 +328,9 @@ def main():
         # `--pmc WRITE_SIZE` passes of this same command (tools/gpu_round.sh -> tools/pmc_summary.py, corrections of
         # MI355X_MICROARCH.md §HBM applied there); launch-weighted mean over the template instantiations of the kernel.
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+        import re
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
+                       key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])  # v10 after v9
         if cands:
             try:
                 tj = json.load(open(cands[-1]))
