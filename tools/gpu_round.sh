@@ -24,13 +24,13 @@ timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; tail -3 $OUT/bench.err
 
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 64 --warmup 8 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-instrument --no-mirror-extra --no-pcie-extra > $OUT/prof_bench.json 2> $OUT/prof.err
 DB=$(ls $OUT/prof/*/*_results.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then python $REPO/tools/rocpd_summary.py $DB > $OUT/kernel_stats.csv; head -25 $OUT/kernel_stats.csv; fi
 
 if [ "$PMC" = "pmc" ]; then
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 --no-cpu-baseline --no-instrument --no-mirror-extra --no-pcie-extra > /dev/null 2> $OUT/pmc_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 16 --warmup 1 --no-cpu-baseline --no-instrument --no-mirror-extra --no-pcie-extra > /dev/null 2> $OUT/pmc_write.err
   python $REPO/tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json 2> $OUT/pmc_summary.err
   head -c 1500 $OUT/hbm_traffic.json
   # keep the merged output small: the raw per-dispatch CSVs are large
