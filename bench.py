@@ -6,21 +6,28 @@ sess.run plus the stage-0 voxelisation:
     raw cloud (300k pts, resident in HBM) -> grid subsample @0.03 m (~30k pts) -> stacked with itself (the
     reference's test generators feed every fragment as a self-pair, datasets/ThreeDMatch.py:190-192) ->
     5-level pyramid (13 radius searches + 4 grid subsamplings) -> KPFCNN forward (10 KPConv + 28 unary) ->
-    32-d descriptors + detection scores in HBM.
+    32-d descriptors + detection scores in HBM, kept as one [xyz | desc | score] record block per fragment.
 Multi-GPU: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...; fragments are sharded across
-ranks (weak scaling: K fragments per rank) and the last fragment's (xyz, desc, score) of every rank is
-all-gathered over RCCL once at the end of the timed region.
+ranks (weak scaling: K fragments per rank); every rank keeps its WHOLE shard's records in HBM and the shards are
+all-gathered over RCCL once at the end of the timed region (the path's only data collective).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel (largest share of GPU time among the timed launches), HIP-event timed on the
+  parity        the engine's output (same F, slots, graph path as the timed region) for the fragments the CPU leg pushes
+                through the oracle: points / level-0 neighbour indices bit-equal, descriptors / scores max |diff|;
+                the process exits non-zero (after printing the line) when a bound is exceeded;
+  roofline      the dominant kernel family (largest share of GPU time among the timed launches), HIP-event timed on the
                 launch stream in a separate instrumented pass over the same fragments;
+  rooflines     the same for every timed kernel family (HBM GB/s of the gather kernels, TFLOP/s of the contractions);
   kpconv_layers ms per KPConv layer (aggregation + contraction kernels);
   cpu_baseline  the same step on the host: reference C++ (oracle/_ref, 1 thread) when available, else the C
                 restatement, for the geometry; torch-CPU restatement of the TF graph for the network (N=1 only).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -35,6 +42,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+PARITY_TOL = 1e-4          # BASELINE.json north_star: descriptors and scores within 1e-4 (absolute), indices bit-exact
 
 
 def parse():
@@ -42,8 +50,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-fragments", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and with it the parity check)")
+    ap.add_argument("--cpu-fragments", type=int, default=5, help="fragments of the CPU / parity sample")
+    ap.add_argument("--no-cpu-1thread", action="store_true", help="skip the 1-thread network row of the CPU baseline")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
     ap.add_argument("--slots", type=int, default=4, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
     ap.add_argument("--batch", type=int, default=4,
@@ -60,32 +69,47 @@ def parse():
 
 
 class Step:
-    """The hot path for one fragment."""
+    """The hot path for one fragment, op by op (instrumented pass, --eager)."""
 
     def __init__(self, cfg, model, limits, device):
         from d3feat_amd.datasets.common import FragmentDataset
         self.cfg, self.model, self.device = cfg, model, device
         self.ds = FragmentDataset([], fast=True)
         self.ds.neighborhood_limits = limits
+        self.ds.stack_group = 2
         self.map = self.ds.get_tf_mapping(cfg)
 
     def __call__(self, raw_dev):
         """raw_dev: one raw cloud, or a list of F raw clouds stacked [c_1; c_1; c_2; c_2; ...] like FragmentEngine(batch=F)."""
         import torch
+        from d3feat_amd import ops
         from d3feat_amd import tf_custom_ops as tfo
-        from d3feat_amd.ops import as_lens as ops_as_lens
         raws = raw_dev if isinstance(raw_dev, list) else [raw_dev]
         subs = [tfo.grid_subsampling(r, self.cfg.first_subsampling_dl) for r in raws]       # stage 0
         pts = torch.cat([x for s in subs for x in (s, s)], 0)                                # self-pairs (device copies)
-        lens = ops_as_lens([int(s.shape[0]) for s in subs for _ in (0, 1)], self.device)
+        lens = ops.as_lens([int(s.shape[0]) for s in subs for _ in (0, 1)], self.device)
         flat = self.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
-        return pts, desc, score
+        return ops.pack_descriptors(pts, desc, score)
 
 
 def kpconv_alg_bytes(Nq, Ns, K, Cin, Cout):
     """algorithmic bytes of one KPConv layer."""
     return 4 * (3 * Nq + 3 * Ns + Nq * K + Ns * Cin + 45 + 15 * Cin * Cout + Nq * Cout)
+
+
+def kpconv_flops(Nq, K, Cin, Cout):
+    """flops_gemm + flops_agg of one KPConv layer."""
+    return 2.0 * Nq * 15 * Cin * Cout, 2.0 * Nq * 15 * K * Cin + 11.0 * Nq * K * 15
+
+
+def source_hash():
+    """sha256 over the kernel sources: ties a committed counter file (tools/pmc_summary.py stamps it) to the code it measured."""
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "d3feat_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -100,8 +124,9 @@ def main():
             print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=device)
 
     from d3feat_amd import ops, parallel
@@ -114,10 +139,14 @@ def main():
 
     cfg = threedmatch_config()
     W = build_variables(cfg, seed=42).values
-    # synthetic fragments of this rank, raw points resident in HBM before timing starts
-    seeds = [rank * 1000 + i for i in range(args.pool)]
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    # synthetic fragments of this rank, raw points resident in HBM before timing starts; the first `pool` are cycled through
+    # the timed region, the first `cpu_fragments` form the CPU / parity sample
+    nfr = max(args.pool, args.cpu_fragments if do_cpu else 0)
+    seeds = [rank * 1000 + i for i in range(nfr)]
     raws_host = [room_fragment(s, n_raw=args.raw_points, edge=args.edge) for s in seeds]
-    raws = [torch.from_numpy(r).to(device) for r in raws_host]
+    raws_all = [torch.from_numpy(r).to(device) for r in raws_host]
+    raws = raws_all[: args.pool]
 
     # neighbourhood limits: calibrated like init_test_input_pipeline on this rank's pool, histograms summed over ranks
     subs = [tfo.grid_subsampling(r, cfg.first_subsampling_dl).cpu().numpy() for r in raws]
@@ -139,56 +168,68 @@ def main():
             torch.cuda.synchronize(device)
 
     engine = None
+    n0_max = max(len(x) for x in subs)
     if not args.eager:
         # the fragment engine: whole fragment = one replayed HIP graph with device-resident sizes, `slots` in flight
         from d3feat_amd.engine import FragmentEngine
-        raw_cap = int(max(r.shape[0] for r in raws) * 1.05) + 1024
-        n0_cap = (int(max(len(x) for x in subs) * 1.3) + 1023) // 1024 * 1024
+        raw_cap = int(max(r.shape[0] for r in raws_all) * 1.05) + 1024
+        n0_cap = (int(n0_max * 1.3) + 1023) // 1024 * 1024
         engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, slots=args.slots, device=device,
                                 n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
                                 batch=args.batch)
+    # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
+    shard = parallel.ShardCollector(rows_cap=(args.steps + 8) * 2 * int(n0_max * 1.02 + 64), width=36, device=device)
 
-    def run(nsteps, engine=engine):
-        """nsteps fragments through the hot path; returns the last fragment's (pts, desc, score)."""
-        out = None
+    def run(nsteps, engine=engine, collect=None, pool=raws):
+        """nsteps fragments through the hot path; every fragment's record block goes to `collect` (ShardCollector)."""
         if engine is None:
             for i in range(nsteps):
-                out = step(raws[i % len(raws)])
-            return out
+                rec = step(pool[i % len(pool)])
+                if collect is not None:
+                    collect.add(rec)
+            return
         S, F = len(engine.slots), engine.F
         busy = [False] * S
+
+        def drain(sl):
+            for rec in engine.fetch(sl, packed=True):
+                if collect is not None:
+                    collect.add(rec)
+            busy[sl] = False
         i = k = 0
         while i < nsteps:                        # replays of up to F fragments each, round-robin over the slots
             sl = k % S
             if busy[sl]:
-                out = engine.fetch(sl)[-1]
+                drain(sl)
             nb = min(F, nsteps - i)
-            engine.submit(sl, [raws[(i + j) % len(raws)] for j in range(nb)])
+            engine.submit(sl, [pool[(i + j) % len(pool)] for j in range(nb)])
             busy[sl] = True
             i += nb
             k += 1
         for kk in range(k, k + S):               # drain in submission order
-            sl = kk % S
-            if busy[sl]:
-                out = engine.fetch(sl)[-1]
-                busy[sl] = False
-        return out
+            if busy[kk % S]:
+                drain(kk % S)
 
     # at least W untimed steps; with the engine, enough of them to replay every slot's graph once
-    out = run(max(args.warmup, (args.slots * args.batch) if engine is not None else 0))
-    if world > 1 and out is not None:
-        parallel.gather_descriptors(*out)
+    run(max(args.warmup, (args.slots * args.batch) if engine is not None else 0), collect=shard)
+    if world > 1:
+        shard.gather()
+    shard.reset()
     sync()
     t0 = time.perf_counter()
-    out = run(args.steps)
-    gathered = parallel.gather_descriptors(*out)
+    run(args.steps, collect=shard)
+    gathered = shard.gather()
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    npts = int(out[0].shape[0] // 2)
+    npts = int(np.mean(shard.frag_rows)) // 2
+    gathered_rows = [int(g[0].shape[0]) for g in gathered]
+    gathered_frags = [len(g[1]) for g in gathered]
+    del gathered
+    shard.reset()
 
     # ---- secondary number (N = 1): PCIe-inclusive -- raw fragments start in pinned HOST memory, results end there -------
     pcie = None
@@ -197,16 +238,11 @@ def main():
             hraws = [r.cpu().pin_memory() for r in raws]
             S, F = len(engine.slots), engine.F
             cap_rows = 2 * engine.n0_cap
-            hout = [[(torch.empty((cap_rows, 3), dtype=torch.float32).pin_memory(),
-                      torch.empty((cap_rows, 32), dtype=torch.float32).pin_memory(),
-                      torch.empty((cap_rows, 1), dtype=torch.float32).pin_memory()) for _ in range(F)] for _ in range(S)]
+            hout = [[torch.empty((cap_rows, 36), dtype=torch.float32).pin_memory() for _ in range(F)] for _ in range(S)]
 
-            def drain(sl):
-                for j, (p, d, sc) in enumerate(engine.fetch(sl)):      # device views -> pinned host, asynchronously
-                    n = p.shape[0]
-                    hout[sl][j][0][:n].copy_(p, non_blocking=True)
-                    hout[sl][j][1][:n].copy_(d, non_blocking=True)
-                    hout[sl][j][2][:n].copy_(sc, non_blocking=True)
+            def drain_host(sl):
+                for j, rec in enumerate(engine.fetch(sl, packed=True)):   # device views -> pinned host, asynchronously
+                    hout[sl][j][: rec.shape[0]].copy_(rec, non_blocking=True)
 
             def run_host(nsteps):
                 busy = [False] * S
@@ -214,7 +250,7 @@ def main():
                 while i < nsteps:
                     sl = k % S
                     if busy[sl]:
-                        drain(sl)
+                        drain_host(sl)
                     nb = min(F, nsteps - i)
                     engine.submit(sl, [hraws[(i + j) % len(hraws)] for j in range(nb)])
                     busy[sl] = True
@@ -222,7 +258,7 @@ def main():
                     k += 1
                 for kk in range(k, k + S):
                     if busy[kk % S]:
-                        drain(kk % S)
+                        drain_host(kk % S)
                         busy[kk % S] = False
 
             run_host(S * F)
@@ -234,7 +270,7 @@ def main():
             pcie = {"value": round(args.steps / dt3, 3), "unit": "fragments/s", "ms_per_step": round(dt3 / args.steps * 1e3, 4),
                     "h2d_bytes_per_fragment": int(np.mean([r.shape[0] for r in raws]) * 12),
                     "d2h_bytes_per_fragment": int(2 * npts * 36 * 4),
-                    "note": "NOT the headline: raw clouds read from pinned host memory, points / descriptors / scores copied back "
+                    "note": "NOT the headline: raw clouds read from pinned host memory, the record blocks copied back "
                             "to pinned host memory, copies on the slot streams overlapped with the other replays"}
         except Exception as exc:  # the secondary number must never cost the headline line
             pcie = {"error": repr(exc)[:200]}
@@ -259,113 +295,16 @@ def main():
         del eng2
 
     # ---- instrumented pass (untimed): per-launch HIP events on the launch stream --------------------------------
-    layers, roof = None, None
+    layers = roof = roofs = None
     if rank == 0 and not args.no_instrument:
-        # same stack shape as the timed region: F fragments per pass (op by op instead of a replayed graph, because HIP
-        # events cannot be placed between the nodes of a graph)
         Fp = engine.F if engine is not None else 1
-        npass = max(2, min(args.steps, 8) // Fp)
-        nprof = npass * Fp                      # fragments covered
-        ops.PROFILE = []
-        for i in range(npass):
-            ops.PROFILE.append(("step", {}, None, None))
-            step([raws[(i * Fp + j) % len(raws)] for j in range(Fp)] if Fp > 1 else raws[i % len(raws)])
-        torch.cuda.synchronize(device)
-        recs, ops.PROFILE = ops.PROFILE, None
-        fam = {}      # kernel family -> totals over the instrumented pass
-        per_step_agg, per_step_gemm = [], []
-        for name, info, s, e in recs:
-            if name == "step":
-                per_step_agg.append([])
-                per_step_gemm.append([])
-                continue
-            ms = s.elapsed_time(e)
-            if name == "kpconv_aggregate":
-                key = "kpconv_agg_vec4<Cin=%d>" % info["Cin"] if info["Cin"] % 4 == 0 else "kpconv_agg_scalar<Cin=%d>" % info["Cin"]
-                # every KPConv of the shipped architecture has Cout == Cin except the first (1 -> 64)
-                cout = info["Cin"] if info["Cin"] > 1 else cfg.first_features_dim
-                nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], info["Cin"], cout), 0.0
-                per_step_agg[-1].append((info, ms))
-            elif name == "kpconv_fused_c1":
-                key = "kpconv_c1_fused_kernel"
-                nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], 1, info["Cout"]), 0.0
-                per_step_agg[-1].append((info, ms))
-            elif name == "kpconv_fused32":
-                key = "kpconv_fused32_kernel"
-                nbytes, flops = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], 32, 32), 0.0
-                per_step_agg[-1].append((info, ms))
-            elif name == "gemm_f32":
-                key = "gemm_fast_kernel"       # the contraction family: tile kernel (+ streaming / split-K reduce kernels)
-                nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
-                flops = 2.0 * info["M"] * info["N"] * info["K"]
-                per_step_gemm[-1].append((info, ms))
-            else:  # nb_search: SURVEY §8(d) bytes_alg = 12*(Nq+Ns) + 4*Nq*K_out
-                key = "nb_search_kernel<first_only=%d>" % info["first_only"]
-                nbytes, flops = 12.0 * (info["Nq"] + info["Ns"]) + 4.0 * info["Nq"] * (1 if info["first_only"] else info["width"]), 0.0
-            f = fam.setdefault(key, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
-            f["ms"] += ms
-            f["launches"] += 1
-            f["bytes"] += nbytes
-            f["flops"] += flops
-        dom_name = max(fam, key=lambda k: fam[k]["ms"])
-        dom = fam[dom_name]
-        avg_ms = dom["ms"] / dom["launches"]
-        if dom_name.startswith("gemm"):
-            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            roof = dict(kernel=dom_name, bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=round(ach / MFMA_F32_PEAK_TF, 5), traffic=None,
-                        alg_flops_per_launch=int(dom["flops"] / dom["launches"]))
-        else:
-            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            roof = dict(kernel=dom_name, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                        alg_bytes_per_launch=int(dom["bytes"] / dom["launches"]))
-        roof["avg_launch_us"] = round(avg_ms * 1e3, 2)
-        roof["launches_per_step"] = round(dom["launches"] / nprof, 2)
-        roof["fragments_per_launch"] = Fp
-        roof["timed_kernels_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in sorted(fam.items())}
-        # HBM traffic per launch of the dominant kernel: from the newest committed pair of `rocprofv3 --pmc FETCH_SIZE` /
-        # `--pmc WRITE_SIZE` passes of this same command (tools/gpu_round.sh -> tools/pmc_summary.py, corrections of
-        # MI355X_MICROARCH.md §HBM applied there); launch-weighted mean over the template instantiations of the kernel.
-        import glob
-        import re
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
-                       key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])  # v10 after v9
-        if cands:
-            try:
-                tj = json.load(open(cands[-1]))
-                fam_names = (("gemm_fast_kernel", "gemm_stream_kernel", "gemm_f32_kernel") if dom_name.startswith("gemm")
-                             else (dom_name.split("<")[0],))
-                ent = [v for k, v in tj.items() if k.split("<")[0] in fam_names and "traffic_bytes_per_launch" in v]
-                nl = sum(e["launches"] for e in ent)
-                if nl:
-                    roof["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl)
-                    roof["traffic_source"] = os.path.basename(cands[-1])
-            except Exception:
-                pass
-        # ms per KPConv layer (call order inside a step = network order): aggregation + its contraction
-        nl = len(per_step_agg[0])
-        layers = []
-        for li in range(nl):
-            infos = [st[li][0] for st in per_step_agg]
-            agg_ms = float(np.mean([st[li][1] for st in per_step_agg]))
-            gem = []
-            for st_a, st_g in zip(per_step_agg, per_step_gemm):
-                d = st_a[li][0]
-                cand = [m for (g, m) in st_g if g["M"] == d["Nq"] and g["K"] == cfg.num_kernel_points * d["Cin"]]
-                if cand:
-                    gem.append(cand[0] if len(cand) == 1 or li % 2 == 0 or True else cand[-1])
-            layers.append(dict(layer=li, Nq=int(np.mean([d["Nq"] for d in infos])), Ns=int(np.mean([d["Ns"] for d in infos])),
-                               K=infos[0]["K"], Cin=infos[0]["Cin"], agg_ms=round(agg_ms, 4),
-                               gemm_ms=round(float(np.mean(gem)), 4) if gem else None,
-                               total_ms=round(agg_ms + (float(np.mean(gem)) if gem else 0.0), 4),
-                               fragments_per_launch=Fp,
-                               total_ms_per_fragment=round((agg_ms + (float(np.mean(gem)) if gem else 0.0)) / Fp, 4)))
+        roof, roofs, layers = instrumented_pass(cfg, step, raws, Fp, max(2, min(args.steps, 8) // Fp), device)
 
-    # ---- CPU baseline (rank 0, N=1) -------------------------------------------------------------------------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, W, limits, raws_host[: max(1, args.cpu_fragments)])
+    # ---- CPU baseline + parity at the benchmarked configuration (rank 0, N=1) ---------------------------------------------
+    cpu = parity = None
+    if do_cpu:
+        cpu, refs = cpu_baseline(cfg, W, limits, raws_host[: max(1, args.cpu_fragments)], one_thread=not args.no_cpu_1thread)
+        parity = parity_check(cfg, engine, step, raws_all[: len(refs)], refs, device)
 
     if rank == 0:
         res = {
@@ -377,66 +316,265 @@ def main():
                                    "weights, 14.1M params) -> 32-d descriptors + scores" % round(npts / 1000),
                        "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
                        "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
-                       "final_gather_ranks": len(gathered),
+                       "final_gather": {"ranks": len(gathered_rows), "fragments_per_rank": gathered_frags,
+                                        "rows_per_rank": gathered_rows, "bytes_per_rank": [r * 144 for r in gathered_rows],
+                                        "what": "every rank's whole shard of [xyz | desc | score] records (144 B/point), "
+                                                "one padded all_gather inside the timed region"},
                        "execution": ("eager op-by-op launches" if engine is None else
                                      "HIP-graph replay of %d stacked fragment(s), device-resident sizes, %d replays in flight%s"
                                      % (engine.F, len(engine.slots),
                                         "; self-pair computed once and mirrored" if args.mirror else "")),
                        "fragments_per_replay": (engine.F if engine is not None else 1),
                        "engine_fallbacks": (engine.fallbacks if engine is not None else None)},
-            "roofline": roof, "kpconv_layers_ms": layers, "cpu_baseline": cpu, "mirror_self_pair": mirror_extra, "pcie_inclusive": pcie,
+            "parity": parity, "roofline": roof, "rooflines": roofs, "kpconv_layers_ms": layers, "cpu_baseline": cpu,
+            "mirror_self_pair": mirror_extra, "pcie_inclusive": pcie,
         }
         if cpu:
             res["vs_cpu_baseline"] = round(res["value"] / cpu["value"], 2)
         print(json.dumps(res))
-    if world > 1:
+        sys.stdout.flush()
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        print("PARITY FAILURE at the benchmarked configuration: %s" % json.dumps(parity), file=sys.stderr)
+        sys.exit(3)
 
 
-def cpu_baseline(cfg, W, limits, raws_host):
-    """The same step on the host cores of this box (reported baseline, not the target)."""
+# ---------------------------------------------------------------------------------------------------------------------
+def instrumented_pass(cfg, step, raws, Fp, npass, device):
+    """Same stack shape as the timed region: F fragments per pass, op by op instead of a replayed graph (HIP events cannot
+    be placed between the nodes of a graph).  -> (dominant-family roofline, all families, per-KPConv-layer table)."""
     import torch
-    from oracle import clib, network_np as onp
+    from d3feat_amd import ops
+    nprof = npass * Fp                      # fragments covered
+    ops.PROFILE = []
+    for i in range(npass):
+        ops.PROFILE.append(("step", {}, None, None))
+        step([raws[(i * Fp + j) % len(raws)] for j in range(Fp)] if Fp > 1 else raws[i % len(raws)])
+    torch.cuda.synchronize(device)
+    recs, ops.PROFILE = ops.PROFILE, None
+    fam = {}      # kernel family -> totals over the instrumented pass
+    per_step_agg, per_step_gemm = [], []
+    for name, info, s, e in recs:
+        if name == "step":
+            per_step_agg.append([])
+            per_step_gemm.append([])
+            continue
+        ms = s.elapsed_time(e)
+        flops = 0.0
+        if name == "kpconv_aggregate":
+            key = "kpconv_agg_vec4<Cin=%d>" % info["Cin"] if info["Cin"] % 4 == 0 else "kpconv_agg_scalar<Cin=%d>" % info["Cin"]
+            # every KPConv of the shipped architecture has Cout == Cin except the first (1 -> 64); the contraction of this
+            # layer is a separate gemm_f32 record, so only the aggregation flops count here
+            cout = info["Cin"] if info["Cin"] > 1 else cfg.first_features_dim
+            nbytes = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], info["Cin"], cout)
+            flops = kpconv_flops(info["Nq"], info["K"], info["Cin"], cout)[1]
+            per_step_agg[-1].append((info, ms))
+        elif name in ("kpconv_fused_c1", "kpconv_fused32", "kpconv_fused"):
+            cin, cout = info["Cin"], info["Cout"]
+            key = {"kpconv_fused_c1": "kpconv_c1_kp_kernel", "kpconv_fused32": "kpconv_fused32_kernel"}.get(
+                name, "kpconv_fused_kernel<Cin=%d>" % cin)
+            nbytes = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], cin, cout)
+            flops = sum(kpconv_flops(info["Nq"], info["K"], cin, cout))
+            info = dict(info, fused=True)
+            per_step_agg[-1].append((info, ms))
+        elif name == "gemm_f32":
+            key = "gemm_fast_kernel"       # the contraction family: tile kernel (+ streaming / split-K reduce kernels)
+            nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
+            flops = 2.0 * info["M"] * info["N"] * info["K"]
+            per_step_gemm[-1].append((info, ms))
+        elif name == "nb_search":  # SURVEY §8(d) bytes_alg = 12*(Nq+Ns) + 4*Nq*K_out
+            key = "nb_search_kernel<first_only=%d>" % info["first_only"]
+            nbytes = 12.0 * (info["Nq"] + info["Ns"]) + 4.0 * info["Nq"] * (1 if info["first_only"] else info["width"])
+        elif name == "nb_grid_build":   # read the supports, write the cell-sorted float4 copy + the index permutation
+            key = "nb_grid_build (5 launches)"
+            nbytes = (12.0 + 16.0 + 4.0) * info["Ns"]
+        elif name == "grid_subsample":  # SURVEY §8(d): 12 N + 12 M
+            key = "grid_subsample (9 + 3 rounds launches)"
+            nbytes = 12.0 * info["N"] + 12.0 * (info["M"] or 0)
+        elif name == "ind_max_pool":    # index matrix + every finer-level row once + the pooled rows
+            key = "maxpool_kernel"
+            nbytes = 4.0 * (info["N2"] * info["K"] + info["N1"] * info["C"] + info["N2"] * info["C"])
+        elif name == "detect_head":     # index matrix + last_unary output read once + descriptors and scores written
+            key = "head32_kernel (+ per-cloud max)"
+            nbytes = 4.0 * (info["N"] * info["K"] + 2 * info["N"] * info["C"] + info["N"])
+        else:
+            continue
+        f = fam.setdefault(key, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+        f["ms"] += ms
+        f["launches"] += 1
+        f["bytes"] += nbytes
+        f["flops"] += flops
+
+    traffic, traffic_src, traffic_stale = load_traffic()
+
+    def describe(name):
+        d = fam[name]
+        avg_ms = d["ms"] / d["launches"]
+        if name.startswith("gemm"):
+            ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            r = dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                     frac=round(ach / MFMA_F32_PEAK_TF, 5), traffic=None, alg_flops_per_launch=int(d["flops"] / d["launches"]))
+        else:
+            ach = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+            r = dict(kernel=name, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, alg_bytes_per_launch=int(d["bytes"] / d["launches"]))
+            if d["flops"]:
+                r["tflops"] = round(d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12, 3)
+        r["avg_launch_us"] = round(avg_ms * 1e3, 2)
+        r["launches_per_step"] = round(d["launches"] / nprof, 2)
+        r["ms_per_step"] = round(d["ms"] / nprof, 4)
+        r["fragments_per_launch"] = Fp
+        # HBM traffic per launch: from the newest committed pair of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
+        # of this same command (tools/gpu_round.sh -> tools/pmc_summary.py, corrections of MI355X_MICROARCH.md §HBM applied
+        # there); launch-weighted mean over the template instantiations of the kernel.  `traffic_stale`: the counter file was
+        # collected for different kernel sources than the ones running now.
+        if traffic is not None:
+            base = name.split("<")[0].split(" ")[0]
+            names = ("gemm_fast_kernel", "gemm_stream_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
+            ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
+                   and "traffic_bytes_per_launch" in v]
+            nl = sum(e["launches"] for e in ent)
+            if nl:
+                r["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl)
+                r["traffic_source"] = traffic_src
+                r["traffic_stale"] = traffic_stale
+        return r
+
+    order = sorted(fam, key=lambda k: -fam[k]["ms"])
+    roofs = [describe(k) for k in order]
+    roof = dict(roofs[0])
+    roof["timed_kernels_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in sorted(fam.items())}
+    roof["timing"] = "HIP events around each launch in an op-by-op pass over the same stacked shapes (not inside the replayed graph)"
+    # ms per KPConv layer (call order inside a step = network order): aggregation + its contraction
+    nl = len(per_step_agg[0])
+    layers = []
+    for li in range(nl):
+        infos = [st[li][0] for st in per_step_agg]
+        agg_ms = float(np.mean([st[li][1] for st in per_step_agg]))
+        gem = []
+        if not infos[0].get("fused") and infos[0]["Cin"] > 1:
+            for st_a, st_g in zip(per_step_agg, per_step_gemm):
+                d = st_a[li][0]
+                cand = [m for (g, m) in st_g if g["M"] == d["Nq"] and g["K"] == cfg.num_kernel_points * d["Cin"]]
+                if cand:
+                    gem.append(cand[0])
+        g_ms = float(np.mean(gem)) if gem else 0.0
+        layers.append(dict(layer=li, Nq=int(np.mean([d["Nq"] for d in infos])), Ns=int(np.mean([d["Ns"] for d in infos])),
+                           K=infos[0]["K"], Cin=infos[0]["Cin"], fused=bool(infos[0].get("fused")), agg_ms=round(agg_ms, 4),
+                           gemm_ms=round(g_ms, 4) if gem else None, total_ms=round(agg_ms + g_ms, 4),
+                           fragments_per_launch=Fp, total_ms_per_fragment=round((agg_ms + g_ms) / Fp, 4)))
+    return roof, roofs, layers
+
+
+def load_traffic():
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
+                   key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])  # v10 after v9
+    if not cands:
+        return None, None, None
+    try:
+        tj = json.load(open(cands[-1]))
+    except Exception:
+        return None, None, None
+    return tj, os.path.basename(cands[-1]), tj.get("__source_hash__") != source_hash()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, W, limits, raws_host, one_thread=True):
+    """The same step on the host cores of this box (reported baseline, not the target).  Geometry: the reference's own
+    C++ (oracle/_ref) on 1 thread (the reference ops are single-threaded and test_3dmatch.py:55 uses one input thread).
+    Network: the torch-CPU restatement of the TF graph on every core, and once on 1 thread.  -> (object, references)."""
+    import torch
+    from oracle import clib, parity as par
     use_ref = clib.ref_available()
     co = clib.COracle()
     rl = clib.RefLib() if use_ref else None
-    nthreads = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(nthreads)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    nthreads = torch.get_num_threads()
+    par.fragment_reference(cfg, W, raws_host[0], limits, co=co, rl=rl)     # warm-up (page-in, thread pools)
+    refs = [par.fragment_reference(cfg, W, r, limits, co=co, rl=rl) for r in raws_host]
+    pre = np.asarray([r["t_geometry"] for r in refs])
+    net = np.asarray([r["t_network"] for r in refs])
+    tot = pre + net
 
-    def nbr(q, s, ql, sl, r):
-        return rl.batch_nanoflann_neighbors(q, s, ql, sl, r) if use_ref else co.batch_neighbors(q, s, ql, sl, r)
+    def stats(a):
+        return {"median": round(float(np.median(a)), 4), "p10": round(float(np.percentile(a, 10)), 4),
+                "p90": round(float(np.percentile(a, 90)), 4), "n": int(len(a))}
+    net1 = None
+    if one_thread:
+        from oracle import network_np as onp
+        torch.set_num_threads(1)
+        t = time.perf_counter()
+        onp.forward(cfg, W, refs[0]["inp"])
+        net1 = time.perf_counter() - t
+        torch.set_num_threads(ncores)
+    out = {"value": round(float(len(refs) / tot.sum()), 4), "unit": "fragments/s", "cores": nthreads,
+           "host_cores": ncores,
+           # geometry = the reference's own C++ (oracle/_ref) when available; the network half has no runnable reference
+           # (TensorFlow 1 is not installable here), it is the torch-CPU restatement -> "port" for the sum
+           "kind": "port", "geometry_kind": "reference" if use_ref else "port",
+           "sample": "%d fragment(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
+                     "thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads (box: %d cores): "
+                     "%.3f s/fragment" % (len(refs), "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
+                                          float(pre.mean()), nthreads, ncores, float(net.mean())),
+           "geometry_s": stats(pre), "network_s": stats(net), "fragment_s": stats(tot),
+           "network_1thread_s": round(net1, 3) if net1 is not None else None,
+           "value_1thread": round(1.0 / (float(np.median(pre)) + net1), 4) if net1 is not None else None}
+    return out, refs
 
-    def sub(p, l, dl):
-        return rl.batch_grid_subsampling(p, l, dl) if use_ref else co.batch_grid_subsampling(p, l, dl)
 
-    def one(raw):
-        t = [time.perf_counter()]
-        s0 = rl.grid_subsampling(raw, cfg.first_subsampling_dl) if use_ref else co.grid_subsampling(raw, cfg.first_subsampling_dl)
-        pts = np.concatenate([s0, s0])
-        lens = np.asarray([len(s0)] * 2, np.int32)
-        inp = onp.descriptor_input(cfg, pts, np.ones((len(pts), 1), np.float32), lens, limits, nbr, sub)
-        t.append(time.perf_counter())
-        onp.forward(cfg, W, inp)
-        t.append(time.perf_counter())
-        return t[1] - t[0], t[2] - t[1]
+def parity_check(cfg, engine, step, raws_dev, refs, device):
+    """The CPU sample's fragments through the SAME execution the timed region used (engine: F fragments per replay, all
+    slots, graph path), compared with the oracle results the CPU leg just produced."""
+    import torch
+    from oracle import parity as par
+    n = len(refs)
+    worst = dict(points_equal=True, idx_equal=True, desc_max_abs=0.0, score_max_abs=0.0)
 
-    one(raws_host[0])  # warm-up (page-in, thread pools)
-    pre, net = [], []
-    for r in raws_host:
-        a, b = one(r)
-        pre.append(a)
-        net.append(b)
-    tot = float(np.sum(pre) + np.sum(net))
-    return {"value": round(len(raws_host) / tot, 4), "unit": "fragments/s", "cores": nthreads,
-            # geometry = the reference's own C++ (oracle/_ref) when available; the network half has no runnable reference
-            # (TensorFlow 1 is not installable here), it is the torch-CPU restatement -> "port" for the sum
-            "kind": "port", "geometry_kind": "reference" if use_ref else "port",
-            "sample": "%d fragment(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
-                      "thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads: %.3f s/fragment"
-                      % (len(raws_host), "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
-                         float(np.mean(pre)), nthreads, float(np.mean(net))),
-            "geometry_s": round(float(np.mean(pre)), 4), "network_s": round(float(np.mean(net)), 4)}
+    def fold(c):
+        worst["points_equal"] &= c["points_equal"]
+        worst["idx_equal"] &= c.get("idx_equal", True)
+        worst["desc_max_abs"] = max(worst["desc_max_abs"], c["desc_max_abs"])
+        worst["score_max_abs"] = max(worst["score_max_abs"], c["score_max_abs"])
+    if engine is None:
+        for raw, ref in zip(raws_dev, refs):
+            rec = step(raw).cpu().numpy()
+            fold(par.compare_fragment(ref, rec[:, :3], rec[:, 3:35], rec[:, 35:36]))
+        how = "eager op-by-op path"
+    else:
+        S, F = len(engine.slots), engine.F
+        i = 0
+        while i < n:                              # one wave of up to S replays in flight, like the timed loop
+            wave = []
+            for sl in range(S):
+                if i >= n:
+                    break
+                nb = min(F, n - i)
+                engine.submit(sl, raws_dev[i:i + nb])
+                wave.append((sl, i, nb))
+                i += nb
+            for sl, i0, nb in wave:
+                fb0 = engine.fallbacks
+                outs = engine.fetch(sl, packed=True)
+                slot = engine.slots[sl]
+                graph_path = engine.fallbacks == fb0 and not engine.mirror   # (a fallback's pyramid is not the slot's)
+                nb0 = slot.flat[cfg.num_layers].cpu().numpy() if graph_path else None
+                total = int(slot.pts.n_dev.item()) if graph_path else None
+                row0 = 0
+                for j in range(nb):
+                    rec = outs[j].cpu().numpy()
+                    fold(par.compare_fragment(refs[i0 + j], rec[:, :3], rec[:, 3:35], rec[:, 35:36], nb0=nb0, row0=row0,
+                                              total=total))
+                    row0 += rec.shape[0]
+        how = "graph engine, %d fragment(s) per replay, %d replays in flight" % (F, S)
+    ok = bool(worst["points_equal"] and worst["idx_equal"] and worst["desc_max_abs"] <= PARITY_TOL
+              and worst["score_max_abs"] <= PARITY_TOL)
+    return {"ok": ok, "fragments": n, "points_equal": worst["points_equal"], "idx_equal": worst["idx_equal"],
+            "desc_max_abs": float("%.3e" % worst["desc_max_abs"]), "score_max_abs": float("%.3e" % worst["score_max_abs"]),
+            "tolerance": PARITY_TOL, "against": "oracle (reference C++ geometry when built + torch-CPU restatement of the TF graph)",
+            "execution": how, "engine_fallbacks": engine.fallbacks if engine is not None else None}
 
 
 if __name__ == "__main__":

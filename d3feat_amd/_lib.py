@@ -45,7 +45,8 @@ SIGNATURES = {
     "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
-    "d3f_detect_head": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "d3f_pack_descriptors": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "d3f_detect_head": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

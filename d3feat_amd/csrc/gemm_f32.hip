@@ -657,7 +657,8 @@ static void gemm_plan(int M, int N, int K, int M_hint, int& bm, int& bn, int& S,
         if (S < 1) S = 1;
     }
     // tuning knob (tools/gemm_bench.py): D3F_GEMM_FORCE="bm,bn,S" overrides the choice; unset in production
-    if (const char* f = getenv("D3F_GEMM_FORCE")) {
+    static const char* const force = getenv("D3F_GEMM_FORCE");   // read once per process
+    if (const char* f = force) {
         int fbm = 0, fbn = 0, fs = 0;
         if (sscanf(f, "%d,%d,%d", &fbm, &fbn, &fs) == 3 && N > 32 &&
             ((fbm == 128 && fbn == 128) || (fbm == 128 && fbn == 64) || (fbm == 64 && fbn == 64))) {
@@ -745,14 +746,10 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
         const int bx_max = gemm_stream_blocks();
         if (bx > bx_max) bx = bx_max;
         dim3 grid(bx, N / (32 * nt));
-        static bool attr_set = false;
-        if (!attr_set) {   // slabs above 64 KB need the opt-in
-            const void* fns[4] = {(const void*)gemm_stream_kernel<2, false>, (const void*)gemm_stream_kernel<1, false>,
-                                  (const void*)gemm_stream_kernel<2, true>, (const void*)gemm_stream_kernel<1, true>};
-            for (int i = 0; i < 4; ++i)
-                if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 73728) != hipSuccess) return D3F_ERR_HIP;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> lds_done{0};   // slabs above 64 KB need the opt-in (per device)
+        const void* const fns[4] = {(const void*)gemm_stream_kernel<2, false>, (const void*)gemm_stream_kernel<1, false>,
+                                    (const void*)gemm_stream_kernel<2, true>, (const void*)gemm_stream_kernel<1, true>};
+        if (d3f_opt_in_lds(lds_done, fns, 73728) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_STREAM(NT_, GA_) gemm_stream_kernel<NT_, GA_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G)
         if (G.gidx) { if (nt == 2) D3F_STREAM(2, true); else D3F_STREAM(1, true); }
         else { if (nt == 2) D3F_STREAM(2, false); else D3F_STREAM(1, false); }
@@ -780,16 +777,10 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
                       (!G.A2 || (G.K1 % 4 == 0 && G.lda2 % 4 == 0 && ((uintptr_t)G.A2 & 15) == 0));
     if (fast) {
         const size_t lds = (size_t)2 * (bm + bn) * GF_S * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {   // the 128 x 128 tile needs 72 KB
-            const void* big[4] = {(const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 0>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 1>,
-                                  (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 2>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 3>};
-            for (int i = 0; i < 4; ++i)
-                if (hipFuncSetAttribute(big[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        2 * 256 * GF_S * (int)sizeof(float)) != hipSuccess)
-                    return D3F_ERR_HIP;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> lds_done{0};   // the 128 x 128 tile needs 72 KB (per device)
+        const void* const big[4] = {(const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 0>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 1>,
+                                    (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 2>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 3>};
+        if (bm == 128 && bn == 128 && d3f_opt_in_lds(lds_done, big, 2 * 256 * GF_S * (int)sizeof(float)) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, EPI_)                                                                     \
     gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, EPI_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, \
                                                                                 M_dev, G)

@@ -64,16 +64,20 @@ __device__ __forceinline__ void kp_influences(const KpParams& P, float rx, float
 
 // row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
 // the support row, so it is evaluated once per support instead of once per (query, neighbour).
+// The test is discontinuous: a row whose fp32 sum lies within rounding of 0 flips with the summation order, and the
+// reference's own order (Eigen's reduction tree inside tf.reduce_sum) is an implementation detail.  The sum is therefore
+// accumulated in fp64 -- exact for <= 2^20 fp32 terms of comparable exponent, so its sign is the sign of the real-number
+// sum whatever the order -- which every fp32 order agrees with wherever that order's own result is not rounding noise.
 __global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict__ f, int Ns, const int* __restrict__ Ns_dev,
                                                         int ldf, int Cin, unsigned char* __restrict__ pos) {
     // one wavefront per row
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (row >= d3f_dyn(Ns, Ns_dev)) return;
-    float s = 0.f;
-    for (int c = lane; c < Cin; c += 64) s += f[(size_t)row * ldf + c];
+    double s = 0.0;
+    for (int c = lane; c < Cin; c += 64) s += (double)f[(size_t)row * ldf + c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) pos[row] = s > 0.f ? 1 : 0;
+    if (lane == 0) pos[row] = s > 0.0 ? 1 : 0;
 }
 
 template <int LQ>  // lanes per query = Cin / 4
@@ -565,13 +569,9 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kpconv_fused32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return D3F_ERR_HIP;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    const void* const fns[1] = {(const void*)kpconv_fused32_kernel};
+    if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
     kpconv_fused32_kernel<<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, out,
                                                                      ldo, Nq_dev, Ns_dev, q_order);
     D3F_LAUNCH_CHECK();

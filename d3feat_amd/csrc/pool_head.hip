@@ -183,20 +183,25 @@ extern "C" int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, con
 // C <= 32 (the shipped 32-d descriptor), generally ceil(C/32) channels per lane; each neighbour row is one
 // coalesced 128-byte read; channel reductions are 5-step xor shuffles inside the 32-lane half.
 // ------------------------------------------------------------------------------------------------
-__global__ void head_max_init_kernel(const int* __restrict__ lens, const int* __restrict__ include_zero_dev, int B,
+__global__ void head_max_init_kernel(const int* __restrict__ lens, const int* __restrict__ include_zero_dev, int group, int B,
                                      unsigned* __restrict__ mx, int* __restrict__ offs) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         // include_zero_dev == NULL: derive it from the lengths (datasets/common.py:453-496: a row of in_batches holds the
-        // shadow index iff the cloud is shorter than the longest one, or all clouds have the same length)
-        int longest = 0, all_eq = 1;
-        for (int b = 0; b < B; ++b) longest = max(longest, lens[b]);
-        for (int b = 0; b < B; ++b) all_eq &= (lens[b] == longest);
+        // shadow index iff the cloud is shorter than the longest one, or all clouds have the same length) -- inside every
+        // group of `group` consecutive clouds (one reference stack each; group <= 0: the whole stack is one)
+        const int g = group > 0 ? group : B;
         int s = 0;
-        for (int b = 0; b < B; ++b) {
-            offs[b] = s;
-            s += lens[b];
-            const int inc = include_zero_dev ? include_zero_dev[b] : ((lens[b] < longest || all_eq) ? 1 : 0);
-            mx[b] = inc ? d3f_f2ord(0.f) : 0u;
+        for (int b0 = 0; b0 < B; b0 += g) {
+            const int b1 = min(b0 + g, B);
+            int longest = 0, all_eq = 1;
+            for (int b = b0; b < b1; ++b) longest = max(longest, lens[b]);
+            for (int b = b0; b < b1; ++b) all_eq &= (lens[b] == longest);
+            for (int b = b0; b < b1; ++b) {
+                offs[b] = s;
+                s += lens[b];
+                const int inc = include_zero_dev ? include_zero_dev[b] : ((lens[b] < longest || all_eq) ? 1 : 0);
+                mx[b] = inc ? d3f_f2ord(0.f) : 0u;
+            }
         }
         offs[B] = s;
     }
@@ -391,15 +396,16 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
 }
 
 extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
-                               const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
-                               int* scratch_dev, const int* row_order, void* stream_) {
+                               const int* lens_dev, const int* include_zero_dev, int stack_group, int B, float* desc, int ldd,
+                               float* score, int* scratch_dev, const int* row_order, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (N < 0 || C < 1 || C > 128 || ldx < C || ldd < C || K < 0 || ld_idx < K || B < 1 || B > D3F_MAX_BATCH) return D3F_ERR_ARG;
+    if (N < 0 || C < 1 || C > 128 || ldx < C || ldd < C || K < 0 || ld_idx < K || B < 1 || B > D3F_MAX_BATCH || stack_group < 0)
+        return D3F_ERR_ARG;
     if (N == 0) return D3F_OK;
     if (!x || !idx || !lens_dev || !desc || !score || !scratch_dev) return D3F_ERR_ARG;
     unsigned* mx = (unsigned*)scratch_dev;  // [B]
     int* offs = scratch_dev + B;            // [B+1]
-    head_max_init_kernel<<<1, 64, 0, stream>>>(lens_dev, include_zero_dev, B, mx, offs);
+    head_max_init_kernel<<<1, 64, 0, stream>>>(lens_dev, include_zero_dev, stack_group, B, mx, offs);
     int chunks = d3f_cdiv((long long)N * C, 256 * 16);
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
@@ -446,4 +452,35 @@ extern "C" int d3f_affine_act(const float* x, int ldx, int M, int N, const float
     return D3F_OK;
 }
 
-extern "C" int d3f_version(void) { return 100; }
+// ------------------------------------------------------------------------------------------------
+// (xyz, desc, score) -> one record f32[3 + C + 1] per point: the 144-byte payload (C = 32) that the testers write per
+// fragment (utils/tester.py:215-229 keeps points / features / scores together) and that the multi-GPU runner gathers once
+// at the end.  One thread per output element; rows are contiguous, so a fragment's records are ONE contiguous block.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ desc, int ldd,
+                                                        int C, const float* __restrict__ score, int N,
+                                                        const int* __restrict__ N_dev, float* __restrict__ out, int ldo) {
+    N = d3f_dyn(N, N_dev);
+    const int W = C + 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * W) return;
+    const int n = (int)(t / W), c = (int)(t % W);
+    float v;
+    if (c < 3) v = xyz[3 * (size_t)n + c];
+    else if (c < 3 + C) v = desc[(size_t)n * ldd + (c - 3)];
+    else v = score[n];
+    out[(size_t)n * ldo + c] = v;
+}
+
+extern "C" int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
+                                    int ldo, const int* N_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || C < 1 || ldd < C || ldo < C + 4) return D3F_ERR_ARG;
+    if (N == 0) return D3F_OK;
+    if (!xyz || !desc || !score || !out) return D3F_ERR_ARG;
+    pack_rows_kernel<<<d3f_cdiv((long long)N * (C + 4), 256), 256, 0, stream>>>(xyz, desc, ldd, C, score, N, N_dev, out, ldo);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+extern "C" int d3f_version(void) { return 200; }

@@ -25,6 +25,9 @@ struct D3fFill {
 
 __device__ __forceinline__ bool d3f_last_block(unsigned* counter, unsigned nblocks) {
     __shared__ int last_flag;
+    // every wave waits for ITS OWN stores to be acknowledged before the barrier: the workgroup-scope release inside
+    // __syncthreads may omit vmcnt(0) outside tgsplit mode, and lane 0's agent-scope release below only covers its own wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -376,7 +376,8 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     // D3F_NB_LPQ=64 restores one wavefront per query (tuning knob)
     cap = (cap + 3) & ~3;   // LDS segments are read four hits at a time
     int lpq = cap > 256 ? 64 : 32;
-    if (const char* f = getenv("D3F_NB_LPQ")) { if (atoi(f) == 64) lpq = 64; else if (atoi(f) == 32) lpq = 32; }
+    static const int lpq_knob = [] { const char* f = getenv("D3F_NB_LPQ"); return f ? atoi(f) : 0; }();   // read once
+    if (lpq_knob == 64 || lpq_knob == 32) lpq = lpq_knob;
     const int qpb = 64 * NB_WAVES_PER_BLOCK / lpq;
     const int blocks = d3f_cdiv(Nq, qpb);
     const size_t lds = first_only ? 0 : (size_t)qpb * cap * 2 * sizeof(float);

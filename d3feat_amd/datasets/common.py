@@ -193,6 +193,7 @@ class Dataset:
 
         overflow = False
         self.static_status = status_all[:len(pending)] if caps is not None else None
+        self.level_lengths = input_batches_len      # per-level stack lengths (device int32[B]); not part of the flat list
         if pending and caps is None:
             # one read-back for all searches of the pyramid
             for kmax, flags in status_all[:len(pending)].tolist():
@@ -217,7 +218,9 @@ class Dataset:
             stacked_batch_inds_1 = self.tf_stack_batch_inds(input_batches_len[-1])
         else:
             # the head kernel works from stack_lengths; the index matrices are only an output of the reference API
-            stacked_batch_inds_0 = stacked_batch_inds_1 = None
+            # (a batched engine stack holds several reference stacks: ops.StackGroups carries their size to the head)
+            stacked_batch_inds_0 = ops.StackGroups(getattr(self, 'stack_group', 0))
+            stacked_batch_inds_1 = None
         li = input_points + input_neighbors + input_pools + input_upsamples
         li += [stacked_features, stacked_weights, stacked_batch_inds_0, stacked_batch_inds_1]
         return li

@@ -15,6 +15,8 @@ synchronisations the GPU idles a third of the time.  Here instead:
 A fragment that does not fit its capacity class (or needs the large neighbour-ordering budget) raises a device-side
 flag; `fetch` then recomputes it through the eager path, so results never depend on the capacities.
 """
+import warnings
+
 import numpy as np
 import torch
 
@@ -92,8 +94,12 @@ class FragmentEngine:
         self._dummy = (torch.rand((256, 3), generator=g) * (6.0 * config.first_subsampling_dl)).to(device)
         # one HIP stream per slot (pass `streams` to share them between engines: the runtime multiplexes every stream of the
         # process onto a few hardware queues, so idle extra streams still cost concurrency)
+        self.neighbor_cap = 192            # hits a query can order in LDS on the fast path (sticky upgrade, see fetch)
         self.slots = [self._build_slot(streams[i] if streams else None) for i in range(int(slots))]
         self.fallbacks = 0
+        self.fragments = 0
+        self._hit_overflows = 0
+        self._warned = False
 
     # ---- the fixed launch sequence -------------------------------------------------------------------------------
     def _sequence(self, sl):
@@ -107,6 +113,10 @@ class FragmentEngine:
             pts, lens = ops.stack_self_pair(sub, sub_l)        # [c_1; c_1; c_2; c_2; ...]
         flat = sl.map(pts, None, None, None, lens, ("a", "a"), pts)
         desc, score = self.model.run(flat)
+        # the pyramid itself stays readable after a replay (parity checks, calibration): static buffers of the graph
+        sl.flat, sl.level_lengths = flat, sl.ds.level_lengths
+        # one 144-byte record [xyz | desc | score] per point: a fragment's result is one contiguous block (fetch(packed=True))
+        sl.packed = ops.pack_descriptors(pts, desc, score)
         return pts, desc, score, sl.ds.static_status, lens
 
     def _build_slot(self, stream=None):
@@ -123,6 +133,11 @@ class FragmentEngine:
         sl.ds.caps = self.caps
         sl.ds.hints = self.hints
         sl.ds.cap_units = self.cap_units
+        # every fragment is its own reference stack (a pair; one cloud when mirrored): the head's per-cloud normalisation
+        # must not see the stack mates (models/D3Feat.py:84-85, datasets/common.py:453-496)
+        sl.ds.stack_group = 1 if self.mirror else 2
+        sl.ds._neighbor_cap = self.neighbor_cap
+        sl.cap = self.neighbor_cap
         sl.map = sl.ds.get_tf_mapping(self.cfg)
         sl.busy = False
         sl.raw_src = None
@@ -155,6 +170,9 @@ class FragmentEngine:
         a pair (raw_a, raw_b) with two_clouds), or -- batch > 1 -- a list of up to `batch` fragments."""
         sl = self.slots[slot]
         assert not sl.busy, "slot %d still holds an unfetched fragment" % slot
+        if sl.cap != self.neighbor_cap:
+            # the ordering budget was raised after repeated overflows: re-capture this slot once, on its own stream
+            sl = self.slots[slot] = self._build_slot(sl.stream)
         single = not isinstance(raw, list)
         frags = [raw] if single else list(raw)
         if not 1 <= len(frags) <= self.F:
@@ -195,14 +213,15 @@ class FragmentEngine:
             sl.host_stat.copy_(sl.dev_stat, non_blocking=True)
             sl.done.record(sl.stream)
 
-    def fetch(self, slot):
+    def fetch(self, slot, packed=False):
         """Wait for slot `slot`; -> (points f32[2n,3], descriptors f32[2n,32], scores f32[2n,1]) device tensors of the stacked
         pair (views into the slot's buffers: valid until the slot is submitted again); a list of such tuples when the
-        submit was given a list."""
+        submit was given a list.  packed=True: one f32[2n, 36] tensor of [xyz | desc | score] records per fragment instead of
+        the tuple (a contiguous view: the unit the sharded runner keeps and gathers)."""
         sl = self.slots[slot]
         assert sl.busy, "slot %d is empty" % slot
         sl.busy = False
-        outs = None
+        outs, flags = None, 0
         if not sl.oversize:
             sl.done.synchronize()
             st = sl.host_stat.numpy()
@@ -213,16 +232,35 @@ class FragmentEngine:
                 outs, o = [], 0
                 for i in range(sl.nfrag):
                     n = sum(lens[i * per:(i + 1) * per])
-                    p, d, s = sl.pts[o:o + n], sl.desc[o:o + n], sl.score[o:o + n]
-                    if self.mirror:   # stacked layout of the reference: both halves hold the cloud
-                        p, d, s = torch.cat([p, p]), torch.cat([d, d]), torch.cat([s, s])
-                    outs.append((p, d, s))
+                    if packed:
+                        r = sl.packed[o:o + n]
+                        outs.append(torch.cat([r, r]) if self.mirror else r)
+                    else:
+                        p, d, s = sl.pts[o:o + n], sl.desc[o:o + n], sl.score[o:o + n]
+                        if self.mirror:   # stacked layout of the reference: both halves hold the cloud
+                            p, d, s = torch.cat([p, p]), torch.cat([d, d]), torch.cat([s, s])
+                        outs.append((p, d, s))
                     o += n
+        self.fragments += sl.nfrag
         if outs is None:
             # capacity exceeded / large ordering budget needed / degenerate cloud: the eager path decides (and raises the
             # reference-level errors where they apply)
             self.fallbacks += sl.nfrag
+            if not sl.oversize and (flags & _lib.ST_HIT_OVERFLOW) and self.neighbor_cap < _lib.NEIGHBOR_CAP:
+                # a query with more in-radius supports than the fast LDS budget: a property of the data set (dense clouds),
+                # not of one fragment -- after the second such replay every slot is re-captured with the full budget
+                self._hit_overflows += 1
+                if self._hit_overflows >= 2:
+                    self.neighbor_cap = _lib.NEIGHBOR_CAP
+                    self._eager_ds._neighbor_cap = _lib.NEIGHBOR_CAP
+            if not self._warned and self.fallbacks >= 8 and self.fallbacks * 10 > self.fragments:
+                self._warned = True
+                warnings.warn("FragmentEngine: %d of %d fragments took the eager fallback (capacities raw_cap=%d n0_cap=%d "
+                              "too small for this data, or degenerate clouds): throughput is that of the op-by-op path"
+                              % (self.fallbacks, self.fragments, self.raw_cap, self.n0_cap))
             outs = [self.run_eager(fr) for fr in sl.raw_src]
+            if packed:
+                outs = [ops.pack_descriptors(*o) for o in outs]
         return outs[0] if sl.single else outs
 
     def run_eager(self, raw):

@@ -58,4 +58,6 @@ def detection_head(features, inputs):
     # or all clouds have the same length (extra pad column).  The head kernel derives that from the lengths on the device;
     # pass inputs['in_batches_padded'] (int32[B] on the device) to override.
     include_zero = inputs.get('in_batches_padded')
-    return ops.detect_head(features, inputs['neighbors'][0], lens_dev, include_zero)
+    ib = inputs.get('in_batches')
+    group = ib.group if isinstance(ib, ops.StackGroups) else 0
+    return ops.detect_head(features, inputs['neighbors'][0], lens_dev, include_zero, stack_group=group)

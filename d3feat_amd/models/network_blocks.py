@@ -150,6 +150,12 @@ def _resnetb(layer_ind, inputs, features, radius, fdim, config, strided):
         else:
             q, s, nb = inputs['points'][layer_ind], inputs['points'][layer_ind], inputs['neighbors'][layer_ind]
         x = KPConv(q, s, nb, x, w, radius, config, epilogue=_epilogue(fdim // 2, config, True))
+    # variables are created in the reference's order (conv3 before shortcut, :342-356 / :585-600) so that lazily created
+    # random weights equal build_variables(seed)'s; the compute order below is free
+    with variable_scope('conv3'):
+        vs = _vs()
+        w3 = vs.weight_variable([fdim // 2, 2 * fdim])
+        bn3 = vs.batch_norm_variables(2 * fdim) if config.use_batch_norm else None
     with variable_scope('shortcut'):
         shortcut = ind_max_pool(features, inputs['pools'][layer_ind]) if strided else features
         need_sc = int(shortcut.shape[1]) != 2 * fdim
@@ -166,9 +172,8 @@ def _resnetb(layer_ind, inputs, features, radius, fdim, config, strided):
                 shortcut = conv_ops.unary_convolution(shortcut, vs.tensor(sc_w), epilogue=_epilogue(2 * fdim, config, False))
     with variable_scope('conv3'):
         vs = _vs()
-        w3 = vs.weight_variable([fdim // 2, 2 * fdim])
         if fuse:
-            W, shift = vs.stacked_branches(w3, vs.batch_norm_variables(2 * fdim), sc_w, sc_bn)
+            W, shift = vs.stacked_branches(w3, bn3, sc_w, sc_bn)
             return ops.gemm_cat2(x, shortcut, W, col_shift=shift, leaky=True, alpha=0.2)
         # leaky_relu(batch_norm(conv3) + shortcut): the add and the activation ride in the contraction's epilogue
         return conv_ops.unary_convolution(x, vs.tensor(w3), epilogue=_epilogue(2 * fdim, config, True, residual=shortcut))

@@ -180,12 +180,14 @@ def batch_grid_subsample(points, lens, dl, features=None, classes=None):
     status = (ctypes.c_int * (B + 2))()
     nbytes = lib.d3f_grid_subsample_workspace_bytes(N, B, fdim, ldim)
     ws = workspace(nbytes, dev)
-    rc = lib.d3f_batch_grid_subsample(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl),
-                                      features.data_ptr() if fdim else None, fdim,
-                                      classes.data_ptr() if ldim else None, ldim,
-                                      sub_p.data_ptr(), sub_f.data_ptr() if fdim else None,
-                                      sub_c.data_ptr() if ldim else None, sub_l.data_ptr(),
-                                      ctypes.addressof(status), ws.data_ptr(), ws.numel(), _stream(dev))
+    with _timed("grid_subsample", dict(N=N, M=None), dev) as tm:
+        rc = lib.d3f_batch_grid_subsample(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl),
+                                          features.data_ptr() if fdim else None, fdim,
+                                          classes.data_ptr() if ldim else None, ldim,
+                                          sub_p.data_ptr(), sub_f.data_ptr() if fdim else None,
+                                          sub_c.data_ptr() if ldim else None, sub_l.data_ptr(),
+                                          ctypes.addressof(status), ws.data_ptr(), ws.numel(), _stream(dev))
+        tm.info["M"] = int(status[0])
     _lib.check(rc, "batch_grid_subsample")
     M = _raise_flags(status[1], "batch_grid_subsample") or status[0]
     sub_l.host_lens = [int(status[2 + b]) for b in range(B)]
@@ -209,9 +211,10 @@ def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0, e
         status = torch.empty((2,), dtype=torch.int32, device=dev)
     nbytes = lib.d3f_grid_subsample_workspace_bytes(N, B, 0, 0)
     ws = workspace(nbytes, dev)
-    rc = lib.d3f_batch_grid_subsample_async(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl), sub_p.data_ptr(),
-                                            int(m_cap), int(elem_cap), sub_l.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
-                                            _stream(dev))
+    with _timed("grid_subsample", dict(N=N, M=int(m_cap)), dev):
+        rc = lib.d3f_batch_grid_subsample_async(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl), sub_p.data_ptr(),
+                                                int(m_cap), int(elem_cap), sub_l.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), _stream(dev))
     _lib.check(rc, "batch_grid_subsample_async")
     sub_p.n_dev = status[0:1]
     sub_p.n_hint = int(m_hint)
@@ -255,8 +258,9 @@ class NeighborGrid:
         self.radius = float(radius)
         self.nbytes = lib.d3f_neighbor_grid_bytes(self.Ns, self.B)
         self.mem = torch.empty((self.nbytes,), dtype=torch.uint8, device=dev)
-        rc = lib.d3f_neighbor_grid_build(self.supports.data_ptr(), self.Ns, self.s_lens.data_ptr(), self.B, self.radius,
-                                         self.mem.data_ptr(), self.nbytes, _stream(dev))
+        with _timed("nb_grid_build", dict(Ns=self.Ns), dev):
+            rc = lib.d3f_neighbor_grid_build(self.supports.data_ptr(), self.Ns, self.s_lens.data_ptr(), self.B, self.radius,
+                                             self.mem.data_ptr(), self.nbytes, _stream(dev))
         _lib.check(rc, "neighbor_grid_build")
         # support indices sorted by cell (a view into the grid object): a spatially coherent visiting order
         off = lib.d3f_neighbor_grid_order_offset(self.Ns, self.B)
@@ -301,6 +305,31 @@ def batch_radius_neighbors(queries, supports, q_lens, s_lens, radius, width, ld=
     No synchronisation: status[0] = Kmax, status[1] = flags (see check_status)."""
     grid = NeighborGrid(supports, s_lens, radius)
     return grid.search(queries, q_lens, width, ld=ld, pad_value=pad_value, cap=cap, first_only=first_only, out=out)
+
+
+class StackGroups:
+    """Stands in for the `in_batches` matrix (datasets/common.py:453-496) on the fast path, where the head kernel works from
+    the stack lengths: `group` = clouds per reference stack inside a batched stack (see d3f_detect_head)."""
+
+    def __init__(self, group=0):
+        self.group = int(group)
+
+
+_KP_HOST = {}
+
+
+def _kp_host(K_points):
+    """Kernel points as a contiguous host float32 array (they ride in the kernel arguments).  The model keeps them on the
+    host; a caller-supplied device tensor is read back once per (storage, version), not once per call."""
+    if isinstance(K_points, torch.Tensor):
+        key = (K_points.data_ptr(), K_points._version, tuple(K_points.shape))
+        kp = _KP_HOST.get(key)
+        if kp is None:
+            if len(_KP_HOST) > 256:
+                _KP_HOST.clear()
+            kp = _KP_HOST[key] = np.ascontiguousarray(K_points.detach().cpu().numpy(), dtype=np.float32)
+        return kp
+    return np.ascontiguousarray(K_points, dtype=np.float32)
 
 
 _INFLUENCE = {"constant": 0, "linear": 1, "gaussian": 2}
@@ -425,8 +454,7 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation_mode not in _AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
-    kp = np.ascontiguousarray(K_points.detach().cpu().numpy() if isinstance(K_points, torch.Tensor) else K_points,
-                              dtype=np.float32)
+    kp = _kp_host(K_points)
     num_kp = kp.shape[0]
     Nq, Ns, K, Cin = q.shape[0], s.shape[0], idx.shape[1], f.shape[1]
     if idx.shape[0] != Nq or f.shape[0] != Ns:
@@ -459,8 +487,7 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     s = _req(support_points, torch.float32, "support_points", 2).contiguous()
     idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
     f, ldf = _rows(_req(features, torch.float32, "features"), "features")
-    kp = np.ascontiguousarray(K_points.detach().cpu().numpy() if isinstance(K_points, torch.Tensor) else K_points,
-                              dtype=np.float32)
+    kp = _kp_host(K_points)
     num_kp, cin, cout = K_values.shape
     if cin != 32 or cout != 32 or f.shape[1] != 32:
         raise ValueError("kpconv_fused32 needs Cin == Cout == 32")
@@ -498,8 +525,7 @@ def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K
     s = _req(support_points, torch.float32, "support_points", 2).contiguous()
     idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
     f, ldf = _rows(_req(features, torch.float32, "features"), "features")
-    kp = np.ascontiguousarray(K_points.detach().cpu().numpy() if isinstance(K_points, torch.Tensor) else K_points,
-                              dtype=np.float32)
+    kp = _kp_host(K_points)
     num_kp, cin, cout = K_values.shape
     if cin != 1 or f.shape[1] != 1:
         raise ValueError("kpconv_fused_c1 needs Cin == 1")
@@ -530,9 +556,10 @@ def ind_max_pool(x, inds):
     dev = x.device
     out = torch.empty((inds.shape[0], x.shape[1]), dtype=torch.float32, device=dev)
     colmin = torch.empty((x.shape[1] + 4,), dtype=torch.float32, device=dev)    # column minima (lazy) + flag word
-    rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
-                              inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _order(inds),
-                              _stream(dev))
+    with _timed("ind_max_pool", dict(N1=x.shape[0], N2=inds.shape[0], K=inds.shape[1], C=x.shape[1]), dev):
+        rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
+                                  inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _order(inds),
+                                  _stream(dev))
     _lib.check(rc, "ind_max_pool")
     return _tag(out, inds)
 
@@ -557,8 +584,9 @@ def closest_pool_cat(x, inds, skip=None):
     return _tag(out, inds)
 
 
-def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev):
-    """-> (desc f32[N,C], score f32[N,1])."""
+def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev, stack_group=0):
+    """-> (desc f32[N,C], score f32[N,1]).  stack_group: clouds per reference stack inside a batched stack (0: the whole
+    stack is one reference stack), see include/d3feat_amd.h."""
     lib = _lib.load()
     x, ldx = _rows(_req(x, torch.float32, "x"), "x")
     nb, ldi = _rows(_req(neighbors, torch.int32, "neighbors"), "neighbors")
@@ -568,11 +596,31 @@ def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev):
     desc = torch.empty((N, Cc), dtype=torch.float32, device=dev)
     score = torch.empty((N, 1), dtype=torch.float32, device=dev)
     scratch = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
-    rc = lib.d3f_detect_head(x.data_ptr(), N, ldx, Cc, nb.data_ptr(), ldi, nb.shape[1],
-                             stack_lengths_dev.data_ptr(), include_zero_dev.data_ptr() if include_zero_dev is not None else None,
-                             B, desc.data_ptr(), Cc, score.data_ptr(), scratch.data_ptr(), _order(nb), _stream(dev))
+    with _timed("detect_head", dict(N=N, K=nb.shape[1], C=Cc), dev):
+        rc = lib.d3f_detect_head(x.data_ptr(), N, ldx, Cc, nb.data_ptr(), ldi, nb.shape[1],
+                                 stack_lengths_dev.data_ptr(),
+                                 include_zero_dev.data_ptr() if include_zero_dev is not None else None,
+                                 int(stack_group), B, desc.data_ptr(), Cc, score.data_ptr(), scratch.data_ptr(), _order(nb),
+                                 _stream(dev))
     _lib.check(rc, "detect_head")
     return _tag(desc, x), _tag(score, x)
+
+
+def pack_descriptors(xyz, desc, score):
+    """-> f32[N, 3 + C + 1] records [xyz | desc | score] (one contiguous block per fragment of a stack)."""
+    lib = _lib.load()
+    xyz = _req(xyz, torch.float32, "xyz", 2).contiguous()
+    desc, ldd = _rows(_req(desc, torch.float32, "desc"), "desc")
+    score = _req(score, torch.float32, "score").contiguous()
+    N, Cc = desc.shape
+    if xyz.shape[0] != N or xyz.shape[1] != 3 or score.numel() != N:
+        raise ValueError("pack_descriptors: %s points, %s descriptors, %s scores" % (tuple(xyz.shape), tuple(desc.shape),
+                                                                                     tuple(score.shape)))
+    out = torch.empty((N, Cc + 4), dtype=torch.float32, device=desc.device)
+    rc = lib.d3f_pack_descriptors(xyz.data_ptr(), desc.data_ptr(), ldd, Cc, score.data_ptr(), N, out.data_ptr(), Cc + 4,
+                                  _nd(xyz) or _nd(desc), _stream(desc.device))
+    _lib.check(rc, "pack_descriptors")
+    return _tag(out, desc)
 
 
 def affine_act(x, col_scale=None, col_shift=None, residual=None, leaky=False, alpha=0.2):

@@ -71,3 +71,63 @@ def gather_descriptors(xyz, desc, score):
     out = [torch.empty_like(payload) for _ in range(ws)]
     dist.all_gather(out, payload)
     return [(o[:s, 0:3], o[:s, 3:3 + C], o[:s, 3 + C:]) for o, s in zip(out, sizes)]
+
+
+class ShardCollector:
+    """This rank's results, kept in HBM as they are produced: one f32[rows, width] buffer of [xyz | desc | score] records
+    (ops.pack_descriptors) plus the row count of every fragment.  `add` is one contiguous device-to-device copy (plumbing,
+    issued on the current stream); `gather` is the path's only data collective."""
+
+    def __init__(self, rows_cap, width=36, device=None):
+        self.buf = torch.empty((int(rows_cap), int(width)), dtype=torch.float32, device=device)
+        self.rows = 0
+        self.frag_rows = []
+
+    def reset(self):
+        self.rows, self.frag_rows = 0, []
+
+    def add(self, packed):
+        n = int(packed.shape[0])
+        if self.rows + n > self.buf.shape[0]:
+            grown = torch.empty((max(2 * self.buf.shape[0], self.rows + n), self.buf.shape[1]), dtype=torch.float32,
+                                device=self.buf.device)
+            grown[: self.rows].copy_(self.buf[: self.rows])
+            self.buf = grown
+        self.buf[self.rows:self.rows + n].copy_(packed, non_blocking=True)
+        self.rows += n
+        self.frag_rows.append(n)
+
+    def records(self):
+        return self.buf[: self.rows]
+
+    def gather(self):
+        return gather_shard(self.records(), self.frag_rows)
+
+
+def gather_shard(records, frag_rows):
+    """Variable-length all_gather of every rank's WHOLE shard: records f32[rows, W] (rows differ per rank) and the
+    per-fragment row counts.  Sizes first, then ONE padded payload collective (RCCL all_gather over xGMI on GPUs, gloo on
+    CPU tensors).  -> list over ranks of (records f32[rows_r, W], frag_rows list)."""
+    rank, ws = world()
+    if ws == 1:
+        return [(records, list(frag_rows))]
+    dev = records.device
+    W = records.shape[1]
+    meta = torch.tensor([records.shape[0], len(frag_rows)], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(ws)]
+    dist.all_gather(metas, meta)
+    metas = [[int(v) for v in m.tolist()] for m in metas]
+    rmax, fmax = max(m[0] for m in metas), max(m[1] for m in metas)
+    fr = torch.zeros((max(fmax, 1),), dtype=torch.int64, device=dev)
+    if frag_rows:
+        fr[: len(frag_rows)] = torch.tensor(list(frag_rows), dtype=torch.int64, device=dev)
+    frs = [torch.zeros_like(fr) for _ in range(ws)]
+    dist.all_gather(frs, fr)
+    if rmax == records.shape[0] and records.is_contiguous():
+        payload = records
+    else:
+        payload = torch.zeros((rmax, W), dtype=torch.float32, device=dev)
+        payload[: records.shape[0]] = records
+    out = [torch.empty((rmax, W), dtype=torch.float32, device=dev) for _ in range(ws)]
+    dist.all_gather(out, payload)
+    return [(o[: m[0]], [int(v) for v in f[: m[1]].tolist()]) for o, m, f in zip(out, metas, frs)]

@@ -242,13 +242,24 @@ int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale
  *   include_zero_dev i32[B] (device) or NULL: 1 if the cloud's row of in_batches contains the shadow index (so that
  *       the per-cloud maximum of :84-85 includes the zero row) -- datasets/common.py:453-496; NULL derives it from
  *       lens_dev on the device (shorter than the longest cloud, or all clouds equally long)
+ *   stack_group: 0 = the B clouds are ONE reference stack (the rule above is applied over all of them); g > 0 = the
+ *       stack is a concatenation of independent reference stacks of g consecutive clouds each (the fragment engine's
+ *       batched replays: g = 2 pairs, g = 1 self-pairs computed once) and the rule is applied inside every group, so a
+ *       fragment's result never depends on its stack mates.  Ignored when include_zero_dev is given.
  *   N is an upper bound: the real point count is sum(lens_dev)
  *   desc f32[N,C] = l2_normalize(x, eps 1e-10);  score f32[N]
  *   scratch_dev: >= 2*B+2 ints of device scratch.  C <= 128.
  * ------------------------------------------------------------------------------------------- */
 int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
-                    const int* lens_dev, const int* include_zero_dev, int B, float* desc, int ldd, float* score,
-                    int* scratch_dev, const int* row_order, void* stream);
+                    const int* lens_dev, const int* include_zero_dev, int stack_group, int B, float* desc, int ldd,
+                    float* score, int* scratch_dev, const int* row_order, void* stream);
+
+/* The per-point output record of the path: out[n] = [ xyz(3) | desc(C) | score(1) ], f32, row stride ldo >= C + 4.
+ * Replaces the three arrays the testers keep per fragment (utils/tester.py:215-229: points, features, scores written
+ * side by side) with one contiguous block per fragment -- the unit the multi-GPU runner gathers once at the end.
+ * N is an upper bound when N_dev (device int) is given. */
+int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
+                         int ldo, const int* N_dev, void* stream);
 
 #ifdef __cplusplus
 }

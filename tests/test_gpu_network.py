@@ -15,12 +15,14 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def _close(got, want, tol=TOL):
+def _close(got, want, tol=TOL, relative=False):
+    """max |got - want| <= tol, ABSOLUTE (the north star's bar).  relative=True scales by max(1, |want|_inf): only for the
+    raw contraction tests, whose random operands produce outputs of arbitrary magnitude (stated at the call site)."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape
-    scale = max(1.0, np.abs(want).max())
+    scale = max(1.0, np.abs(want).max()) if relative else 1.0
     err = np.abs(got - want).max()
-    assert err <= tol * scale, "max abs err %.3e (scale %.3g)" % (err, scale)
+    assert err <= tol * scale, "max abs err %.3e (|want|max %.3g)" % (err, np.abs(want).max())
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 32), (777, 15, 64), (4097, 128, 256), (390, 7680, 512), (200, 1024, 2048),
@@ -36,11 +38,11 @@ def test_gemm_epilogues(device, M, K, N):
     res = rng.standard_normal((M, N)).astype(np.float32)
     ref = A.astype(np.float64) @ B.astype(np.float64)
     got = ops.gemm(_t(A, device), _t(B, device)).cpu().numpy()
-    _close(got, ref, 2e-5)
+    _close(got, ref, 2e-5, relative=True)      # raw contraction, random operands
     full = ref * rs[:, None] * cs + ch + res
     full = np.where(full > 0, full, 0.2 * full)
     got = ops.gemm(_t(A, device), _t(B, device), _t(rs, device), _t(cs, device), _t(ch, device), _t(res, device), True, 0.2)
-    _close(got.cpu().numpy(), full, 2e-5)
+    _close(got.cpu().numpy(), full, 2e-5, relative=True)
 
 
 def test_gemm_streaming_kernel_everywhere(device):
@@ -64,7 +66,7 @@ def test_gemm_strided_views(device):
     B = rng.standard_normal((40, 24)).astype(np.float32)
     tb = _t(big, device)
     got = ops.gemm(tb[:, 8:48], _t(B, device)).cpu().numpy()      # lda = 96, base not 16B-multiple of row
-    _close(got, big[:, 8:48].astype(np.float64) @ B, 2e-5)
+    _close(got, big[:, 8:48].astype(np.float64) @ B, 2e-5, relative=True)
 
 
 def _layer_case(seed, cin, cout, strided, layer=0):
@@ -170,6 +172,37 @@ def test_detection_head_vs_oracle(device, coracle, lens):
     desc, score = detection_head(_t(x, device), inputs)
     _close(desc.cpu().numpy(), want_d, 1e-5)
     _close(score.cpu().numpy(), want_s)
+
+
+def test_detection_head_stack_groups_all_negative(device, coracle):
+    """A batched engine stack holds several reference stacks (pairs).  The per-cloud maximum of models/D3Feat.py:84-85 includes
+    the zero shadow row iff the cloud's in_batches row is padded (datasets/common.py:453-496) -- a rule about the cloud's OWN
+    pair.  With all-negative last_unary outputs the zero row IS the maximum wherever it is included, so the grouping is
+    visible: every pair of the 6-cloud stack must equal the oracle head run on that pair alone (equal lengths: both clouds
+    padded; unequal: only the shorter one), whatever the lengths of its stack mates."""
+    from d3feat_amd import ops
+    from oracle import network_np as onp
+    s0 = surface_cloud(17, n_raw=24000)
+    n = len(s0)
+    cuts = [0, n // 6, 2 * (n // 6), 2 * (n // 6) + n // 4, 2 * (n // 6) + n // 4 + n // 10, n - n // 5, n]
+    L = np.diff(cuts).astype(np.int32)           # pairs: (equal, equal), (long, short), (x, y)
+    assert L[0] == L[1] and L[2] != L[3]
+    nb = coracle.batch_neighbors(s0, s0, L, L, np.float32(0.075))[:, :30]
+    rng = np.random.default_rng(2)
+    x = (-np.abs(rng.standard_normal((n, 32))) - 0.05).astype(np.float32)          # every entry negative
+    desc, score = ops.detect_head(_t(x, device), _t(nb.astype(np.int32), device), _t(L, device), None, stack_group=2)
+    score = score.cpu().numpy()
+    for g in range(3):
+        a, b = cuts[2 * g], cuts[2 * g + 2]
+        Lp = L[2 * g:2 * g + 2]
+        nbp = nb[a:b].astype(np.int64)
+        nbp = np.where(nbp >= n, b - a, nbp - a)                                    # re-based to the pair
+        want = onp.detection_head(torch.from_numpy(x[a:b]), nbp, onp.stack_batch_inds(Lp), Lp).numpy()
+        # (a padded cloud's maximum is the zero row: y = x / 1e-6 -- scores of order 1e7, hence the relative bound here)
+        _close(score[a:b], want, relative=True)
+    # and the whole-stack rule (group 0) differs from it on this input: the grouping is not vacuous
+    _, score0 = ops.detect_head(_t(x, device), _t(nb.astype(np.int32), device), _t(L, device), None, stack_group=0)
+    assert np.abs(score0.cpu().numpy() - score).max() > 1.0
 
 
 def _pair_inputs(coracle, cfg, cloud, limits):
@@ -289,4 +322,4 @@ def test_gemm_upsample_cat_equals_materialised(device, C1, C2, N):
                          ([skip.cpu().numpy()] if C2 else []), 1).astype(np.float64) @ W.cpu().numpy().astype(np.float64)
     ref = ref * cs.cpu().numpy() + ch.cpu().numpy()
     ref = np.where(ref > 0, ref, 0.2 * ref)
-    _close(got.cpu().numpy(), ref, 2e-5)
+    _close(got.cpu().numpy(), ref, 2e-5, relative=True)

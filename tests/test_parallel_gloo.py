@@ -71,6 +71,21 @@ def _worker(rank, world, port, out_dir):
         e = 0 if rank == 1 else 5
         res = parallel.gather_descriptors(torch.ones(e, 3), torch.ones(e, 32), torch.ones(e, 1))
         assert [r[0].shape[0] for r in res] == [5 if r != 1 else 0 for r in range(world)]
+        # ---- whole-shard gather: every fragment of every rank arrives, in order, with its row count
+        col = parallel.ShardCollector(rows_cap=64, width=36)           # deliberately small: grows
+        nfr = 3 + rank
+        for i in range(nfr):
+            gi = torch.Generator().manual_seed(1000 * rank + i)
+            col.add(torch.rand(50 + 7 * i + rank, 36, generator=gi))
+        shards = col.gather()
+        assert len(shards) == world
+        for r, (rec, fr) in enumerate(shards):
+            assert fr == [50 + 7 * i + r for i in range(3 + r)] and rec.shape == (sum(fr), 36)
+            o = 0
+            for i, n in enumerate(fr):
+                gi = torch.Generator().manual_seed(1000 * r + i)
+                assert torch.equal(rec[o:o + n], torch.rand(n, 36, generator=gi))
+                o += n
         open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     finally:
         dist.barrier()

@@ -44,6 +44,14 @@ def main(dirs):
             w = a.get("WRITE_SIZE", [0.0, 1])
             e["traffic_bytes_per_launch"] = int(2 * 1024 * f[0] / max(f[1], 1) + 1024 * w[0] / max(w[1], 1))
         out[k] = e
+    # tie the counters to the kernel sources they measured (bench.py marks `traffic_stale` when the hash differs)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(root, "d3feat_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    out["__source_hash__"] = h.hexdigest()[:16]
     json.dump(out, sys.stdout, indent=1)
     print()
 
