@@ -1,0 +1,2 @@
+def __getattr__(name):
+    raise NotImplementedError("matplotlib is not installed; compat stand-in has no cm.%s" % name)

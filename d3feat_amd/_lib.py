@@ -38,6 +38,10 @@ SIGNATURES = {
                                  _f, _vp, _i, _vp, _vp, _vp, _vp]),
     "d3f_kpconv_fused32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp,
                                 _i, _vp, _vp, _vp, _vp]),
+    "d3f_kpconv_fused_supported": (_i, [_i, _i, _i, _i, _i]),
+    "d3f_kpconv_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "d3f_kpconv_fused": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
+                              _f, _vp, _i, _vp, _vp, _vp, _vp]),
     "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "d3f_gemm_upsample_cat_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _sz,
@@ -46,6 +50,13 @@ SIGNATURES = {
     "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
     "d3f_pack_descriptors": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "d3f_feature_nn_workspace_bytes": (_sz, [_i]),
+    "d3f_feature_nn": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_mutual_matches_workspace_bytes": (_sz, [_i]),
+    "d3f_mutual_matches": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_ransac_hypotheses": (_i, [_vp, _i, _vp, _i, _vp, _i, _f, _f, C.c_uint64, C.c_uint64, _i, _vp, _vp, _vp]),
+    "d3f_ransac_draw": (_i, [C.c_uint64, C.c_uint64, _i, _i]),
+    "d3f_neighbor_grid_score": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "d3f_detect_head": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
 }
 

@@ -62,6 +62,28 @@ __device__ __forceinline__ void kp_influences(const KpParams& P, float rx, float
     }
 }
 
+// The configuration every shipped model uses (linear influence, 'sum' aggregation, 15 kernel points -- parameters.txt:
+// KP_influence = linear, convolution_mode = sum, num_kernel_points = 15) as straight-line code: 15 x {3 subtractions,
+// 3 multiply-adds, add, v_sqrt, multiply-subtract, max}, no mode branches, the kernel points read as scalar operands.
+// FAST = false keeps the general function above (other modes / fewer kernel points).
+template <bool FAST>
+__device__ __forceinline__ void kp_influences_t(const KpParams& P, float rx, float ry, float rz, float* w) {
+    if (FAST) {
+#pragma unroll
+        for (int p = 0; p < KP_MAXP - 1; ++p) {
+            const float dx = rx - P.kp[3 * p], dy = ry - P.kp[3 * p + 1], dz = rz - P.kp[3 * p + 2];
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            w[p] = fmaxf(fmaf(-__builtin_amdgcn_sqrtf(d2 + 1e-10f), P.inv_2extent, 1.0f), 0.0f);
+        }
+        w[KP_MAXP - 1] = 0.f;
+    } else {
+        kp_influences(P, rx, ry, rz, w);
+    }
+}
+static inline bool kp_fast_config(int num_kp, int influence, int aggregation) {
+    return num_kp == KP_MAXP - 1 && influence == 1 && aggregation == 0;
+}
+
 // row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
 // the support row, so it is evaluated once per support instead of once per (query, neighbour).
 // The test is discontinuous: a row whose fp32 sum lies within rounding of 0 flips with the summation order, and the
@@ -80,7 +102,7 @@ __global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict_
     if (lane == 0) pos[row] = s > 0.0 ? 1 : 0;
 }
 
-template <int LQ>  // lanes per query = Cin / 4
+template <int LQ, bool FAST>  // lanes per query = Cin / 4; FAST: linear / sum / 15 kernel points (kp_influences_t)
 __global__ void __launch_bounds__(256)
 kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                 int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
@@ -118,7 +140,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
             float w[KP_MAXP];
             if (id >= 0 && id < Ns) {
                 const float rx = s[3 * (size_t)id] - qx, ry = s[3 * (size_t)id + 1] - qy, rz = s[3 * (size_t)id + 2] - qz;
-                kp_influences(P, rx, ry, rz, w);
+                kp_influences_t<FAST>(P, rx, ry, rz, w);
                 if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
             } else {
                 id = -1;
@@ -408,6 +430,7 @@ typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
 #define KF_HP 8                        // kernel points per contraction pass (the wf tile goes through LDS in two passes)
 #define KF_TS (KF_HP * 32 + 1)        // wf tile stride per query: odd, so the MFMA A-fragment column reads hit 32 banks
 
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                       int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
@@ -444,7 +467,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
             if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
             if (id >= 0 && id < Ns) {
-                kp_influences(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
+                kp_influences_t<FAST>(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
                 if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
             } else {
                 id = -1;
@@ -570,10 +593,260 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static std::atomic<unsigned long long> lds_done{0};
-    const void* const fns[1] = {(const void*)kpconv_fused32_kernel};
+    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true>, (const void*)kpconv_fused32_kernel<false>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-    kpconv_fused32_kernel<<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, out,
-                                                                     ldo, Nq_dev, Ns_dev, q_order);
+    if (kp_fast_config(num_kp, influence, aggregation))
+        kpconv_fused32_kernel<true><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E,
+                                                                               out, ldo, Nq_dev, Ns_dev, q_order);
+    else
+        kpconv_fused32_kernel<false><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E,
+                                                                                out, ldo, Nq_dev, Ns_dev, q_order);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole KPConv_ops (kernels/convolution_ops.py:161-255) + inference epilogue for Cin = 64 / 128 -- levels 1 and 2, whose
+// aggregation tensors wf = [Nq, 15*Cin] were written to and read back from memory by the two-kernel form (224 MB each way
+// per level-1 layer at four fragments per replay, against 41 MB of algorithmic traffic).  Here wf never leaves the chip:
+//   * a workgroup owns 16 queries x LQ = Cin/4 lanes (256 / 512 threads); phases A / B are kpconv_agg_vec4<LQ>'s (influences
+//     of one (query, neighbour) pair per thread parked in LDS, then 60 register accumulators per lane over float4 feature
+//     gathers, eight in flight);
+//   * the 16 x (15*Cin) tile of weighted features then goes through ONE 33 KB LDS region in passes of 512 k-values
+//     (8 kernel points at Cin = 64, 4 at Cin = 128) and is contracted with K_values on the matrix cores
+//     (v_mfma_f32_16x16x4_f32, exact fp32): wave w owns output columns 16w..16w+15 over the whole k range -- no cross-wave
+//     reduction -- with two accumulator chains (the instruction's dependent latency is 40 cycles against a 32-cycle issue);
+//   * k may be visited in any order, so lane (row r, group g) owns k = 16*blk + 4*g + {0,1,2,3} of every 16-deep block: its
+//     four A operands are ONE ds_read_b128, its four B operands ONE 16-byte load from the k-block-packed copy of K_values
+//     (d3f_kpconv_pack_weights: Wp[blk][g][n][j] = W[16*blk + 4*g + j][n]; 256 contiguous bytes per 16-lane group), two
+//     groups of four blocks prefetched ahead of the multiplies;
+//   * neighbour-count division, batch norm, residual and LeakyReLU in the accumulator registers; only out [Nq, Cout]
+//     reaches memory.
+// VALU (aggregation) and matrix (contraction) phases of different workgroups on a CU overlap: the two pipes are separate.
+// ------------------------------------------------------------------------------------------------
+typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
+
+#define KG_TQ 16                        // queries per workgroup = rows of one 16x16x4 tile
+#define KG_KT 512                       // k-values per contraction pass
+#define KG_TS (KG_KT + 4)               // LDS row stride of the wf tile (floats): 16-byte aligned rows, TS/4 odd
+
+// Registers: 60 accumulators + the gather prefetch decide the occupancy.  512-thread workgroups (Cin = 128) are two waves
+// per SIMD each: at more than 128 registers only ONE workgroup fits a CU and its gather and matrix phases cannot overlap with
+// anybody's, so that variant prefetches four rows instead of eight and is held to 128 registers (two workgroups per CU).
+template <int LQ>   // lanes per query = Cin / 4 (16 or 32); Cout == Cin; waves = LQ / 4 = Cout / 16
+__global__ void __launch_bounds__(KG_TQ * LQ, LQ == 32 ? 4 : 3)
+kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                    int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                    KpParams P, const float* __restrict__ Wp, KpEpi E, float* __restrict__ out, int ldo,
+                    const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
+    constexpr int CIN = 4 * LQ, COUT = CIN;
+    constexpr int KC = LQ;                  // neighbours per chunk (one (query, neighbour) pair per thread)
+    constexpr int WS = KC * 16 + 4;         // phase-A stride per query (floats)
+    constexpr int HP = KG_KT / CIN;         // kernel points per contraction pass
+    static_assert(KG_TQ * WS <= KG_TQ * KG_TS, "the influence region must fit the tile region");
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
+    if ((int)(blockIdx.x * KG_TQ) >= Nq) return;
+    __shared__ __attribute__((aligned(16))) float region[KG_TQ * KG_TS];   // influences, then the wf tile of each pass
+    __shared__ int lidx[KG_TQ * KC];
+    __shared__ int lcnt[KG_TQ];
+    __shared__ int lq[KG_TQ];
+    float* lw = region;
+    float* wft = region;
+    const int tid = threadIdx.x;
+    const int ql = tid / LQ, cl = tid % LQ;
+    const int qslot = blockIdx.x * KG_TQ + ql;
+    const int qg = (q_order && qslot < Nq) ? q_order[qslot] : qslot;
+    if (tid < KG_TQ) lcnt[tid] = 0;
+    if (cl == 0) lq[ql] = qslot < Nq ? qg : -1;
+    float acc[KP_MAXP - 1][4];
+#pragma unroll
+    for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (qslot < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
+            const int k = k0 + cl;
+            int id = Ns;
+            if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
+            float w[KP_MAXP];
+            if (id >= 0 && id < Ns) {
+                kp_influences_t<true>(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
+                if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
+            } else {
+                id = -1;
+#pragma unroll
+                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
+            }
+            lidx[ql * KC + cl] = id;
+            float4* dst = (float4*)&lw[ql * WS + cl * 16];
+            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
+            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
+            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
+        }
+        __syncthreads();
+        // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3); PF feature rows requested before any is consumed ----
+        const int kend = min(KC, K - k0);
+        constexpr int PF = LQ == 32 ? 4 : 8;
+        for (int kg = 0; kg < kend; kg += PF) {
+            float4 fv[PF];
+            int ids[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
+                fv[u] = ids[u] >= 0 ? *(const float4*)&f[(size_t)ids[u] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
+                const float4* src = (const float4*)&lw[ql * WS + (kg + u) * 16];
+                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+                for (int p = 0; p < KP_MAXP - 1; ++p) {
+                    acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
+                    acc[p][1] = fmaf(w[p], fv[u].y, acc[p][1]);
+                    acc[p][2] = fmaf(w[p], fv[u].z, acc[p][2]);
+                    acc[p][3] = fmaf(w[p], fv[u].w, acc[p][3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- contraction: out[16 x Cout] = wf[16 x 15*Cin] @ K_values, the wf tile through LDS in passes of HP kernel points ----
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    kp_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const int npass = (P.num_kp + HP - 1) / HP;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int p0 = pass * HP;
+        const int np = min(P.num_kp - p0, HP);
+        if (pass) __syncthreads();                      // the previous pass's tile has been consumed
+        // this thread's weighted features of the pass -> tile row ql, k = pp*Cin + 4*cl + {0..3}  (k order of K_values)
+#pragma unroll
+        for (int p = 0; p < KP_MAXP - 1; ++p) {
+            const int pp = p - p0;
+            if (pp >= 0 && pp < np)
+                *(float4*)&wft[ql * KG_TS + pp * CIN + 4 * cl] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+        }
+        __syncthreads();
+        const int ngrp = np * CIN / 64;                 // groups of four 16-deep k-blocks (np*Cin is a multiple of 64)
+        // B: packed K_values, float4 index ((blk*4 + g) * COUT + n); blocks of this pass start at p0*CIN/16.  Every address
+        // is (wave-uniform block base, in scalar registers) + ONE 32-bit per-lane offset: a single address VGPR for all loads
+        const float4* bpass = (const float4*)Wp + (size_t)(p0 * CIN / 16) * 4 * COUT;
+        const unsigned boff = (unsigned)(g * COUT + 16 * wave + r16);
+        const float* ap = &wft[r16 * KG_TS + 4 * g];
+        constexpr unsigned BSTEP = 4u * COUT;           // float4s per k-block
+#define KG_BLOAD(GRP_, U_) (bpass + (size_t)((unsigned)(4 * (GRP_) + (U_)) * BSTEP))[boff]
+        float4 b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b0[u] = KG_BLOAD(0, u);
+        {
+            const int g1 = min(1, ngrp - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b1[u] = KG_BLOAD(g1, u);
+        }
+#define KG_CONSUME(BQ_, GI_)                                                                     \
+        do {                                                                                     \
+            float4 a_ = *(const float4*)&ap[16 * (4 * (GI_))];                                   \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                      \
+                const float4 an_ = *(const float4*)&ap[16 * (4 * (GI_) + (u < 3 ? u + 1 : u))];  \
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.x, BQ_[u].x, c0, 0, 0, 0);          \
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.y, BQ_[u].y, c1, 0, 0, 0);          \
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.z, BQ_[u].z, c0, 0, 0, 0);          \
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_.w, BQ_[u].w, c1, 0, 0, 0);          \
+                a_ = an_;                                                                        \
+            }                                                                                    \
+        } while (0)
+        int gi = 0;
+        for (; gi + 1 < ngrp; gi += 2) {
+            // a buffer is refilled (group gi+2 / gi+3, clamped: straight-line code, no branch between a load and its use)
+            // right after its multiplies are issued: every load has the other buffer's 16 multiplies (512 cycles) of cover
+            const int ga = min(gi + 2, ngrp - 1), gb = min(gi + 3, ngrp - 1);
+            KG_CONSUME(b0, gi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b0[u] = KG_BLOAD(ga, u);
+            KG_CONSUME(b1, gi + 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b1[u] = KG_BLOAD(gb, u);
+        }
+        if (gi < ngrp) KG_CONSUME(b0, gi);              // odd group count: the last group sits in b0
+#undef KG_CONSUME
+#undef KG_BLOAD
+    }
+    // ---- epilogue in the accumulator registers: C/D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + i ----
+    const int n = 16 * wave + r16;
+    const float cs = E.col_scale ? E.col_scale[n] : 1.f;
+    const float ch = E.col_shift ? E.col_shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * g + i;
+        const int gq = lq[row];
+        if (gq < 0) continue;
+        float v = (c0[i] + c1[i]) * (1.0f / fmaxf((float)lcnt[row], 1.0f));
+        v = v * cs + ch;
+        if (E.residual) v += E.residual[(size_t)gq * E.ldr + n];
+        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+        out[(size_t)gq * ldo + n] = v;
+    }
+}
+
+// Wp[blk][g][n][j] = W[16*blk + 4*g + j][n]   (K % 16 == 0): the B-operand order of kpconv_fused_kernel
+__global__ void __launch_bounds__(256) kp_pack_weights_kernel(const float* __restrict__ W, int K, int N, float* __restrict__ Wp) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)K * N) return;
+    const int j = (int)(t & 3);
+    const long long u = t >> 2;
+    const int n = (int)(u % N);
+    const long long v = u / N;
+    const int g = (int)(v & 3);
+    const long long blk = v >> 2;
+    Wp[t] = W[(size_t)(16 * blk + 4 * g + j) * N + n];
+}
+
+extern "C" int d3f_kpconv_pack_weights(const float* W, int K, int N, float* Wp, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 16 || (K % 16) || N < 1 || !W || !Wp) return D3F_ERR_ARG;
+    kp_pack_weights_kernel<<<d3f_cdiv((long long)K * N, 256), 256, 0, stream>>>(W, K, N, Wp);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// the fused kernel exists for the configuration of the shipped models only (kp_influences_t<true>); anything else takes the
+// two-kernel form (d3f_kpconv_aggregate + d3f_gemm_f32)
+extern "C" int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int influence, int aggregation) {
+    return (Cin == Cout && (Cin == 64 || Cin == 128) && kp_fast_config(num_kp, influence, aggregation)) ? 1 : 0;
+}
+
+extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                                const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                                float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,
+                                const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
+                                float alpha, float* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d3f_kpconv_fused_supported(Cin, Cout, num_kp, influence, aggregation)) return D3F_ERR_ARG;
+    if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < Cin || (ldf % 4) || num_kp < 1 || num_kp > KP_MAXP - 1 ||
+        influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || ldo < Cout ||
+        (residual && ldr < Cout))
+        return D3F_ERR_ARG;
+    if (Nq == 0) return D3F_OK;
+    if (!q || !s || !idx || !f || !rowpos || !kp_host || !W_packed || !out || (((uintptr_t)f | (uintptr_t)W_packed) & 15))
+        return D3F_ERR_ARG;
+    KpParams P;
+    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
+    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
+    P.aggregation = aggregation;
+    KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
+    const int blocks = d3f_cdiv(Nq, KG_TQ);
+#define D3F_KG(LQ_)                                                                                                         \
+    kpconv_fused_kernel<LQ_><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, E, out, \
+                                                                 ldo, Nq_dev, Ns_dev, q_order)
+    if (Cin == 64) D3F_KG(16); else D3F_KG(32);
+#undef D3F_KG
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -605,9 +878,14 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
     P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
     P.aggregation = aggregation;
     const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0);
-#define D3F_AGG(LQ_)                                                                                          \
-    kpconv_agg_vec4<LQ_><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, \
-                                                                      P, wf, inv_cnt, Nq_dev, Ns_dev, q_order)
+    const bool fast = kp_fast_config(num_kp, influence, aggregation);
+#define D3F_AGG(LQ_)                                                                                                        \
+    do {                                                                                                                    \
+        if (fast) kpconv_agg_vec4<LQ_, true><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, \
+                                                                                          rowpos, P, wf, inv_cnt, Nq_dev, Ns_dev, q_order); \
+        else kpconv_agg_vec4<LQ_, false><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf,   \
+                                                                                       rowpos, P, wf, inv_cnt, Nq_dev, Ns_dev, q_order); \
+    } while (0)
     if (vec && Cin == 4) D3F_AGG(1);
     else if (vec && Cin == 8) D3F_AGG(2);
     else if (vec && Cin == 16) D3F_AGG(4);

@@ -135,6 +135,51 @@ __global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict
 // query has ~120 candidates and ~40 hits: with a whole wavefront per query half the lanes idle in every phase and the kernel
 // is bound by the dependent memory round trips per wavefront, so packing several queries into a wavefront raises the work
 // in flight per round trip.  Lane groups are independent: shuffles use width LPQ, ballots are masked to the group.
+// ---- ordering of a query's hits: bitonic network over 64 keys, two per lane of a 32-lane group ----------------------------
+// The rows must come out ascending by (d2, index).  Counting ranks against every other hit costs m^2 comparisons fed by LDS
+// reads (m ~ 40-70: the larger half of this kernel's time); the keys (d2 bits << 32 | index: d2 >= +0, so its bit pattern
+// orders like the value; indices are unique) instead go through the 21 compare-exchange stages of a 64-key bitonic sort, in
+// registers: partners at distance 1 / 2 via DPP quad permutes, 4 / 8 / 16 via ds_swizzle (no LDS memory), distance 32 is the
+// lane's own second key.  Element e = 32*slot + lane ends up holding rank e.
+template <int J>
+__device__ __forceinline__ unsigned nb_xor_lane(unsigned v) {
+    if constexpr (J == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (J << 10) | 0x1F);                          // lane ^ J (bit mode)
+}
+template <int J>
+__device__ __forceinline__ void nb_cmpx(unsigned& hi, unsigned& lo, bool take_min) {
+    const unsigned phi = nb_xor_lane<J>(hi), plo = nb_xor_lane<J>(lo);
+    const bool p_less = (phi < hi) || (phi == hi && plo < lo);
+    const bool take_p = (take_min == p_less);       // keys are unique (or both the +inf padding): !p_less means p is greater
+    hi = take_p ? phi : hi;
+    lo = take_p ? plo : lo;
+}
+// lane: 0..31 inside the group; (h0,l0) = element lane, (h1,l1) = element 32 + lane
+__device__ __forceinline__ void nb_bitonic64(int lane, unsigned& h0, unsigned& l0, unsigned& h1, unsigned& l1) {
+#define NB_STAGE(K_, J_)                                                                         \
+    do {                                                                                         \
+        const bool low_ = (lane & (J_)) == 0;                                                    \
+        const bool up0_ = ((K_) >= 32) ? true : ((lane & (K_)) == 0);                            \
+        const bool up1_ = ((K_) == 64) ? true : (((K_) == 32) ? false : ((lane & (K_)) == 0));   \
+        nb_cmpx<J_>(h0, l0, up0_ == low_);                                                       \
+        nb_cmpx<J_>(h1, l1, up1_ == low_);                                                       \
+    } while (0)
+    NB_STAGE(2, 1);
+    NB_STAGE(4, 2); NB_STAGE(4, 1);
+    NB_STAGE(8, 4); NB_STAGE(8, 2); NB_STAGE(8, 1);
+    NB_STAGE(16, 8); NB_STAGE(16, 4); NB_STAGE(16, 2); NB_STAGE(16, 1);
+    NB_STAGE(32, 16); NB_STAGE(32, 8); NB_STAGE(32, 4); NB_STAGE(32, 2); NB_STAGE(32, 1);
+    {   // K = 64, J = 32: the partner is the lane's own other key; ascending for both
+        const bool swap = (h1 < h0) || (h1 == h0 && l1 < l0);
+        const unsigned th = swap ? h1 : h0, tl = swap ? l1 : l0;
+        h1 = swap ? h0 : h1; l1 = swap ? l0 : l1;
+        h0 = th; l0 = tl;
+    }
+    NB_STAGE(64, 16); NB_STAGE(64, 8); NB_STAGE(64, 4); NB_STAGE(64, 2); NB_STAGE(64, 1);
+#undef NB_STAGE
+}
+
 template <bool FIRST_ONLY, int LPQ>
 __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
 nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
@@ -194,22 +239,25 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     const unsigned long long lt = (1ull << lane) - 1ull;
     float bd2 = 3.4e38f;
     int bidx = 0x7fffffff;
-    // two candidate loads in flight per lane: the loads of consecutive steps are independent, only the hit compaction is
-    // sequential, so issue both before consuming either (halves the exposed memory round trips of this loop)
-    for (int v0 = 0; v0 < T; v0 += 2 * LPQ) {
-        float4 sp[2];
-        bool in[2];
+    // four candidate loads in flight per lane (a typical query's ~120 candidates in ONE round trip): the loads of consecutive
+    // steps are independent, only the hit compaction is sequential.  Straight-line loads: a lane beyond the list re-reads
+    // the list's first candidate (address clamp) instead of branching around the load.
+    constexpr int NLD = 4;
+    for (int v0 = 0; v0 < T; v0 += NLD * LPQ) {
+        float4 sp[NLD];
+        bool in[NLD];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int v = v0 + u * LPQ + lane;
-            in[u] = v < T;
+        for (int u = 0; u < NLD; ++u) {
+            const int vv = v0 + u * LPQ + lane;
+            in[u] = vv < T;
+            const int v = in[u] ? vv : 0;
             int t = v + off[0];
 #pragma unroll
             for (int j = 1; j < 9; ++j) t = (v >= pre[j]) ? v + off[j] : t;
-            sp[u] = in[u] ? sorted[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            sp[u] = sorted[t];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NLD; ++u) {
             if (v0 + u * LPQ >= T) break;   // group-uniform
             const float dx = __fsub_rn(qx, sp[u].x), dy = __fsub_rn(qy, sp[u].y), dz = __fsub_rn(qz, sp[u].z);
             const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -250,6 +298,17 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     if (m + lane < m4) { hd2[m + lane] = 3.4e38f; hidx[m + lane] = 0x7fffffff; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (LPQ == 32 && n <= 64 && cap >= 64) {      // group-uniform: the common case goes through the register network
+        unsigned h0 = 0xFFFFFFFFu, l0 = 0xFFFFFFFFu, h1 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu;
+        if (lane < m) { h0 = __float_as_uint(hd2[lane]); l0 = (unsigned)hidx[lane]; }
+        if (lane + 32 < m) { h1 = __float_as_uint(hd2[lane + 32]); l1 = (unsigned)hidx[lane + 32]; }
+        nb_bitonic64(lane, h0, l0, h1, l1);
+        const int mw = min(m, width);
+        if (lane < mw) row[lane] = (int)l0;
+        if (lane + 32 < mw) row[lane + 32] = (int)l1;
+        for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
+        return;
+    }
     for (int e0 = 0; e0 < m; e0 += LPQ) {
         const int ei = e0 + lane;
         if (ei < m) {
@@ -389,6 +448,76 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     if (first_only) { if (lpq == 64) D3F_NB(true, 64); else D3F_NB(true, 32); }
     else { if (lpq == 64) D3F_NB(false, 64); else D3F_NB(false, 32); }
 #undef D3F_NB
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ---- scoring of rigid-transform hypotheses against a built grid (downstream matching, registration.hip) --------------------
+// For hypothesis v and source point i: p = R_v s_i + t_v; its nearest support strictly inside `radius` (same fp32 metric as the
+// searches) is an inlier correspondence: count[v] += 1, sumd2[v] += d2 (fixed point, 2^-32 units: integer atomics make the
+// sum independent of the order of arrival).  One thread per (v, i); the grid must hold ONE cloud (B = 1).
+__global__ void __launch_bounds__(256) nb_score_kernel(const NbElem* __restrict__ el, const int* __restrict__ cell_start,
+                                                       const int* __restrict__ cell_base, const float4* __restrict__ sorted,
+                                                       const float* __restrict__ src, int Ns, const float* __restrict__ T, int V,
+                                                       float r2, int* __restrict__ count, unsigned long long* __restrict__ sumd2,
+                                                       int* __restrict__ nearest /* [Ns] or null, only meaningful for V == 1 */) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)V * Ns) return;
+    const int v = (int)(tid / Ns), i = (int)(tid % Ns);
+    const float* M = T + (size_t)v * 12;
+    const float sx = src[3 * (size_t)i], sy = src[3 * (size_t)i + 1], sz = src[3 * (size_t)i + 2];
+    const float qx = fmaf(M[0], sx, fmaf(M[1], sy, fmaf(M[2], sz, M[3])));
+    const float qy = fmaf(M[4], sx, fmaf(M[5], sy, fmaf(M[6], sz, M[7])));
+    const float qz = fmaf(M[8], sx, fmaf(M[9], sy, fmaf(M[10], sz, M[11])));
+    const NbElem e = el[0];
+    int cx, cy, cz;
+    nb_cell_of(e, qx, qy, qz, cx, cy, cz);
+    cx = min(max(cx, -2), e.dims[0] + 1);
+    cy = min(max(cy, -2), e.dims[1] + 1);
+    cz = min(max(cz, -2), e.dims[2] + 1);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, e.dims[0] - 1);
+    float bd2 = 3.4e38f;
+    int bidx = -1;
+    if (x0 <= x1) {
+        for (int j = 0; j < 9; ++j) {
+            const int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
+            if (y < 0 || y >= e.dims[1] || z < 0 || z >= e.dims[2]) continue;
+            const int rowbase = e.cbase + e.dims[0] * (y + e.dims[1] * z);
+            const int lo = d3f_scan_at(cell_start, cell_base, rowbase + x0), hi = d3f_scan_at(cell_start, cell_base, rowbase + x1 + 1);
+            for (int t = lo; t < hi; ++t) {
+                const float4 sp = sorted[t];
+                const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
+                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                const int si = __float_as_int(sp.w);
+                if (d2 < r2 && (d2 < bd2 || (d2 == bd2 && si < bidx))) { bd2 = d2; bidx = si; }
+            }
+        }
+    }
+    if (nearest && v == 0) nearest[i] = bidx;
+    if (bidx >= 0) {
+        atomicAdd(&count[v], 1);
+        atomicAdd(&sumd2[v], (unsigned long long)((double)bd2 * 4294967296.0));
+    }
+}
+
+// grid: built over the TARGET points (one cloud).  src f32[Ns,3]; T f32[V,12] row-major [R | t] per hypothesis.
+// count_dev i32[V] / sumd2_dev u64[V] (2^-32 units) are OVERWRITTEN; nearest_dev i32[Ns] (optional): the correspondence of
+// every source point under hypothesis 0 (-1: none inside the radius).
+extern "C" int d3f_neighbor_grid_score(const void* grid, size_t grid_bytes, int Nt, const float* src, int Ns, const float* T,
+                                       int V, float radius, int* count_dev, unsigned long long* sumd2_dev, int* nearest_dev,
+                                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nt < 0 || Ns < 0 || V < 0 || !(radius >= 0.f)) return D3F_ERR_ARG;
+    if (V == 0) return D3F_OK;
+    if (!grid || !T || !count_dev || !sumd2_dev || (Ns > 0 && !src)) return D3F_ERR_ARG;
+    NbGrid g = nb_carve((void*)grid, grid_bytes, Nt, 1);
+    if (!g.ok) return D3F_ERR_WORKSPACE;
+    int rc = d3f_fill_u32(count_dev, (size_t)V, 0u, stream);
+    if (rc != D3F_OK) return rc;
+    if ((rc = d3f_fill_u32(sumd2_dev, (size_t)V * 2, 0u, stream)) != D3F_OK) return rc;
+    if (Ns == 0) return D3F_OK;
+    nb_score_kernel<<<d3f_cdiv((long long)V * Ns, 256), 256, 0, stream>>>(g.el, g.cell_start, g.stmp, g.sorted, src, Ns, T, V,
+                                                                         radius * radius, count_dev, sumd2_dev, nearest_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

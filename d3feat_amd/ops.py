@@ -516,6 +516,65 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     return _tag(out, query_points)
 
 
+def kpconv_fused_supported(cin, cout, num_kp, KP_influence, aggregation_mode):
+    return bool(_lib.load().d3f_kpconv_fused_supported(int(cin), int(cout), int(num_kp), _INFLUENCE.get(KP_influence, -1),
+                                                       _AGGREGATION.get(aggregation_mode, -1)))
+
+
+def packed_kpconv_weights(K_values):
+    """K_values f32[num_kp, Cin, Cout] -> the k-block-packed copy d3f_kpconv_fused reads (made once per weight tensor and
+    version: the result rides on the tensor object, so a model's cached device weights are packed at their first use --
+    the engine's eager warm-up -- and never inside a captured graph)."""
+    cached = getattr(K_values, "_d3f_packed", None)
+    if cached is not None and cached[0] == K_values._version:
+        return cached[1]
+    lib = _lib.load()
+    num_kp, cin, cout = K_values.shape
+    W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
+    Wp = torch.empty_like(W)
+    _lib.check(lib.d3f_kpconv_pack_weights(W.data_ptr(), num_kp * cin, cout, Wp.data_ptr(), _stream(W.device)), "kpconv_pack_weights")
+    K_values._d3f_packed = (K_values._version, Wp)
+    return Wp
+
+
+def kpconv_fused(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
+                 KP_influence="linear", aggregation_mode="sum", col_scale=None, col_shift=None, residual=None,
+                 leaky=False, alpha=0.2):
+    """Whole KPConv (+ epilogue) for Cin == Cout in {64, 128} in one kernel (kpconv_fused_supported says when)."""
+    lib = _lib.load()
+    q = _req(query_points, torch.float32, "query_points", 2).contiguous()
+    s = _req(support_points, torch.float32, "support_points", 2).contiguous()
+    idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
+    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    kp = _kp_host(K_points)
+    num_kp, cin, cout = K_values.shape
+    if f.shape[1] != cin:
+        raise ValueError("kpconv_fused: features have %d channels, K_values expects %d" % (f.shape[1], cin))
+    Wp = packed_kpconv_weights(K_values)
+    Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
+    dev = q.device
+    out = torch.empty((Nq, cout), dtype=torch.float32, device=dev)
+    row_pos = torch.empty((max(Ns, 1),), dtype=torch.uint8, device=dev)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
+    st = _stream(dev)
+    nq_dev, ns_dev = _nd(query_points), _nd(support_points)
+    if ns_dev is None:
+        ns_dev = _nd(features)
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, cin, row_pos.data_ptr(), ns_dev, st), "row_positive")
+    with _timed("kpconv_fused", dict(Nq=Nq, Ns=Ns, K=K, Cin=cin, Cout=cout), dev):
+        rc = lib.d3f_kpconv_fused(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf, cin,
+                                  row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
+                                  _AGGREGATION[aggregation_mode], Wp.data_ptr(), cout,
+                                  col_scale.data_ptr() if col_scale is not None else None,
+                                  col_shift.data_ptr() if col_shift is not None else None,
+                                  residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
+                                  float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), st)
+    _lib.check(rc, "kpconv_fused")
+    return _tag(out, query_points)
+
+
 def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
                     KP_influence="linear", aggregation_mode="sum", col_scale=None, col_shift=None, residual=None,
                     leaky=False, alpha=0.2):

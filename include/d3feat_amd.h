@@ -15,6 +15,7 @@
 #define D3FEAT_AMD_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -182,6 +183,22 @@ int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int
                        const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
                        const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
 
+/* Whole KPConv_ops + epilogue in one kernel for Cin == Cout in {64, 128} (levels 1 and 2 of the shipped architecture), the
+ * [Nq, 15*Cin] weighted-feature tensor of kernels/convolution_ops.py:237-240 staying in LDS (tiles of 16 queries, passes of
+ * 512 k-values, v_mfma_f32_16x16x4_f32).  Only the configuration of the shipped models (linear influence, 'sum'
+ * aggregation, 15 kernel points): d3f_kpconv_fused_supported() says whether a call qualifies; otherwise use
+ * d3f_kpconv_aggregate + d3f_gemm_f32.  W_packed: K_values [15*Cin, Cout] reordered once by d3f_kpconv_pack_weights
+ * (Wp[blk][g][n][j] = W[16*blk + 4*g + j][n]: the MFMA B-operand order, one 16-byte load per lane and k-block).
+ * Arguments otherwise as d3f_kpconv_fused32. */
+int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int influence, int aggregation);
+int d3f_kpconv_pack_weights(const float* W, int K, int N, float* W_packed, void* stream);
+int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                     const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                     float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,
+                     const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
+                     float alpha, float* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
  * Replaces kernels/convolution_ops.py:90-99 (unary_convolution = tf.matmul) and :243-253 (the
@@ -260,6 +277,42 @@ int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int l
  * N is an upper bound when N_dev (device int) is given. */
 int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
                          int ldo, const int* N_dev, void* stream);
+
+/* =============================================================================================
+ * Downstream matching -- what the reference does with the descriptors after the hot path.
+ * ============================================================================================= */
+
+/* Nearest descriptor: idx[i] = argmin_j ||A_i - B_j||^2 (lowest j on ties, -1 when Nb == 0); d2_out (optional) the minimum.
+ * Replaces the argmin over the dense distance matrix of geometric_registration/evaluate.py:17-21 (one direction per call)
+ * and the KD-tree feature lookup inside open3d.registration_ransac_based_on_feature_matching (evaluate.py:93-99).
+ * A f32[Na,C] (lda), B f32[Nb,C] (ldb), C in {16, 32, 64}. */
+size_t d3f_feature_nn_workspace_bytes(int Na);
+int d3f_feature_nn(const float* A, int Na, int lda, const float* B, int Nb, int ldb, int C, int* idx, float* d2_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Mutually closest pairs (evaluate.py:21-26 build_correspondence): pairs (i, ab[i]) with ba[ab[i]] == i, ascending i.
+ * pairs i32[<= Na, 2]; count_dev i32[1] on the device. */
+size_t d3f_mutual_matches_workspace_bytes(int Na);
+int d3f_mutual_matches(const int* ab, int Na, const int* ba, int Nb, int* pairs, int* count_dev, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* RANSAC hypotheses of open3d.registration_ransac_based_on_feature_matching (demo_registration.py:184-192, evaluate.py:
+ * 93-99) for iterations it0 .. it0+H-1: sample ransac_n source points (counter-based random numbers: a pure function of
+ * (seed, iteration, draw) -- d3f_ransac_draw is the host copy), pair each with nn[.] (its nearest target FEATURE),
+ * CorrespondenceCheckerBasedOnEdgeLength(edge_similarity; <= 0: off), rigid fit without scaling
+ * (TransformationEstimationPointToPoint(False)), CorrespondenceCheckerBasedOnDistance(checker_distance; <= 0: off).
+ * T_out f32[H,12] row-major [R | t]; valid_out u8[H]. */
+int d3f_ransac_hypotheses(const float* src, int Ns, const float* tgt, int Nt, const int* nn, int ransac_n,
+                          float edge_similarity, float checker_distance, uint64_t seed, uint64_t it0,
+                          int H, float* T_out, unsigned char* valid_out, void* stream);
+int d3f_ransac_draw(uint64_t seed, uint64_t iteration, int d, int n);
+
+/* Fitness of V hypotheses (Open3D's GetRegistrationResultAndCorrespondences): for every transformed source point the
+ * nearest TARGET point strictly inside `radius` (grid built over the target by d3f_neighbor_grid_build, one cloud);
+ * count_dev i32[V] inliers, sumd2_dev u64[V] sum of squared distances in 2^-32 units (order independent),
+ * nearest_dev i32[Ns] (optional) the correspondences under hypothesis 0. */
+int d3f_neighbor_grid_score(const void* grid, size_t grid_bytes, int Nt, const float* src, int Ns, const float* T, int V,
+                            float radius, int* count_dev, uint64_t* sumd2_dev, int* nearest_dev, void* stream);
 
 #ifdef __cplusplus
 }

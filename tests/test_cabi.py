@@ -12,7 +12,7 @@ from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "d3feat_amd.h")
 
-_C2CT = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t}
+_C2CT = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64}
 
 
 def _declarations():

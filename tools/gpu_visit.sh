@@ -1,0 +1,58 @@
+#!/bin/bash
+# One GPU-box visit, sections chosen by name:  bash tools/gpu_visit.sh <tag> [tests] [smoke] [bench] [prof] [pmc] [proto] [x:<cmd>]
+#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh r02_v1 tests smoke bench prof'
+# Everything lands under gpurun_out/<tag>/ (merged back into the repo's gpurun_out/ by gpurun).
+TAG=${1:-run}; shift
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+{ rocm-smi --showproductname 2>/dev/null | head -8; nproc; } > $OUT/box.txt
+LEAN="--no-cpu-baseline --no-instrument --no-mirror-extra --no-pcie-extra"
+for SEC in "$@"; do
+case "$SEC" in
+tests)
+  timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -6 $OUT/tests.log;;
+tests-all)   # no -x: every failure of a visit in one go
+  timeout 1500 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -25 $OUT/tests.log;;
+smoke)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log;;
+bench)
+  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
+  python - <<PY
+import json
+try:
+    r = json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
+    print({k: r[k] for k in ("value", "ms_per_step", "parity", "vs_cpu_baseline")})
+    print({k: r["roofline"][k] for k in ("kernel", "achieved", "frac")})
+    print(r["roofline"]["timed_kernels_ms_per_step"])
+    print(r["cpu_baseline"])
+except Exception as e:
+    print("bench line unreadable:", e)
+PY
+  tail -3 $OUT/bench.err;;
+benchlean)
+  timeout 600 python bench.py $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err; cut -c1-160 $OUT/bench_lean.json;;
+prof)
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 64 --warmup 8 $LEAN > $OUT/prof_bench.json 2> $OUT/prof.err
+  cd $REPO
+  DB=$(ls $OUT/prof/*/*_results.db 2>/dev/null | head -1)
+  if [ -n "$DB" ]; then python tools/rocpd_summary.py $DB > $OUT/kernel_stats.csv; head -28 $OUT/kernel_stats.csv | cut -c1-150; fi
+  rm -rf $OUT/prof/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
+pmc)
+  cd /tmp
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 16 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_write.err
+  cd $REPO
+  python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json 2> $OUT/pmc_summary.err
+  head -c 600 $OUT/hbm_traffic.json
+  find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" -size +2M -delete;;
+proto)
+  for f in gemm_bf16x3 mfma_rate; do
+    [ -x tools/ubench/$f.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/ubench/$f.hip -o tools/ubench/$f.bin
+  done
+  timeout 200 tools/ubench/gemm_bf16x3.bin > $OUT/gemm_bf16x3.txt 2>&1; cat $OUT/gemm_bf16x3.txt;;
+x:*)
+  CMD="${SEC#x:}"; echo "== $CMD"; timeout 900 bash -c "$CMD" 2>&1 | tail -40;;
+esac
+done
+du -sh $OUT
