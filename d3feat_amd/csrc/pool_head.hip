@@ -483,4 +483,49 @@ extern "C" int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd
     return D3F_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage-0 ingestion: xyz out of raw file records on the GPU.  A binary PLY vertex element (demo_registration.py:23,
+// datasets/ThreeDMatch.py:348: float or double coordinates among other properties, either byte order) or a KITTI velodyne
+// sweep (datasets/KITTI.py:131: 16-byte records) is copied to the device AS BYTES; one thread per point picks the three
+// coordinates out of its record and writes the float32 [n,3] array the grid subsampler reads -- the host never touches the
+// payload.  double -> float is the round-to-nearest cast numpy's astype(float32) performs in the reference's loaders.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rec_coord(const unsigned char* __restrict__ p, int is_f64, int swap) {
+    if (is_f64) {
+        unsigned long long u = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) u |= (unsigned long long)p[swap ? 7 - b : b] << (8 * b);
+        return (float)__longlong_as_double((long long)u);
+    }
+    unsigned u = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) u |= (unsigned)p[swap ? 3 - b : b] << (8 * b);
+    return __uint_as_float(u);
+}
+
+__global__ void __launch_bounds__(256) decode_records_kernel(const unsigned char* __restrict__ raw, int n, int stride, int ox,
+                                                             int oy, int oz, int is_f64, int swap, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* r = raw + (size_t)i * stride;
+    out[3 * (size_t)i] = rec_coord(r + ox, is_f64, swap);
+    out[3 * (size_t)i + 1] = rec_coord(r + oy, is_f64, swap);
+    out[3 * (size_t)i + 2] = rec_coord(r + oz, is_f64, swap);
+}
+
+extern "C" int d3f_decode_xyz_records(const void* raw, int n, int stride, int off_x, int off_y, int off_z, int is_f64,
+                                      int big_endian, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int w = is_f64 ? 8 : 4;
+    if (n < 0 || stride < 3 * w || off_x < 0 || off_y < 0 || off_z < 0 || off_x + w > stride || off_y + w > stride ||
+        off_z + w > stride)
+        return D3F_ERR_ARG;
+    if (n == 0) return D3F_OK;
+    if (!raw || !out) return D3F_ERR_ARG;
+    decode_records_kernel<<<d3f_cdiv(n, 256), 256, 0, stream>>>((const unsigned char*)raw, n, stride, off_x, off_y, off_z,
+                                                                is_f64 ? 1 : 0, big_endian ? 1 : 0, out);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
 extern "C" int d3f_version(void) { return 200; }

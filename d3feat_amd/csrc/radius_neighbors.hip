@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256) nb_score_kernel(const NbElem* __restrict_
 // count_dev i32[V] / sumd2_dev u64[V] (2^-32 units) are OVERWRITTEN; nearest_dev i32[Ns] (optional): the correspondence of
 // every source point under hypothesis 0 (-1: none inside the radius).
 extern "C" int d3f_neighbor_grid_score(const void* grid, size_t grid_bytes, int Nt, const float* src, int Ns, const float* T,
-                                       int V, float radius, int* count_dev, unsigned long long* sumd2_dev, int* nearest_dev,
+                                       int V, float radius, int* count_dev, uint64_t* sumd2_dev, int* nearest_dev,
                                        void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nt < 0 || Ns < 0 || V < 0 || !(radius >= 0.f)) return D3F_ERR_ARG;
@@ -517,7 +517,7 @@ extern "C" int d3f_neighbor_grid_score(const void* grid, size_t grid_bytes, int 
     if ((rc = d3f_fill_u32(sumd2_dev, (size_t)V * 2, 0u, stream)) != D3F_OK) return rc;
     if (Ns == 0) return D3F_OK;
     nb_score_kernel<<<d3f_cdiv((long long)V * Ns, 256), 256, 0, stream>>>(g.el, g.cell_start, g.stmp, g.sorted, src, Ns, T, V,
-                                                                         radius * radius, count_dev, sumd2_dev, nearest_dev);
+                                                                         radius * radius, count_dev, (unsigned long long*)sumd2_dev, nearest_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256) rg_hypotheses_kernel(const float* __restr
 
 // H hypotheses for iterations it0 .. it0 + H - 1.  nn i32[Ns]: nearest target FEATURE of every source point.
 extern "C" int d3f_ransac_hypotheses(const float* src, int Ns, const float* tgt, int Nt, const int* nn, int ransac_n,
-                                     float edge_similarity, float checker_distance, unsigned long long seed,
-                                     unsigned long long it0, int H, float* T_out, unsigned char* valid_out, void* stream_) {
+                                     float edge_similarity, float checker_distance, uint64_t seed, uint64_t it0, int H,
+                                     float* T_out, unsigned char* valid_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Ns < 1 || Nt < 1 || ransac_n < 3 || ransac_n > RG_MAXN || H < 0) return D3F_ERR_ARG;
     if (H == 0) return D3F_OK;
@@ -277,6 +277,6 @@ extern "C" int d3f_ransac_hypotheses(const float* src, int Ns, const float* tgt,
 }
 
 // host copy of the sampler (bindings / tests draw the very same indices)
-extern "C" int d3f_ransac_draw(unsigned long long seed, unsigned long long iteration, int d, int n) {
+extern "C" int d3f_ransac_draw(uint64_t seed, uint64_t iteration, int d, int n) {
     return n > 0 ? rg_draw(seed, iteration, d, n) : -1;
 }

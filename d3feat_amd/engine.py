@@ -201,7 +201,10 @@ class FragmentEngine:
             sl.stream.wait_stream(cur)
             o = 0
             for p in parts:
-                sl.raw[o:o + p.shape[0]].copy_(p, non_blocking=True)
+                if isinstance(p, ops.RawRecords):      # file records: bytes to the device, xyz decoded in place (stage-0 ingestion)
+                    p.decode(self.device, out=sl.raw[o:o + p.shape[0]])
+                else:
+                    sl.raw[o:o + p.shape[0]].copy_(p, non_blocking=True)
                 o += int(p.shape[0])
             sl.raw_len.copy_(sl.host_n, non_blocking=True)
             sl.graph.replay()
@@ -264,6 +267,10 @@ class FragmentEngine:
         return outs[0] if sl.single else outs
 
     def run_eager(self, raw):
+        if isinstance(raw, ops.RawRecords):
+            raw = raw.decode(self.device)
+        elif isinstance(raw, (tuple, list)):
+            raw = tuple(r.decode(self.device) if isinstance(r, ops.RawRecords) else r for r in raw)
         if self.two:
             subs = [tfo.grid_subsampling(p if p.is_cuda else p.to(self.device), self.cfg.first_subsampling_dl) for p in raw]
             pts = torch.cat(subs, 0)

@@ -665,6 +665,49 @@ def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev, stack_group=0
     return _tag(desc, x), _tag(score, x)
 
 
+class RawRecords:
+    """A cloud still in its file encoding (utils.ply.read_ply_records / utils.results.read_kitti_records): raw bytes + record
+    layout.  FragmentEngine.submit takes it wherever it takes a float32 [n,3] cloud and decodes it on the GPU, straight into
+    the slot's stage-0 input buffer."""
+
+    def __init__(self, raw, layout, pin=True):
+        if not isinstance(raw, torch.Tensor):
+            raw = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.uint8))
+        if pin and not raw.is_cuda and torch.cuda.is_available():
+            raw = raw.pin_memory()
+        self.raw, self.layout = raw, dict(layout)
+        self.shape = (int(layout["n"]), 3)
+        self.is_cuda = raw.is_cuda
+
+    def decode(self, device=None, out=None):
+        return decode_xyz_records(self.raw if device is None or self.raw.is_cuda else self.raw.to(device, non_blocking=True),
+                                  self.layout, out=out)
+
+
+def decode_xyz_records(raw, layout, out=None):
+    """Raw file records (uint8 tensor on the device, or pinned / plain host bytes that are copied there asynchronously) ->
+    float32 [n,3] on the device.  layout: utils.ply.read_ply_records / utils.results.read_kitti_records."""
+    lib = _lib.load()
+    dev = out.device if out is not None else torch.device("cuda", torch.cuda.current_device())
+    if not isinstance(raw, torch.Tensor):
+        raw = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.uint8))
+    if not raw.is_cuda:
+        raw = raw.to(dev, non_blocking=True)
+    raw = raw.contiguous()
+    n, stride = int(layout["n"]), int(layout["stride"])
+    if raw.dtype != torch.uint8 or raw.numel() < n * stride:
+        raise ValueError("decode_xyz_records: %d bytes for %d records of %d bytes" % (raw.numel(), n, stride))
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    elif out.shape[0] < n or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("decode_xyz_records: output buffer too small or not contiguous float32")
+    ox, oy, oz = (int(v) for v in layout["offsets"])
+    rc = lib.d3f_decode_xyz_records(raw.data_ptr(), n, stride, ox, oy, oz, 1 if layout["dtype"] == "f8" else 0,
+                                    1 if layout.get("big_endian") else 0, out.data_ptr(), _stream(dev))
+    _lib.check(rc, "decode_xyz_records")
+    return out[:n]
+
+
 def pack_descriptors(xyz, desc, score):
     """-> f32[N, 3 + C + 1] records [xyz | desc | score] (one contiguous block per fragment of a stack)."""
     lib = _lib.load()

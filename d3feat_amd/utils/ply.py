@@ -73,6 +73,41 @@ def read_ply(filename, triangular_mesh=False):
         return [data, faces]
 
 
+def ply_vertex_count(filename):
+    """Number of vertices, from the header only (the sharded runner balances fragments by it without reading them)."""
+    with open(filename, 'rb') as f:
+        _, elements = _parse_header(f)
+    if not elements or elements[0][0] != 'vertex':
+        raise ValueError('first PLY element must be "vertex"')
+    return int(elements[0][1])
+
+
+def read_ply_records(filename):
+    """The vertex element as RAW bytes plus its record layout, for decoding on the GPU (ops.decode_xyz_records):
+    -> (uint8 array [n * stride], dict(n, stride, offsets=(ox, oy, oz), dtype='f4'|'f8', big_endian=bool))."""
+    with open(filename, 'rb') as f:
+        ext, elements = _parse_header(f)
+        if not elements or elements[0][0] != 'vertex':
+            raise ValueError('first PLY element must be "vertex"')
+        _, n, props = elements[0]
+        if any(p[0] == 'list' for p in props):
+            raise ValueError('list properties on vertices are not supported')
+        dt = np.dtype(props)
+        offs, kinds = [], set()
+        for ax in ('x', 'y', 'z'):
+            if ax not in dt.fields:
+                raise ValueError('PLY vertex element has no property "%s"' % ax)
+            fdt, off = dt.fields[ax][0], dt.fields[ax][1]
+            offs.append(int(off))
+            kinds.add(fdt.str[1:])
+        if len(kinds) != 1 or next(iter(kinds)) not in ('f4', 'f8'):
+            raise ValueError('x / y / z must share one floating type (float or double)')
+        raw = np.fromfile(f, dtype=np.uint8, count=n * dt.itemsize)
+        if raw.shape[0] != n * dt.itemsize:
+            raise ValueError('PLY file truncated')
+    return raw, dict(n=int(n), stride=int(dt.itemsize), offsets=tuple(offs), dtype=next(iter(kinds)), big_endian=(ext == '>'))
+
+
 def read_ply_xyz(filename):
     """float32 [N,3] of the x/y/z properties (contiguous)."""
     d = read_ply(filename)

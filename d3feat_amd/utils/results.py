@@ -14,6 +14,14 @@ def read_kitti_bin(path):
     return np.ascontiguousarray(raw.reshape(-1, 4)[:, :3])
 
 
+def read_kitti_records(path):
+    """One velodyne sweep as RAW bytes + record layout for ops.decode_xyz_records (16-byte records x, y, z, reflectance)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size % 16 != 0:
+        raise ValueError("%s: %d bytes, not a multiple of 16" % (path, raw.size))
+    return raw, dict(n=raw.size // 16, stride=16, offsets=(0, 4, 8), dtype='f4', big_endian=False)
+
+
 def select_first_cloud(points, features, scores, first_len):
     """The keypoint selection of utils/tester.py:208-213 / demo_registration.py:158-164 for a stacked self-pair: rows of the
     FIRST cloud (the reference indexes them through in_batches[0][:-1]), in ASCENDING score order as its np.argsort leaves

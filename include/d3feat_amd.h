@@ -278,6 +278,13 @@ int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int l
 int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
                          int ldo, const int* N_dev, void* stream);
 
+/* Stage-0 ingestion: float32 xyz [n,3] out of raw file records already on the device -- a binary PLY
+ * vertex element (demo_registration.py:23, datasets/ThreeDMatch.py:348; float or double coordinates at byte offsets
+ * off_x/y/z of `stride`-byte records, either byte order) or a KITTI velodyne sweep (datasets/KITTI.py:131, 277-278:
+ * stride 16, offsets 0/4/8).  The output feeds d3f_batch_grid_subsample directly. */
+int d3f_decode_xyz_records(const void* raw, int n, int stride, int off_x, int off_y, int off_z, int is_f64, int big_endian,
+                           float* out, void* stream);
+
 /* =============================================================================================
  * Downstream matching -- what the reference does with the descriptors after the hot path.
  * ============================================================================================= */
