@@ -199,12 +199,21 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     for (int j = 0; j < B; ++j) nq_real += qlens[j];
     if (wq >= min(Nq, nq_real)) return;   // Nq is the capacity, sum(qlens) the real number of queries
     if (pad == D3F_PAD_NUM_SUPPORTS) pad = *ns_dev;
-    // queries that ARE the supports are visited in cell order: neighbouring groups then share their candidate runs in L2
-    const int qi = qorder ? qorder[wq] : wq;
+    // queries that ARE the supports are visited in cell order: neighbouring groups then share their candidate runs in L2;
+    // the cell-sorted copy holds position AND index of the wq-th support in one 16-byte record, so the query needs no
+    // (order -> point) chain of dependent loads: one round trip less on the kernel's critical path
+    int qi = wq;
+    float qx, qy, qz;
+    if (qorder) {
+        const float4 me = sorted[wq];
+        qi = __float_as_int(me.w);
+        qx = me.x; qy = me.y; qz = me.z;
+    } else {
+        qx = q[3 * (size_t)qi]; qy = q[3 * (size_t)qi + 1]; qz = q[3 * (size_t)qi + 2];
+    }
     int b = 0;   // batch element of the query: the last one starting at or before qi (lens -> offsets on the fly, B is small)
     for (int j = 1, start = qlens[0]; j < B; ++j) { if (qi >= start) b = j; start += qlens[j]; }
     const NbElem e = el[b];
-    const float qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
     int cx, cy, cz;
     nb_cell_of(e, qx, qy, qz, cx, cy, cz);
     cx = min(max(cx, -2), e.dims[0] + 1);

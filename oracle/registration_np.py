@@ -42,8 +42,16 @@ def build_correspondence(source_desc, target_desc):
 
 
 def feature_nn(A, B):
-    d2 = ((A[:, None, :].astype(np.float64) - B[None, :, :].astype(np.float64)) ** 2).sum(-1)
-    return d2.argmin(1), d2.min(1)
+    """argmin_j ||A_i - B_j||^2 in float64 (|a|^2 + |b|^2 - 2 a.b, evaluated in row blocks: no [n, m, C] temporary)."""
+    A, B = A.astype(np.float64), B.astype(np.float64)
+    b2 = (B * B).sum(1)
+    idx, val = np.empty(len(A), np.int64), np.empty(len(A), np.float64)
+    for a in range(0, len(A), 2048):
+        blk = A[a:a + 2048]
+        d2 = np.maximum((blk * blk).sum(1)[:, None] + b2[None, :] - 2.0 * (blk @ B.T), 0.0)
+        idx[a:a + 2048] = d2.argmin(1)
+        val[a:a + 2048] = d2[np.arange(len(blk)), idx[a:a + 2048]]
+    return idx, val
 
 
 def kabsch(s, t):

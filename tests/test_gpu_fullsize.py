@@ -44,7 +44,7 @@ def test_config2_full_size_engine_vs_oracle(device, coracle):
     from d3feat_amd.utils.synthetic import room_fragment
     from oracle import network_np as onp
     from oracle import parity as par
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))     # more intra-op threads than that made the CPU graph slower
     cfg = threedmatch_config()
     W = build_variables(cfg, seed=42).values           # bench.py's weights
     raws_host = [room_fragment(s, n_raw=300000, edge=1.68) for s in range(4)]

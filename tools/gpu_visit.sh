@@ -10,13 +10,13 @@ LEAN="--no-cpu-baseline --no-instrument --no-mirror-extra --no-pcie-extra"
 for SEC in "$@"; do
 case "$SEC" in
 tests)
-  timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -6 $OUT/tests.log;;
+  timeout ${TESTS_TIMEOUT:-600} python -m pytest tests -m gpu -x -q --durations=15 > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -6 $OUT/tests.log;;
 tests-all)   # no -x: every failure of a visit in one go
-  timeout 1500 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -25 $OUT/tests.log;;
+  timeout ${TESTS_TIMEOUT:-600} python -m pytest tests -m gpu -q --durations=30 > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -60 $OUT/tests.log;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log;;
 bench)
-  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
+  timeout ${BENCH_TIMEOUT:-400} python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
   python - <<PY
 import json
 try:
