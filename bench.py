@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-mirror-extra", action="store_true", help="skip the secondary mirrored measurement")
     ap.add_argument("--no-pcie-extra", action="store_true", help="skip the secondary PCIe-inclusive measurement")
     ap.add_argument("--no-instrument", action="store_true", help="skip the per-launch HIP-event pass (clean rocprof runs)")
+    ap.add_argument("--ablate", default="", help="MEASUREMENT TOOL, results invalid: comma list of op families whose library calls "
+                    "are skipped (gemm, kpconv, maxpool, head, rowpos): the replay keeps its shape (sizes are device-resident and "
+                    "do not depend on feature values), so the throughput difference is that family's cost in the concurrent regime")
     ap.add_argument("--raw-points", type=int, default=300000, help="raw points per synthetic fragment (config #2: 300k)")
     ap.add_argument("--edge", type=float, default=1.68, help="room edge in metres (config #2: 1.68 -> ~30k pts at 0.03 m)")
     return ap.parse_args()
@@ -139,6 +142,9 @@ def main():
 
     cfg = threedmatch_config()
     W = build_variables(cfg, seed=42).values
+    if args.ablate:
+        install_ablation(args.ablate.split(","))
+        args.no_cpu_baseline = args.no_instrument = args.no_mirror_extra = args.no_pcie_extra = True
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     # synthetic fragments of this rank, raw points resident in HBM before timing starts; the first `pool` are cycled through
     # the timed region, the first `cpu_fragments` form the CPU / parity sample
@@ -331,6 +337,9 @@ def main():
         }
         if cpu:
             res["vs_cpu_baseline"] = round(res["value"] / cpu["value"], 2)
+        if args.ablate:
+            res = {"INVALID": "ablation run (--ablate %s): op families skipped, outputs are garbage" % args.ablate,
+                   "value": res["value"], "ms_per_step": res["ms_per_step"], "ablate": args.ablate}
         print(json.dumps(res))
         sys.stdout.flush()
     if dist.is_initialized():
@@ -342,6 +351,32 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def install_ablation(families):
+    """Replace the torch-level front ends of the named op families by allocations without a library call (bench.py --ablate)."""
+    import torch
+    from d3feat_amd import _lib, ops
+    lib = _lib.load()
+
+    class _Skip:
+        def __init__(self, names):
+            self.names = set(names)
+
+        def __getattr__(self, name):
+            if name in self.names:
+                return lambda *a, **k: 0
+            return getattr(lib, name)
+    skip = set()
+    for f in families:
+        skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32"},
+                 "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused"},
+                 "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_aggregate"},
+                 "kpconv32": {"d3f_kpconv_fused32"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
+                 "rowpos": {"d3f_row_positive"}, "maxpool": {"d3f_ind_max_pool"}, "head": {"d3f_detect_head"},
+                 "pack": {"d3f_pack_descriptors"}}[f.strip()]
+    proxy = _Skip(skip)
+    _lib.load = lambda: proxy
+
+
 def instrumented_pass(cfg, step, raws, Fp, npass, device):
     """Same stack shape as the timed region: F fragments per pass, op by op instead of a replayed graph (HIP events cannot
     be placed between the nodes of a graph).  -> (dominant-family roofline, all families, per-KPConv-layer table)."""

@@ -22,6 +22,7 @@
 //  * kpconv_agg_scalar: any other Cin, one thread per (query, channel).
 // Queries are visited in the cell-sorted order of the neighbour grid when the caller passes it (q_order).
 #include "common.h"
+#include <cstdlib>
 
 #define KP_MAXP D3F_NUM_KP_MAX  // 16 slots, 15 used by the reference
 
@@ -430,8 +431,8 @@ typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
 #define KF_HP 8                        // kernel points per contraction pass (the wf tile goes through LDS in two passes)
 #define KF_TS (KF_HP * 32 + 1)        // wf tile stride per query: odd, so the MFMA A-fragment column reads hit 32 banks
 
-template <bool FAST>
-__global__ void __launch_bounds__(256)
+template <bool FAST, int PF = 8>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
+__global__ void __launch_bounds__(256, PF == 4 ? 4 : 3)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                       int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                       KpParams P, const float* __restrict__ W, KpEpi E, float* __restrict__ out, int ldo,
@@ -485,26 +486,29 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
         // all eight feature rows of the chunk are requested before any is consumed: the gathers are independent, so their
         // latencies overlap instead of adding up (the kernel is bound by these round trips, not by the FMAs)
-        float4 fv[KF_LQ];
-        int ids[KF_LQ];
 #pragma unroll
-        for (int kk = 0; kk < KF_LQ; ++kk) {
-            ids[kk] = lidx[ql * KF_LQ + kk];
-            fv[kk] = ids[kk] >= 0 ? *(const float4*)&f[(size_t)ids[kk] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k1 = 0; k1 < KF_LQ; k1 += PF) {
+            float4 fv[PF];
+            int ids[PF];
 #pragma unroll
-        for (int kk = 0; kk < KF_LQ; ++kk) {
-            if (ids[kk] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
-            const float4* src = (const float4*)&lw[ql * KF_WS + kk * 16];
-            const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-            const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                 w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+            for (int u = 0; u < PF; ++u) {
+                ids[u] = lidx[ql * KF_LQ + k1 + u];
+                fv[u] = ids[u] >= 0 ? *(const float4*)&f[(size_t)ids[u] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int p = 0; p < KP_MAXP - 1; ++p) {
-                acc[p][0] = fmaf(w[p], fv[kk].x, acc[p][0]);
-                acc[p][1] = fmaf(w[p], fv[kk].y, acc[p][1]);
-                acc[p][2] = fmaf(w[p], fv[kk].z, acc[p][2]);
-                acc[p][3] = fmaf(w[p], fv[kk].w, acc[p][3]);
+            for (int u = 0; u < PF; ++u) {
+                if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
+                const float4* src = (const float4*)&lw[ql * KF_WS + (k1 + u) * 16];
+                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+                for (int p = 0; p < KP_MAXP - 1; ++p) {
+                    acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
+                    acc[p][1] = fmaf(w[p], fv[u].y, acc[p][1]);
+                    acc[p][2] = fmaf(w[p], fv[u].z, acc[p][2]);
+                    acc[p][3] = fmaf(w[p], fv[u].w, acc[p][3]);
+                }
             }
         }
         __syncthreads();
@@ -593,14 +597,18 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static std::atomic<unsigned long long> lds_done{0};
-    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true>, (const void*)kpconv_fused32_kernel<false>};
+    const void* const fns[3] = {(const void*)kpconv_fused32_kernel<true, 8>, (const void*)kpconv_fused32_kernel<true, 4>,
+                                (const void*)kpconv_fused32_kernel<false, 8>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-    if (kp_fast_config(num_kp, influence, aggregation))
-        kpconv_fused32_kernel<true><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E,
-                                                                               out, ldo, Nq_dev, Ns_dev, q_order);
-    else
-        kpconv_fused32_kernel<false><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E,
-                                                                                out, ldo, Nq_dev, Ns_dev, q_order);
+    // tuning knob (read once): D3F_KF_PF4=1 runs the shallow-prefetch variant (128 registers, four workgroups per CU)
+    static const int pf4 = [] { const char* e = getenv("D3F_KF_PF4"); return e ? atoi(e) : 0; }();
+#define D3F_KF(FAST_, PF_)                                                                                                   \
+    kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
+                                                                                 out, ldo, Nq_dev, Ns_dev, q_order)
+    if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
+    else if (pf4) D3F_KF(true, 4);
+    else D3F_KF(true, 8);
+#undef D3F_KF
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
@@ -633,8 +641,8 @@ typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
 // Registers: 60 accumulators + the gather prefetch decide the occupancy.  512-thread workgroups (Cin = 128) are two waves
 // per SIMD each: at more than 128 registers only ONE workgroup fits a CU and its gather and matrix phases cannot overlap with
 // anybody's, so that variant prefetches four rows instead of eight and is held to 128 registers (two workgroups per CU).
-template <int LQ>   // lanes per query = Cin / 4 (16 or 32); Cout == Cin; waves = LQ / 4 = Cout / 16
-__global__ void __launch_bounds__(KG_TQ * LQ, LQ == 32 ? 4 : 3)
+template <int LQ, int PF = (LQ == 32 ? 4 : 8)>   // lanes per query = Cin / 4 (16 or 32); Cout == Cin; waves = LQ / 4 = Cout / 16
+__global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)
 kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                     int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                     KpParams P, const float* __restrict__ Wp, KpEpi E, float* __restrict__ out, int ldo,
@@ -689,7 +697,6 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
         __syncthreads();
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3); PF feature rows requested before any is consumed ----
         const int kend = min(KC, K - k0);
-        constexpr int PF = LQ == 32 ? 4 : 8;
         for (int kg = 0; kg < kend; kg += PF) {
             float4 fv[PF];
             int ids[PF];
@@ -842,10 +849,14 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
     P.aggregation = aggregation;
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const int blocks = d3f_cdiv(Nq, KG_TQ);
-#define D3F_KG(LQ_)                                                                                                         \
-    kpconv_fused_kernel<LQ_><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, E, out, \
-                                                                 ldo, Nq_dev, Ns_dev, q_order)
-    if (Cin == 64) D3F_KG(16); else D3F_KG(32);
+#define D3F_KG(LQ_, PF_)                                                                                                    \
+    kpconv_fused_kernel<LQ_, PF_><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, E, \
+                                                                      out, ldo, Nq_dev, Ns_dev, q_order)
+    // tuning knob (read once): D3F_KG_PF4=1 runs the Cin = 64 variant with the shallow gather prefetch (128 registers, four
+    // workgroups per CU instead of three)
+    static const int pf4 = [] { const char* e = getenv("D3F_KG_PF4"); return e ? atoi(e) : 0; }();
+    if (Cin == 64) { if (pf4) D3F_KG(16, 4); else D3F_KG(16, 8); }
+    else D3F_KG(32, 4);
 #undef D3F_KG
     D3F_LAUNCH_CHECK();
     return D3F_OK;
