@@ -143,7 +143,6 @@ def main():
     cfg = threedmatch_config()
     W = build_variables(cfg, seed=42).values
     if args.ablate:
-        install_ablation(args.ablate.split(","))
         args.no_cpu_baseline = args.no_instrument = args.no_mirror_extra = args.no_pcie_extra = True
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     # synthetic fragments of this rank, raw points resident in HBM before timing starts; the first `pool` are cycled through
@@ -166,6 +165,8 @@ def main():
 
     model = KernelPointFCNN(None, cfg, weights=W, device=device)
     step = Step(cfg, model, limits, device)          # eager op-by-op path (instrumented pass, --eager)
+    if args.ablate:
+        install_ablation(args.ablate.split(","))     # after the calibration (which reads its results back)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -372,7 +373,9 @@ def install_ablation(families):
                  "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_aggregate"},
                  "kpconv32": {"d3f_kpconv_fused32"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
                  "rowpos": {"d3f_row_positive"}, "maxpool": {"d3f_ind_max_pool"}, "head": {"d3f_detect_head"},
-                 "pack": {"d3f_pack_descriptors"}}[f.strip()]
+                 "pack": {"d3f_pack_descriptors"},
+                 # geometry: only meaningful together with the whole network ablated (nothing consumes the index matrices then)
+                 "nb_search": {"d3f_neighbor_grid_search"}, "nb_build": {"d3f_neighbor_grid_build"}}[f.strip()]
     proxy = _Skip(skip)
     _lib.load = lambda: proxy
 

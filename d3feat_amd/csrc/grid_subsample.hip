@@ -21,7 +21,7 @@
 //     {bucket first-position (atomicMin), bucket sizes, reverse scan, rank inside bucket chain}, each fully
 //     parallel: rounds up to 1109 buckets run in ONE 1024-thread workgroup per batch element, larger rounds grid-wide
 //     (insert / tile scan + tile sums in its last workgroup / place);
-//   * 9 + 3*rounds launches per call (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
+//   * 7 + 3*rounds launches per call (points only; 9 + 3*rounds with features) (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
 //     (d3f_batch_grid_subsample_async) all sizes stay on the device and an overflowing call reports an empty result.
 #include "prims.h"
 
@@ -233,38 +233,44 @@ struct GsOrderArgs {
     int max_m;      // largest element the grid-wide rounds were launched for (capacity mode); larger ones are skipped
 };
 
+// All state of the small rounds (<= 1109 buckets, <= 1109 list entries) lives in LDS: the rounds are a chain of
+// {reset, insert with atomics, reverse scan, chain-rank placement} phases separated by barriers, and with the bucket arrays in
+// HBM every phase paid L2 round trips (225 us for the seven rounds of a 30 k-voxel cloud, on every fragment's critical path);
+// with LDS atomics a phase costs a few hundred cycles.  Only the final list (and the finished positions) go to memory.
+#define GS_SMALL_NB 1109   // D3F_CHAIN[GS_SMALL_LAST]
 __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int small_last) {
     __shared__ int wsum[16];
+    __shared__ int sBF[GS_SMALL_NB], sBC[GS_SMALL_NB], sBH[GS_SMALL_NB], sNX[GS_SMALL_NB], sCD[GS_SMALL_NB], sBK[GS_SMALL_NB];
+    __shared__ int sL[2][GS_SMALL_NB];
+    __shared__ unsigned long long sKey[GS_SMALL_NB];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int M = A.moffs[b + 1] - A.moffs[b];
     if (M <= 0) return;
     const unsigned long long* key = A.vkey + A.moffs[b];
-    int* NXT = A.nx + A.offs[b];
-    int* CD = A.cd + A.offs[b];
     int* VP = A.vpos + A.moffs[b];
     const long long bbase = A.el[b].bbase;
-    int lo = 0;
+    if (small_last > GS_SMALL_LAST) small_last = GS_SMALL_LAST;     // the LDS arrays are sized for 1109 buckets
+    for (int t = tid; t < min(M, GS_SMALL_NB); t += 1024) sKey[t] = key[t];
+    int lo = 0, cur = 0;
     bool done = false;
+    __syncthreads();
     for (int j = 0; j <= small_last && j < D3F_NCHAIN; ++j) {
         const int nb = (int)D3F_CHAIN_DEV[j];
         const double inv_nb = 1.0 / (double)nb;
         const bool last = M <= nb;
         const int hi = last ? M : nb;
-        int* La = A.P[j & 1] + A.offs[b];
-        int* Lb = A.P[(j + 1) & 1] + A.offs[b];
-        int* BF = A.bf[j & 1] + bbase;
-        int* BC = A.bc[j & 1] + bbase;
-        int* BH = A.bh[j & 1] + bbase;
-        for (int t = tid; t < nb; t += 1024) { BF[t] = 0x7fffffff; BC[t] = 0; BH[t] = -1; }
+        const int* La = sL[cur];
+        int* Lb = sL[cur ^ 1];
+        for (int t = tid; t < nb; t += 1024) { sBF[t] = 0x7fffffff; sBC[t] = 0; sBH[t] = -1; }
         __syncthreads();
         for (int t = tid; t < hi; t += 1024) {
-            const int id = (t < lo) ? gs_ld(&La[t]) : t;
-            const int bk = gs_mod(key[id], (unsigned)nb, inv_nb);
-            atomicMin(&BF[bk], t);
-            atomicAdd(&BC[bk], 1);
-            NXT[t] = atomicExch(&BH[bk], t);
-            A.bkt[A.offs[b] + t] = bk;
+            const int id = (t < lo) ? La[t] : t;
+            const int bk = gs_mod(sKey[id], (unsigned)nb, inv_nb);
+            atomicMin(&sBF[bk], t);
+            atomicAdd(&sBC[bk], 1);
+            sNX[t] = atomicExch(&sBH[bk], t);
+            sBK[t] = bk;
         }
         __syncthreads();
         int carry = 0;
@@ -272,8 +278,8 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
             const int u = c0 + tid, t = hi - 1 - u;
             int c = 0;
             if (u < hi) {
-                const int bk = gs_ld(&A.bkt[A.offs[b] + t]);
-                c = (gs_ld(&BF[bk]) == t) ? gs_ld(&BC[bk]) : 0;
+                const int bk = sBK[t];
+                c = (sBF[bk] == t) ? sBC[bk] : 0;
             }
             int x = c;
 #pragma unroll
@@ -291,26 +297,29 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
                 tot += v;
             }
             __syncthreads();
-            if (u < hi) CD[t] = carry + wbase + x - c;
+            if (u < hi) sCD[t] = carry + wbase + x - c;
             carry += tot;
         }
         __syncthreads();
         for (int t = tid; t < hi; t += 1024) {
-            const int id = (t < lo) ? gs_ld(&La[t]) : t;
-            const int bk = gs_ld(&A.bkt[A.offs[b] + t]);
+            const int id = (t < lo) ? La[t] : t;
+            const int bk = sBK[t];
             int r = 0;
-            for (int q = gs_ld(&BH[bk]); q >= 0; q = gs_ld(&NXT[q])) r += (q > t) ? 1 : 0;
-            const int dest = gs_ld(&CD[gs_ld(&BF[bk])]) + r;
+            for (int q = sBH[bk]; q >= 0; q = sNX[q]) r += (q > t) ? 1 : 0;
+            const int dest = sCD[sBF[bk]] + r;
             Lb[dest] = id;
             if (last) VP[id] = dest;
         }
         __syncthreads();
+        cur ^= 1;
         if (last) { done = true; break; }
         lo = hi;
     }
     if (!done && small_last + 1 < D3F_NCHAIN) {
-        // prepare the bucket arrays of the first grid-wide round
+        // hand over to the first grid-wide round j: it reads the current list from P[j & 1] and expects clean bucket arrays
         const int j = small_last + 1;
+        int* P = A.P[j & 1] + A.offs[b];
+        for (int t = tid; t < lo; t += 1024) P[t] = sL[cur][t];
         const int nb = (int)D3F_CHAIN_DEV[j];
         int* BF = A.bf[j & 1] + bbase;
         int* BC = A.bc[j & 1] + bbase;
@@ -503,6 +512,61 @@ __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__
     }
 }
 
+// Points-only form of the accumulation (every call of the hot path): one thread per voxel walks the voxel's chain ONCE,
+// orders the <= 32 point indices in its own LDS segment (chains come out nearly descending -- later points were pushed later --
+// so the insertion sort from the back is ~O(1) per element) and sums the points in ascending input order.  Replaces the
+// per-point in-chain rank (n link reads per POINT), the voxel-start scan and the `sorted` scatter / gather: n link reads and
+// n point reads per VOXEL.  Longer chains (> 32 points in one voxel) select the next index by repeated minimum over the chain.
+#define GS_ACC_MAX 32
+__global__ void __launch_bounds__(256) gs_accum_chain_kernel(const float* __restrict__ pts, int* __restrict__ status,
+                                                             const int* __restrict__ moffs, int B,
+                                                             const int* __restrict__ vhead, const int* __restrict__ pnext,
+                                                             const int* __restrict__ vcnt, const int* __restrict__ vpos,
+                                                             float* __restrict__ out_p, int out_cap) {
+    __shared__ int seg[256 * (GS_ACC_MAX + 1)];   // stride 33: the 64 lanes of a wave hit distinct banks
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= status[0]) return;
+    const int b = d3f_find_elem(moffs, B, v);
+    const int n = vcnt[v];
+    const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
+    if (dest >= (size_t)out_cap) {   // more voxels than the caller's output rows (capacity mode): report, never write
+        atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
+        return;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (n <= GS_ACC_MAX) {
+        int* a = seg + threadIdx.x * (GS_ACC_MAX + 1);   // descending order
+        int cnt = 0;
+        for (int j = vhead[v]; j >= 0 && cnt < GS_ACC_MAX; j = pnext[j]) {
+            int k = cnt;
+            while (k > 0 && a[k - 1] < j) { a[k] = a[k - 1]; --k; }
+            a[k] = j;
+            ++cnt;
+        }
+        for (int t = cnt - 1; t >= 0; --t) {
+            const size_t i = (size_t)a[t];
+            sx = __fadd_rn(sx, pts[3 * i + 0]);
+            sy = __fadd_rn(sy, pts[3 * i + 1]);
+            sz = __fadd_rn(sz, pts[3 * i + 2]);
+        }
+    } else {
+        int lastj = -1;
+        for (int t = 0; t < n; ++t) {
+            int best = 0x7fffffff;
+            for (int j = vhead[v]; j >= 0; j = pnext[j]) best = (j > lastj && j < best) ? j : best;
+            const size_t i = (size_t)best;
+            sx = __fadd_rn(sx, pts[3 * i + 0]);
+            sy = __fadd_rn(sy, pts[3 * i + 1]);
+            sz = __fadd_rn(sz, pts[3 * i + 2]);
+            lastj = best;
+        }
+    }
+    const float sc = (float)(1.0 / (double)n);  // `1.0 / v.second.count` is a double, narrowed by operator*(PointXYZ, float)
+    out_p[3 * dest + 0] = __fmul_rn(sx, sc);
+    out_p[3 * dest + 1] = __fmul_rn(sy, sc);
+    out_p[3 * dest + 2] = __fmul_rn(sz, sc);
+}
+
 // classes: the reference's max_element over unordered_map<int,int> compares (label, count) pairs, label
 // first, i.e. returns the LARGEST label id present in the voxel (grid_subsampling.cpp:94).
 __global__ void __launch_bounds__(256) gs_fill_kernel(int* __restrict__ p, size_t n, int v) {
@@ -643,9 +707,14 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
 
     gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, vbase, pvid, vkey, vhead, vcnt, pnext, offs + B);
     D3F_LAUNCH_CHECK();
-    if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, meta, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
-        return rc;
-    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
+    // points only (the hot path): the per-voxel accumulation walks the chains itself (gs_accum_chain_kernel); the in-chain
+    // rank / voxel-start scan / `sorted` list are needed only when features are averaged too (cpp_wrappers' compute())
+    const bool chain_accum = (fdim == 0);
+    if (!chain_accum) {
+        if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, meta, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
+            return rc;
+        gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
+    }
     // ---- libstdc++ iteration order ----
     // Rounds > GS_SMALL_LAST are spread grid-wide.  (Keeping ALL rounds in the single workgroup per element saves ~50 launches
     // per fragment but was measured slower end to end, 580 vs 640 fragments/s: the serial rounds of the 30 k-voxel stage sit
@@ -660,8 +729,12 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j * B);
         gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
     }
-    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
-                                                                     vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
+    if (chain_accum)
+        gs_accum_chain_kernel<<<d3f_cdiv(M, 256), 256, 0, stream>>>(points, meta, moffs, B, vhead, pnext, vcnt, A.vpos,
+                                                                               sub_points, M_cap);
+    else
+        gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
+                                                                         vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
     if (ldim > 0) {
         const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);
