@@ -587,123 +587,6 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     kf32_contract_epilogue(acc, ql, cl, tid, kf_smem, lcnt, lq, P, W, E, out, ldo);
 }
 
-// Software-pipelined form of kpconv_fused32_kernel for the shipped configuration (kp_influences_t<true>).  The two-phase
-// loop above pays, per chunk of 8 neighbours, two barriers and two chains of dependent memory round trips (index -> support
-// position before the influences; LDS index -> feature row before the multiply-adds), which is where the kernel's time went
-// (a quarter of the VALU peak).  Here nothing a chunk needs is requested inside that chunk:
-//   * A side (thread = query, neighbour slot): the neighbour index is loaded two chunks ahead, the support position and its
-//     row-positive flag one chunk ahead; the influences of chunk c are computed from registers filled an iteration earlier;
-//   * B side (thread = query, 4 channels): the 8 indices of the query's next chunk come straight from the index matrix (no
-//     LDS hand-off), and each half of the 8 feature rows is re-requested for chunk c+1 the moment its registers have been
-//     consumed for chunk c: 4-8 gathers are always in flight behind the 480 multiply-adds of a chunk;
-//   * the influences go through TWO LDS buffers, so one barrier per chunk separates writer and readers.
-#define KF_LW2 (2 * KF_TQ * KF_WS)      // floats: two influence buffers (>= the wf tile of the contraction)
-static_assert(KF_LW2 >= KF_TQ * KF_TS && KF_LW2 >= 4096, "LDS region must hold every life");
-
-__global__ void __launch_bounds__(256, 3)
-kpconv_fused32_pipe_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
-                           int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
-                           KpParams P, const float* __restrict__ W, KpEpi E, float* __restrict__ out, int ldo,
-                           const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
-    Nq = d3f_dyn(Nq, Nq_dev);
-    Ns = d3f_dyn(Ns, Ns_dev);
-    if ((int)(blockIdx.x * KF_TQ) >= Nq) return;
-    extern __shared__ __attribute__((aligned(16))) float kf_smem[];
-    int* lcnt = (int*)(kf_smem + KF_LW2);                   // [32]
-    int* lq = lcnt + KF_TQ;                                 // [32] global query index of each tile row
-    const int tid = threadIdx.x;
-    const int ql = tid / KF_LQ, cl = tid % KF_LQ;
-    const int qslot = blockIdx.x * KF_TQ + ql;
-    const bool live = qslot < Nq;
-    const int qg = (q_order && live) ? q_order[qslot] : (live ? qslot : 0);
-    if (tid < KF_TQ) lcnt[tid] = 0;
-    if (cl == 0) lq[ql] = live ? qg : -1;
-    float acc[KP_MAXP - 1][4];
-#pragma unroll
-    for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
-    const float qx = q[3 * (size_t)qg], qy = q[3 * (size_t)qg + 1], qz = q[3 * (size_t)qg + 2];
-    const int* row = idx + (size_t)qg * ld_idx;
-    const int nch = (K + KF_LQ - 1) / KF_LQ;
-    // neighbour index of slot k of this thread's query: -1 for a dead row, a column beyond K or a shadow neighbour
-    auto nb_at = [&](int k) -> int {
-        const int v = row[min(k, K - 1)];
-        return (live && k < K && v >= 0 && v < Ns) ? v : -1;
-    };
-    // ---- prologue: A side = chunk 0 position + chunk 1 index; B side = chunk 0 indices and feature rows
-    int idA = K > 0 ? nb_at(cl) : -1;
-    int idA_n = K > 0 ? nb_at(KF_LQ + cl) : -1;
-    float ax, ay, az;
-    unsigned char arp;
-    {
-        const size_t o3 = 3 * (size_t)max(idA, 0);
-        ax = s[o3]; ay = s[o3 + 1]; az = s[o3 + 2];
-        arp = rowpos[max(idA, 0)];
-    }
-    int ids[KF_LQ];
-    float4 fv[KF_LQ];
-#pragma unroll
-    for (int u = 0; u < KF_LQ; ++u) {
-        ids[u] = K > 0 ? nb_at(u) : -1;
-        fv[u] = *(const float4*)&f[(size_t)max(ids[u], 0) * ldf + 4 * cl];
-    }
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        float* lw = kf_smem + (c & 1) * (KF_TQ * KF_WS);
-        // ---- A side: requests for the chunks ahead (consumed one iteration later), then the influences of chunk c ----
-        const int idA_nn = nb_at((c + 2) * KF_LQ + cl);
-        const size_t o3n = 3 * (size_t)max(idA_n, 0);
-        const float nx = s[o3n], ny = s[o3n + 1], nz = s[o3n + 2];
-        const unsigned char nrp = rowpos[max(idA_n, 0)];
-        {
-            float w[KP_MAXP];
-            if (idA >= 0) {
-                kp_influences_t<true>(P, ax - qx, ay - qy, az - qz, w);
-                if (arp) atomicAdd(&lcnt[ql], 1);
-            } else {
-#pragma unroll
-                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
-            }
-            float4* dst = (float4*)&lw[ql * KF_WS + cl * 16];
-            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
-            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
-            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
-            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
-        }
-        __syncthreads();
-        // ---- B side: the next chunk's indices, then chunk c in two halves, each half re-requested for chunk c+1 when consumed
-        int idn[KF_LQ];
-#pragma unroll
-        for (int u = 0; u < KF_LQ; ++u) idn[u] = nb_at((c + 1) * KF_LQ + u);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int u = 4 * h; u < 4 * h + 4; ++u) {
-                if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
-                const float4* src = (const float4*)&lw[ql * KF_WS + u * 16];
-                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-#pragma unroll
-                for (int p = 0; p < KP_MAXP - 1; ++p) {
-                    acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
-                    acc[p][1] = fmaf(w[p], fv[u].y, acc[p][1]);
-                    acc[p][2] = fmaf(w[p], fv[u].z, acc[p][2]);
-                    acc[p][3] = fmaf(w[p], fv[u].w, acc[p][3]);
-                }
-            }
-#pragma unroll
-            for (int u = 4 * h; u < 4 * h + 4; ++u) {
-                ids[u] = idn[u];
-                fv[u] = *(const float4*)&f[(size_t)max(ids[u], 0) * ldf + 4 * cl];
-            }
-        }
-        idA = idA_n; ax = nx; ay = ny; az = nz; arp = nrp;
-        idA_n = idA_nn;
-    }
-    __syncthreads();   // the influence buffers are dead: the region becomes the wf tile
-    kf32_contract_epilogue(acc, ql, cl, tid, kf_smem, lcnt, lq, P, W, E, out, ldo);
-}
-
 extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                                   const float* f, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
                                   float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
@@ -723,7 +606,6 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
-    const size_t lds_pipe = (size_t)KF_LW2 * sizeof(float) + (size_t)(2 * KF_TQ) * sizeof(int);
     static std::atomic<unsigned long long> lds_done{0};
     const void* const fns[3] = {(const void*)kpconv_fused32_kernel<true, 8>, (const void*)kpconv_fused32_kernel<true, 4>,
                                 (const void*)kpconv_fused32_kernel<false, 8>};
@@ -733,15 +615,7 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 #define D3F_KF(FAST_, PF_)                                                                                                   \
     kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
                                                                                  out, ldo, Nq_dev, Ns_dev, q_order)
-    // tuning knob (read once): D3F_KF_PIPE=0 falls back to the two-phase kernel for the shipped configuration too
-    static const int pipe = [] { const char* e = getenv("D3F_KF_PIPE"); return e ? atoi(e) : 1; }();
-    static std::atomic<unsigned long long> lds_done2{0};
-    const void* const fns2[1] = {(const void*)kpconv_fused32_pipe_kernel};
-    if (d3f_opt_in_lds(lds_done2, fns2, (int)lds_pipe) != D3F_OK) return D3F_ERR_HIP;
     if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
-    else if (pipe && K > 0 && Ns > 0)
-        kpconv_fused32_pipe_kernel<<<d3f_cdiv(Nq, KF_TQ), 256, lds_pipe, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W,
-                                                                                 E, out, ldo, Nq_dev, Ns_dev, q_order);
     else if (pf4) D3F_KF(true, 4);
     else D3F_KF(true, 8);
 #undef D3F_KF

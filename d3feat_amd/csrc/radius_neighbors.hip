@@ -186,7 +186,7 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                  const float4* __restrict__ sorted,
                  const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
-                 int ld, int width, int cap, int* __restrict__ status) {
+                 int ld, int width, int cap, int* __restrict__ status, int want_kmax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QPB = 64 * NB_WAVES_PER_BLOCK / LPQ;   // queries per workgroup
     const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
@@ -285,7 +285,7 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     if (lane == 0) {
         // one shared word: an unconditional atomic per query serialises at ~12 ns each in L2 (60k queries = 0.7 ms);
         // read first, update only when this query raises the maximum (a handful of times per launch)
-        if (n > __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[0], n);
+        if (want_kmax && n > __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[0], n);
         if (!FIRST_ONLY && n > cap) atomicOr(&status[1], D3F_ST_HIT_OVERFLOW);
     }
     int* row = out + (size_t)qi * ld;
@@ -434,7 +434,8 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
     if (!grid || !status_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
     if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
-    if (reset_status) { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
+    if (reset_status & 1) { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
+    const int want_kmax = (reset_status & D3F_NB_NO_KMAX) ? 0 : 1;
     if (Nq == 0) return D3F_OK;
     NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
     if (!g.ok) return D3F_ERR_WORKSPACE;
@@ -453,7 +454,7 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
 #define D3F_NB(FO_, LPQ_)                                                                                              \
     nb_search_kernel<FO_, LPQ_><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                                      \
         queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
-        kcap, status_dev)
+        kcap, status_dev, want_kmax)
     if (first_only) { if (lpq == 64) D3F_NB(true, 64); else D3F_NB(true, 32); }
     else { if (lpq == 64) D3F_NB(false, 64); else D3F_NB(false, 32); }
 #undef D3F_NB

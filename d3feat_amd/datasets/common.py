@@ -135,7 +135,7 @@ class Dataset:
                 if getattr(s, 'order', None) is None:
                     s.order = grid.order   # cell-sorted visiting order of this level's points (ops._order)
             out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)],
-                                      reset_status=False)
+                                      reset_status=False, want_kmax=False)
             pending.append(status)
             return out
 

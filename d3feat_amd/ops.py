@@ -267,9 +267,10 @@ class NeighborGrid:
         self.order = self.mem[off: off + 4 * max(self.Ns, 1)].view(torch.int32)
 
     def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None,
-               reset_status=True):
+               reset_status=True, want_kmax=True):
         """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation.  reset_status=False: the caller has
-        zeroed `status` (saves one launch per search)."""
+        zeroed `status` (saves one launch per search).  want_kmax=False: status[0] (largest neighbour count) is not maintained
+        (callers that allocate a fixed number of columns do not need it; see D3F_NB_NO_KMAX)."""
         lib = _lib.load()
         queries = _req(queries, torch.float32, "queries", 2).contiguous()
         dev = queries.device
@@ -290,7 +291,8 @@ class NeighborGrid:
             rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
                                               ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),
                                               int(pad_value), int(cap),
-                                              1 if first_only else 0, 1 if reset_status else 0, status.data_ptr(),
+                                              1 if first_only else 0, (1 if reset_status else 0) | (0 if want_kmax else 2),
+                                              status.data_ptr(),
                                               _stream(dev))
         _lib.check(rc, "neighbor_grid_search")
         o = getattr(queries, "order", None)

@@ -35,6 +35,7 @@ extern "C" {
 
 /* pad_value of the neighbour searches meaning "the number of supports as known on the DEVICE" (sum of s_lens_dev) --
  * what BatchOrderedNeighbors pads with (neighbors.cpp:324) when the host only knows an upper bound of Ns */
+#define D3F_NB_NO_KMAX 2
 #define D3F_PAD_NUM_SUPPORTS (-2147483647 - 1)
 
 #define D3F_MAX_BATCH 255        /* batch elements per stacked call */
@@ -127,8 +128,11 @@ int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* suppor
  *       first_only            1: only column 0 (the nearest support, ties by index) is computed -- all that
  *                             closest_pool reads of the upsampling matrices (models/network_blocks.py:81);
  *                             columns 1..width-1 are filled with pad_value
- *       reset_status          1: status_dev is zeroed first (one extra launch); 0: the caller zeroed it (a captured
- *                             fragment zeroes the status words of all its ops with one fill)
+ *       reset_status          bit 0: status_dev is zeroed first (one extra launch); clear: the caller zeroed it (a
+ *                             captured fragment zeroes the status words of all its ops with one fill).
+ *                             bit 1 (D3F_NB_NO_KMAX): status_dev[0] (the largest neighbour count, which only callers that
+ *                             size their output by it need) is NOT maintained -- every query otherwise reads one shared
+ *                             word through L2, a same-address hot spot that serialises the whole launch
  */
 size_t d3f_neighbor_grid_bytes(int Ns, int B);
 /* byte offset inside a built grid of `order` i32[Ns]: the support indices sorted by cell.  Passing it as q_order /
