@@ -85,6 +85,25 @@ static inline bool kp_fast_config(int num_kp, int influence, int aggregation) {
     return num_kp == KP_MAXP - 1 && influence == 1 && aggregation == 0;
 }
 
+// The 16 influences of one (query, neighbour) pair in LDS: four 16-byte quads at base + 16*slot floats.  Eight adjacent
+// lanes store their pairs with ds_write_b128 at a 64-byte stride, i.e. on two bank groups only (4-way conflict: a third of the
+// LDS-active cycles of these kernels); rotating the quad order by slot/2 spreads them over all eight.  Readers undo it.
+__device__ __forceinline__ void kp_store_w(float* __restrict__ pair_base, int slot, const float* w) {
+    float4* dst = (float4*)pair_base;
+    const int r = slot >> 1;
+    dst[(0 + r) & 3] = make_float4(w[0], w[1], w[2], w[3]);
+    dst[(1 + r) & 3] = make_float4(w[4], w[5], w[6], w[7]);
+    dst[(2 + r) & 3] = make_float4(w[8], w[9], w[10], w[11]);
+    dst[(3 + r) & 3] = make_float4(w[12], w[13], w[14], w[15]);
+}
+__device__ __forceinline__ void kp_load_w(const float* __restrict__ pair_base, int slot, float* w) {
+    const float4* src = (const float4*)pair_base;
+    const int r = slot >> 1;
+    const float4 w0 = src[(0 + r) & 3], w1 = src[(1 + r) & 3], w2 = src[(2 + r) & 3], w3 = src[(3 + r) & 3];
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+    w[8] = w2.x; w[9] = w2.y; w[10] = w2.z; w[11] = w2.w; w[12] = w3.x; w[13] = w3.y; w[14] = w3.z; w[15] = w3.w;
+}
+
 // row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
 // the support row, so it is evaluated once per support instead of once per (query, neighbour).
 // The test is discontinuous: a row whose fp32 sum lies within rounding of 0 flips with the summation order, and the
@@ -149,11 +168,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
             lidx[ql * KC + cl] = id;
-            float4* dst = (float4*)&lw[ql * WS + cl * 16];
-            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
-            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
-            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
-            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
+            kp_store_w(&lw[ql * WS + cl * 16], cl, w);
         }
         __syncthreads();
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
@@ -172,10 +187,8 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 if (ids[u] < 0) continue;   // shadow neighbour: influence 0, feature row 0
-                const float4* src = (const float4*)&lw[ql * WS + (kg + u) * 16];
-                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                float w[16];
+                kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
 #pragma unroll
                 for (int p = 0; p < KP_MAXP - 1; ++p) {
                     acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
@@ -547,11 +560,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
             lidx[ql * KF_LQ + cl] = id;
-            float4* dst = (float4*)&lw[ql * KF_WS + cl * 16];
-            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
-            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
-            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
-            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
+            kp_store_w(&lw[ql * KF_WS + cl * 16], cl, w);
         }
         __syncthreads();
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
@@ -569,10 +578,8 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
-                const float4* src = (const float4*)&lw[ql * KF_WS + (k1 + u) * 16];
-                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                float w[16];
+                kp_load_w(&lw[ql * KF_WS + (k1 + u) * 16], k1 + u, w);
 #pragma unroll
                 for (int p = 0; p < KP_MAXP - 1; ++p) {
                     acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
@@ -698,11 +705,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
             lidx[ql * KC + cl] = id;
-            float4* dst = (float4*)&lw[ql * WS + cl * 16];
-            dst[0] = make_float4(w[0], w[1], w[2], w[3]);
-            dst[1] = make_float4(w[4], w[5], w[6], w[7]);
-            dst[2] = make_float4(w[8], w[9], w[10], w[11]);
-            dst[3] = make_float4(w[12], w[13], w[14], w[15]);
+            kp_store_w(&lw[ql * WS + cl * 16], cl, w);
         }
         __syncthreads();
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3); PF feature rows requested before any is consumed ----
@@ -718,10 +721,8 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
-                const float4* src = (const float4*)&lw[ql * WS + (kg + u) * 16];
-                const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-                const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                     w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                float w[16];
+                kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
 #pragma unroll
                 for (int p = 0; p < KP_MAXP - 1; ++p) {
                     acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);

@@ -32,6 +32,7 @@ struct NbElem {
 };
 
 #define NB_WAVES_PER_BLOCK 4
+#define NB_EL_LDS 18      // batch elements whose grid geometry fits the search kernel's LDS copy (256 threads x 4 bytes / 56)
 
 // one thread per element: choose the cell edge (>= radius*(1+2^-20); doubled until the element's grid fits
 // its share of the cell budget), grid dims and cell base.
@@ -195,6 +196,14 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     float* hd2 = (float*)smem + (size_t)grp * 2 * cap;
     int* hidx = (int*)hd2 + cap;
     const int wq = blockIdx.x * QPB + grp;
+    // the per-element grid geometry (a handful of 56-byte records) is staged in LDS by the workgroup's first lanes while the
+    // queries' own first loads are in flight: el[b] then costs an LDS read instead of a dependent memory round trip
+    __shared__ NbElem sel[NB_EL_LDS];
+    if (B <= NB_EL_LDS) {
+        constexpr int W = (int)(sizeof(NbElem) / sizeof(int));
+        if ((int)threadIdx.x < B * W) ((int*)sel)[threadIdx.x] = ((const int*)el)[threadIdx.x];
+        __syncthreads();
+    }
     int nq_real = 0;
     for (int j = 0; j < B; ++j) nq_real += qlens[j];
     if (wq >= min(Nq, nq_real)) return;   // Nq is the capacity, sum(qlens) the real number of queries
@@ -213,7 +222,7 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     }
     int b = 0;   // batch element of the query: the last one starting at or before qi (lens -> offsets on the fly, B is small)
     for (int j = 1, start = qlens[0]; j < B; ++j) { if (qi >= start) b = j; start += qlens[j]; }
-    const NbElem e = el[b];
+    const NbElem e = (B <= NB_EL_LDS) ? sel[b] : el[b];
     int cx, cy, cz;
     nb_cell_of(e, qx, qy, qz, cx, cy, cz);
     cx = min(max(cx, -2), e.dims[0] + 1);
