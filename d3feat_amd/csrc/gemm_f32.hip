@@ -812,3 +812,185 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
+
+// =====================================================================================================================
+// bf16-operand contraction (BASELINE.json configs[4]: batched inference, "bf16 features with MFMA contraction").
+//
+// Same operator as d3f_gemm_f32 / d3f_gemm_upsample_cat_f32 -- same composite A operand, same epilogue -- but both operands are
+// rounded to bfloat16 (round to nearest even) on their way into LDS and multiplied with v_mfma_f32_32x32x16_bf16, fp32
+// accumulate: 16x the fp32 matrix rate, which turns every contraction of the network from matrix-pipe bound into memory
+// bound.  NOT the fp32 path's arithmetic: each product carries the 2^-9 relative rounding of its operands, so results are
+// compared with the fp32 oracle at a documented, looser tolerance (tests/test_gpu_bf16.py) and are reported as a separate
+// bench configuration, never as the fp32 headline.
+//   A  f32 (activations stay fp32 in HBM; converted while staging)     W  pre-packed once: bf16 [N][Kp], k contiguous,
+//   Kp = K rounded up to 32 and zero padded (d3f_gemm_pack_bf16), so A and W tiles are staged by the same code:
+//   rows = output index, 32 k-values = 64 bytes per row and stage, row stride 80 bytes in LDS (16-byte aligned fragments,
+//   the 16 lanes of a ds_read_b128 group on 16 distinct 4-bank slots).
+// Workgroup 256 threads = 2 x 2 wavefronts x one 32x32 accumulator tile; BK = 32 (two MFMAs per stage and wave), double
+// buffered.  Skinny deep layers reuse the fp32 kernel's K split (slabs + ordered reduction).
+// =====================================================================================================================
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+#define GB_BK 32
+#define GB_LS 40          // LDS row stride in bf16 elements (80 bytes)
+
+__device__ __forceinline__ unsigned gb_rne(float f) {          // fp32 -> bf16 bits, round to nearest even (NaN stays NaN)
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned gb_pack2(float a, float b) { return gb_rne(a) | (gb_rne(b) << 16); }
+
+__global__ void __launch_bounds__(256) gemm_pack_bf16_kernel(const float* __restrict__ B, int ldb, int K, int N, int Kp,
+                                                             unsigned short* __restrict__ Wt) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * Kp) return;
+    const int n = (int)(t / Kp), k = (int)(t % Kp);
+    Wt[t] = (unsigned short)(k < K ? gb_rne(B[(size_t)k * ldb + n]) : 0u);
+}
+
+extern "C" int d3f_gemm_pack_bf16(const float* B, int ldb, int K, int N, void* Wt, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 1 || N < 1 || ldb < N || !B || !Wt) return D3F_ERR_ARG;
+    const int Kp = (K + GB_BK - 1) / GB_BK * GB_BK;
+    gemm_pack_bf16_kernel<<<d3f_cdiv((long long)N * Kp, 256), 256, 0, stream>>>(B, ldb, K, N, Kp, (unsigned short*)Wt);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+__global__ void __launch_bounds__(256)
+gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wt, int Kp, float* __restrict__ C,
+                 int ldc, int M, int N, int K, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
+                 const int* __restrict__ M_dev, GemmGather G) {
+    constexpr int BM = 64, BN = 64;
+    const int Mcap = M;
+    M = d3f_dyn(M, M_dev);
+    if ((int)(blockIdx.z * BM) >= M) return;   // capacity-sized grid (row tile = slowest dispatch dimension, as gemm_fast_kernel)
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * GB_LS];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * GB_LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.z * BM, n0 = blockIdx.x * BN;
+    const int nt_all = Kp / GB_BK;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_end = min(nt_all, t_begin + tiles_per_split);
+    // staging roles: A tile 64 rows x 32 k fp32 = 512 float4 slots -> 2 per thread (row = slot / 8, k4 = slot % 8);
+    //                W tile 64 rows x 32 k bf16 = 256 uint4 slots (8 bf16 each) -> 1 per thread (row = tid / 4, k8 = tid % 4)
+    int srow[2];
+    {
+        const int n1 = d3f_dyn(G.N1, G.N1_dev);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gm = m0 + ((tid + i * 256) >> 3);
+            int sr = gm < M ? gm : -1;
+            if (G.gidx && sr >= 0) {
+                sr = G.gidx[(size_t)gm * G.ld_gidx];
+                if (sr < 0 || sr >= n1) sr = -1;      // shadow neighbour: zero row
+            }
+            srow[i] = sr;
+        }
+    }
+    const int brow = n0 + (tid >> 2);
+    float4 ra[2];
+    uint4 rb;
+    auto load_tile = [&](int t) {
+        const int k0 = t * GB_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256;
+            const int gm = m0 + (e >> 3), k = k0 + ((e & 7) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < M && k < K) {                 // (K, K1 and the leading dimensions are multiples of 4: checked by the launcher)
+                if (G.A2 && k >= G.K1) v = *(const float4*)(G.A2 + (size_t)gm * G.lda2 + (k - G.K1));
+                else if (srow[i] >= 0) v = *(const float4*)(A + (size_t)srow[i] * lda + k);
+            }
+            ra[i] = v;
+        }
+        rb = (brow < N) ? *(const uint4*)(Wt + (size_t)brow * Kp + k0 + ((tid & 3) << 3)) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 256;
+            uint2 p = make_uint2(gb_pack2(ra[i].x, ra[i].y), gb_pack2(ra[i].z, ra[i].w));
+            *(uint2*)&As[buf][(e >> 3) * GB_LS + ((e & 7) << 2)] = p;
+        }
+        *(uint4*)&Bs[buf][(tid >> 2) * GB_LS + ((tid & 3) << 3)] = rb;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const int buf = (t - t_begin) & 1;
+            if (t + 1 < t_end) load_tile(t + 1);
+            // fragments: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of a 16-deep MFMA step
+            const unsigned short* ap = &As[buf][(32 * wm + (lane & 31)) * GB_LS + ((lane >> 5) << 3)];
+            const unsigned short* bp = &Bs[buf][(32 * wn + (lane & 31)) * GB_LS + ((lane >> 5) << 3)];
+            const uint4 a0 = *(const uint4*)ap, a1 = *(const uint4*)(ap + 16);
+            const uint4 b0 = *(const uint4*)bp, b1 = *(const uint4*)(bp + 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, a0), __builtin_bit_cast(gb_bf16x8, b0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, a1), __builtin_bit_cast(gb_bf16x8, b1), acc, 0, 0, 0);
+            if (t + 1 < t_end) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int gn = n0 + 32 * wn + (lane & 31);
+    if (gn >= N) return;
+    float cs = 1.f, ch = 0.f;
+    if (!slab) { cs = E.col_scale ? E.col_scale[gn] : 1.f; ch = E.col_shift ? E.col_shift[gn] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm >= M) continue;
+        if (slab) { slab[((size_t)blockIdx.y * Mcap + gm) * N + gn] = acc[r]; continue; }
+        float v = acc[r];
+        if (E.row_scale) v *= E.row_scale[gm];
+        v = v * cs + ch;
+        if (E.residual) v += E.residual[(size_t)gm * E.ldr + gn];
+        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+        C[(size_t)gm * ldc + gn] = v;
+    }
+}
+
+// A f32[M,K] (lda) or the composite [ x'[idx[m,0]] | skip[m] ] (idx != NULL / skip != NULL, as d3f_gemm_upsample_cat_f32);
+// Wt = d3f_gemm_pack_bf16(W [K,N]).  K, K1 = C1, lda, lds multiples of 4 and 16-byte aligned bases (else D3F_ERR_ARG: use the
+// fp32 entry points).  workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint).
+extern "C" int d3f_gemm_bf16(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds,
+                             int C2, const void* Wt, float* C, int ldc, int M, int N, const float* row_scale,
+                             const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
+                             float alpha, void* workspace, size_t workspace_bytes, const int* M_dev, const int* N1_dev,
+                             int M_hint, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K = C1 + C2;
+    if (M < 0 || N < 1 || N1 < 0 || C1 < 4 || C2 < 0 || (K % 4) || (C1 % 4) || lda < C1 || (lda % 4) || ldc < N ||
+        (C2 > 0 && (lds < C2 || (lds % 4))) || (residual && ldr < N) || (idx && ld_idx < 1) || (!idx && N1 < M))
+        return D3F_ERR_ARG;
+    if (M == 0) return D3F_OK;
+    if (!A || !Wt || !C || (C2 > 0 && !skip) || (((uintptr_t)A | (uintptr_t)skip | (uintptr_t)Wt) & 15)) return D3F_ERR_ARG;
+    const int Kp = (K + GB_BK - 1) / GB_BK * GB_BK;
+    int bm, bn, S, tps;
+    gemm_plan(M, N > 32 ? N : 64, K, M_hint, bm, bn, S, tps);   // (tile is 64 x 64 here; the plan only decides the K split)
+    const int nt = Kp / GB_BK;
+    if (S > nt) S = nt;
+    tps = d3f_cdiv(nt, S);
+    S = d3f_cdiv(nt, tps);
+    float* slab = nullptr;
+    if (S > 1) {
+        if (!workspace || workspace_bytes < (size_t)S * M * N * sizeof(float)) return D3F_ERR_WORKSPACE;
+        slab = (float*)workspace;
+    }
+    if (d3f_cdiv(M, 64) > 65535) return D3F_ERR_ARG;
+    GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
+    GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
+    dim3 grid(d3f_cdiv(N, 64), S, d3f_cdiv(M, 64));
+    gemm_bf16_kernel<<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wt, Kp, C, ldc, M, N, K, tps, slab, E, M_dev, G);
+    if (S > 1)
+        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}

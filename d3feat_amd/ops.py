@@ -338,6 +338,70 @@ _INFLUENCE = {"constant": 0, "linear": 1, "gaussian": 2}
 _AGGREGATION = {"sum": 0, "closest": 1}
 
 
+# ---- bf16-operand contractions (BASELINE configs[4]) -------------------------------------------------------------------------
+# Off by default: the fp32 path is the parity path.  `with bf16_contraction():` routes every contraction issued inside it (the
+# engine wraps its capture in it when built with bf16=True) through d3f_gemm_bf16.
+BF16_CONTRACTION = False
+_BF16_PACKED = {}
+
+
+class bf16_contraction:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global BF16_CONTRACTION
+        self.prev, BF16_CONTRACTION = BF16_CONTRACTION, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global BF16_CONTRACTION
+        BF16_CONTRACTION = self.prev
+        return False
+
+
+def packed_bf16_weights(W):
+    """W f32[K,N] (contiguous rows) -> the bf16 [N][Kp] copy d3f_gemm_bf16 reads; made once per (storage, shape, version)."""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), W._version)
+    t = _BF16_PACKED.get(key)
+    if t is None:
+        lib = _lib.load()
+        K, N = W.shape
+        Kp = (K + 31) // 32 * 32
+        t = torch.empty((N, Kp), dtype=torch.int16, device=W.device)
+        _lib.check(lib.d3f_gemm_pack_bf16(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_bf16")
+        if len(_BF16_PACKED) > 4096:
+            _BF16_PACKED.clear()
+        _BF16_PACKED[key] = t
+    return t
+
+
+def _bf16_ok(*operands):
+    """(tensor, leading dimension, columns) triples: float4-addressable?"""
+    for t, ld, cols in operands:
+        if t is None:
+            continue
+        if cols % 4 or ld % 4 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def _gemm_bf16(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky,
+               alpha, m_dev, n1_dev, hint, dev):
+    lib = _lib.load()
+    Wp = packed_bf16_weights(W)
+    ws = workspace(lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint), dev)
+    with _timed("gemm_bf16", dict(M=M, N=N, K=C1 + C2), dev):
+        rc = lib.d3f_gemm_bf16(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
+                               skip.data_ptr() if skip is not None else None, lds, C2, Wp.data_ptr(), out.data_ptr(), N, M, N,
+                               row_scale.data_ptr() if row_scale is not None else None,
+                               col_scale.data_ptr() if col_scale is not None else None,
+                               col_shift.data_ptr() if col_shift is not None else None,
+                               residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0, float(alpha),
+                               ws.data_ptr(), ws.numel(), m_dev, n1_dev, hint, _stream(dev))
+    _lib.check(rc, "gemm_bf16")
+
+
 def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, leaky=False, alpha=0.2, out=None):
     """out = act((A @ Bm) * row_scale[:,None] * col_scale + col_shift + residual) on the matrix cores."""
     lib = _lib.load()
@@ -360,6 +424,10 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
             if v.numel() != n or not v.is_contiguous():
                 raise ValueError("%s must be a contiguous vector of %d" % (name, n))
     hint = int(getattr(A, "n_hint", 0) or 0)
+    if BF16_CONTRACTION and K >= 4 and ldc == N and Bm.is_contiguous() and _bf16_ok((A, lda, K)):
+        _gemm_bf16(A, M, lda, K, None, 0, None, 0, 0, Bm, out, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky, alpha,
+                   _nd(A), None, hint, dev)
+        return _tag(out, A)
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, K, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=K), dev):
@@ -406,6 +474,10 @@ def gemm_upsample_cat(u, W, col_scale=None, col_shift=None, leaky=False, alpha=0
     dev = x.device
     out = torch.empty((M, N), dtype=torch.float32, device=dev)
     hint = int(getattr(inds, "n_hint", 0) or 0)
+    if BF16_CONTRACTION and W.is_contiguous() and _bf16_ok((x, ldx, C1), (skip, lds, C2)):
+        _gemm_bf16(x, x.shape[0], ldx, C1, inds, ldi, skip, lds, C2, W, out, M, N, None, col_scale, col_shift, None, 0, leaky, alpha,
+                   _nd(inds), _nd(x), hint, dev)
+        return _tag(out, inds)
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
@@ -432,6 +504,10 @@ def gemm_cat2(A1, A2, W, col_scale=None, col_shift=None, leaky=False, alpha=0.2)
     dev = A1.device
     out = torch.empty((M, N), dtype=torch.float32, device=dev)
     hint = int(getattr(A1, "n_hint", 0) or 0)
+    if BF16_CONTRACTION and W.is_contiguous() and _bf16_ok((A1, ld1, C1), (A2, ld2, C2)):
+        _gemm_bf16(A1, M, ld1, C1, None, 0, A2, ld2, C2, W, out, M, N, None, col_scale, col_shift, None, 0, leaky, alpha,
+                   _nd(A1), _nd(A1), hint, dev)
+        return _tag(out, A1)
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):

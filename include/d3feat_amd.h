@@ -282,6 +282,19 @@ int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int l
 int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
                          int ldo, const int* N_dev, void* stream);
 
+/* bf16-operand form of the contractions (BASELINE.json configs[4]: batched inference, bf16 MFMA contraction): the operator of
+ * d3f_gemm_f32 / d3f_gemm_upsample_cat_f32 -- A f32[M, C1] (rows in place when idx == NULL, else the gathered rows
+ * x'[idx[m,0]], zero row for indices outside [0, N1)), optional second operand skip f32[M, C2], K = C1 + C2, same epilogue --
+ * with both operands rounded to bfloat16 (nearest even) and multiplied by v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+ * NOT bit-compatible with the fp32 path (2^-9 relative operand rounding); separate tolerance, separate bench configuration.
+ * W_packed: d3f_gemm_pack_bf16(W f32[K,N]) -> bf16 [N][Kp], Kp = K rounded up to 32 (2 * N * Kp bytes).
+ * C1, C2, lda, lds multiples of 4, 16-byte aligned bases.  workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint). */
+int d3f_gemm_pack_bf16(const float* W, int ldb, int K, int N, void* W_packed, void* stream);
+int d3f_gemm_bf16(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
+                  const void* W_packed, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
+                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
+                  size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream);
+
 /* Stage-0 ingestion: float32 xyz [n,3] out of raw file records already on the device -- a binary PLY
  * vertex element (demo_registration.py:23, datasets/ThreeDMatch.py:348; float or double coordinates at byte offsets
  * off_x/y/z of `stride`-byte records, either byte order) or a KITTI velodyne sweep (datasets/KITTI.py:131, 277-278:
