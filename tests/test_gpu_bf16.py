@@ -12,8 +12,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DESC_TOL = 5e-2       # max |descriptor component| difference vs the fp32 oracle (unit-norm 32-d descriptors)
-SCORE_TOL = 5e-2      # max |score| difference
+DESC_TOL = 3e-2       # max |descriptor component| difference vs the fp32 oracle (unit-norm 32-d descriptors); measured 5e-3
+SCORE_TOL = 3e-2      # max |score| difference; measured 1e-2
 
 
 def _bf16_round(a):
