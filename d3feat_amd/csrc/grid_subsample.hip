@@ -21,7 +21,7 @@
 //     {bucket first-position (atomicMin), bucket sizes, reverse scan, rank inside bucket chain}, each fully
 //     parallel: rounds up to 1109 buckets run in ONE 1024-thread workgroup per batch element, larger rounds grid-wide
 //     (insert / tile scan + tile sums in its last workgroup / place);
-//   * 7 + 3*rounds launches per call (points only; 9 + 3*rounds with features) (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
+//   * 9 + 3*rounds launches per call (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
 //     (d3f_batch_grid_subsample_async) all sizes stay on the device and an overflowing call reports an empty result.
 #include "prims.h"
 
@@ -512,61 +512,6 @@ __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__
     }
 }
 
-// Points-only form of the accumulation (every call of the hot path): one thread per voxel walks the voxel's chain ONCE,
-// orders the <= 32 point indices in its own LDS segment (chains come out nearly descending -- later points were pushed later --
-// so the insertion sort from the back is ~O(1) per element) and sums the points in ascending input order.  Replaces the
-// per-point in-chain rank (n link reads per POINT), the voxel-start scan and the `sorted` scatter / gather: n link reads and
-// n point reads per VOXEL.  Longer chains (> 32 points in one voxel) select the next index by repeated minimum over the chain.
-#define GS_ACC_MAX 32
-__global__ void __launch_bounds__(256) gs_accum_chain_kernel(const float* __restrict__ pts, int* __restrict__ status,
-                                                             const int* __restrict__ moffs, int B,
-                                                             const int* __restrict__ vhead, const int* __restrict__ pnext,
-                                                             const int* __restrict__ vcnt, const int* __restrict__ vpos,
-                                                             float* __restrict__ out_p, int out_cap) {
-    __shared__ int seg[256 * (GS_ACC_MAX + 1)];   // stride 33: the 64 lanes of a wave hit distinct banks
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= status[0]) return;
-    const int b = d3f_find_elem(moffs, B, v);
-    const int n = vcnt[v];
-    const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
-    if (dest >= (size_t)out_cap) {   // more voxels than the caller's output rows (capacity mode): report, never write
-        atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
-        return;
-    }
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    if (n <= GS_ACC_MAX) {
-        int* a = seg + threadIdx.x * (GS_ACC_MAX + 1);   // descending order
-        int cnt = 0;
-        for (int j = vhead[v]; j >= 0 && cnt < GS_ACC_MAX; j = pnext[j]) {
-            int k = cnt;
-            while (k > 0 && a[k - 1] < j) { a[k] = a[k - 1]; --k; }
-            a[k] = j;
-            ++cnt;
-        }
-        for (int t = cnt - 1; t >= 0; --t) {
-            const size_t i = (size_t)a[t];
-            sx = __fadd_rn(sx, pts[3 * i + 0]);
-            sy = __fadd_rn(sy, pts[3 * i + 1]);
-            sz = __fadd_rn(sz, pts[3 * i + 2]);
-        }
-    } else {
-        int lastj = -1;
-        for (int t = 0; t < n; ++t) {
-            int best = 0x7fffffff;
-            for (int j = vhead[v]; j >= 0; j = pnext[j]) best = (j > lastj && j < best) ? j : best;
-            const size_t i = (size_t)best;
-            sx = __fadd_rn(sx, pts[3 * i + 0]);
-            sy = __fadd_rn(sy, pts[3 * i + 1]);
-            sz = __fadd_rn(sz, pts[3 * i + 2]);
-            lastj = best;
-        }
-    }
-    const float sc = (float)(1.0 / (double)n);  // `1.0 / v.second.count` is a double, narrowed by operator*(PointXYZ, float)
-    out_p[3 * dest + 0] = __fmul_rn(sx, sc);
-    out_p[3 * dest + 1] = __fmul_rn(sy, sc);
-    out_p[3 * dest + 2] = __fmul_rn(sz, sc);
-}
-
 // classes: the reference's max_element over unordered_map<int,int> compares (label, count) pairs, label
 // first, i.e. returns the LARGEST label id present in the voxel (grid_subsampling.cpp:94).
 __global__ void __launch_bounds__(256) gs_fill_kernel(int* __restrict__ p, size_t n, int v) {
@@ -707,14 +652,9 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
 
     gs_chain_kernel<<<nblk, 256, 0, stream>>>(N, slot, tfirst, tkey, vscan, vbase, pvid, vkey, vhead, vcnt, pnext, offs + B);
     D3F_LAUNCH_CHECK();
-    // points only (the hot path): the per-voxel accumulation walks the chains itself (gs_accum_chain_kernel); the in-chain
-    // rank / voxel-start scan / `sorted` list are needed only when features are averaged too (cpp_wrappers' compute())
-    const bool chain_accum = (fdim == 0);
-    if (!chain_accum) {
-        if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, meta, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
-            return rc;
-        gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
-    }
+    if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, meta, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
+        return rc;
+    gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
     // ---- libstdc++ iteration order ----
     // Rounds > GS_SMALL_LAST are spread grid-wide.  (Keeping ALL rounds in the single workgroup per element saves ~50 launches
     // per fragment but was measured slower end to end, 580 vs 640 fragments/s: the serial rounds of the 30 k-voxel stage sit
@@ -729,12 +669,8 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j * B);
         gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
     }
-    if (chain_accum)
-        gs_accum_chain_kernel<<<d3f_cdiv(M, 256), 256, 0, stream>>>(points, meta, moffs, B, vhead, pnext, vcnt, A.vpos,
-                                                                               sub_points, M_cap);
-    else
-        gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
-                                                                         vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
+    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
+                                                                     vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
     if (ldim > 0) {
         const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);
