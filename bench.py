@@ -533,6 +533,10 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
             names = ("gemm_fast_kernel", "gemm_stream_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
             ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
                    and "traffic_bytes_per_launch" in v]
+            m = re.match(r"kpconv_fused_kernel<Cin=(\d+)>", name)     # template argument = lanes per query = Cin / 4
+            if m:
+                ent = [v for k, v in traffic.items() if isinstance(v, dict) and "traffic_bytes_per_launch" in v
+                       and k.startswith("kpconv_fused_kernel<%d," % (int(m.group(1)) // 4))]
             nl = sum(e["launches"] for e in ent)
             if nl:
                 r["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl)
