@@ -437,6 +437,7 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
 // batch norm and LeakyReLU.  Only out [Nq, 32] reaches HBM.
 // ------------------------------------------------------------------------------------------------
 typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
+typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
 
 #define KF_TQ 32
 #define KF_LQ 8
@@ -446,10 +447,10 @@ typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
 
 // contraction + epilogue of the Cin = Cout = 32 kernels: the 60 register accumulators of every (query, channel group) thread
 // go through the LDS tile in two passes and are contracted with K_values on the matrix cores (see the header comment)
-__device__ __forceinline__ void kf32_contract_epilogue(float (&acc)[KP_MAXP - 1][4], int ql, int cl, int tid, float* kf_smem,
-                                                       const int* lcnt, const int* lq, const KpParams& P,
-                                                       const float* __restrict__ W, const KpEpi& E, float* __restrict__ out,
-                                                       int ldo) {
+template <class TileWriter>   // write_tile(wft, p0, np): this thread's weighted features of kernel points p0 .. p0+np-1 -> LDS tile
+__device__ __forceinline__ void kf32_contract_epilogue(TileWriter write_tile, int tid, float* kf_smem, const int* lcnt,
+                                                       const int* lq, const KpParams& P, const float* __restrict__ W,
+                                                       const KpEpi& E, float* __restrict__ out, int ldo) {
     float* wft = kf_smem;
     // ---- contraction on the matrix cores: out[32 x 32] = wf[32 x 480] @ W[480 x 32], in two passes of 8 / 7 kernel points:
     //      this thread's weighted features -> LDS tile wft[ql][(p - p0)*32 + 4*cl + j] (k index = p*Cin + c, as K_values),
@@ -463,14 +464,7 @@ __device__ __forceinline__ void kf32_contract_epilogue(float (&acc)[KP_MAXP - 1]
         const int p0 = pass * KF_HP;
         const int np = min(P.num_kp - p0, KF_HP);
         if (pass) __syncthreads();                      // the previous pass's tile has been consumed
-#pragma unroll
-        for (int pp = 0; pp < KF_HP; ++pp) {
-            const int p = p0 + pp;
-            if (p < KP_MAXP - 1 && pp < np) {
-                float* d = &wft[ql * KF_TS + pp * 32 + 4 * cl];
-                d[0] = acc[p][0]; d[1] = acc[p][1]; d[2] = acc[p][2]; d[3] = acc[p][3];
-            }
-        }
+        write_tile(wft, p0, np);
         __syncthreads();
         if (np <= 0) continue;
         const int ksteps = np * 16;                     // k-steps of 2
@@ -591,7 +585,17 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
         }
         __syncthreads();
     }
-    kf32_contract_epilogue(acc, ql, cl, tid, kf_smem, lcnt, lq, P, W, E, out, ldo);
+    auto write_tile = [&](float* wft, int p0, int np) {
+#pragma unroll
+        for (int pp = 0; pp < KF_HP; ++pp) {
+            const int p = p0 + pp;
+            if (p < KP_MAXP - 1 && pp < np) {
+                float* d = &wft[ql * KF_TS + pp * 32 + 4 * cl];
+                d[0] = acc[p][0]; d[1] = acc[p][1]; d[2] = acc[p][2]; d[3] = acc[p][3];
+            }
+        }
+    };
+    kf32_contract_epilogue(write_tile, tid, kf_smem, lcnt, lq, P, W, E, out, ldo);
 }
 
 extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
@@ -649,8 +653,6 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 //     reaches memory.
 // VALU (aggregation) and matrix (contraction) phases of different workgroups on a CU overlap: the two pipes are separate.
 // ------------------------------------------------------------------------------------------------
-typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
-
 #define KG_TQ 16                        // queries per workgroup = rows of one 16x16x4 tile
 #define KG_KT 512                       // k-values per contraction pass
 #define KG_TS (KG_KT + 4)               // LDS row stride of the wf tile (floats): 16-byte aligned rows, TS/4 odd
