@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libd3feat_amd.so")
+# D3FEAT_AMD_LIB: another build of the same library (A/B measurements of kernel changes inside one GPU visit)
+LIB_PATH = os.environ.get("D3FEAT_AMD_LIB") or os.path.join(_HERE, "lib", "libd3feat_amd.so")
 
 D3F_OK = 0
 ERRORS = {-1: "HIP runtime / kernel launch failure", -2: "workspace too small", -3: "invalid argument"}

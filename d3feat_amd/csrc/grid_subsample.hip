@@ -28,6 +28,7 @@
 #define GS_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GS_KEYBITS 56
 #define GS_KEYMASK ((1ull << GS_KEYBITS) - 1ull)
+#define GS_MAX_PROBE 4096
 
 __constant__ unsigned long long D3F_CHAIN_DEV[D3F_NCHAIN] = {
     13ull, 29ull, 59ull, 127ull, 257ull, 541ull, 1109ull, 2357ull, 5087ull, 10273ull, 20753ull, 42043ull, 85229ull,
@@ -116,11 +117,15 @@ __global__ void __launch_bounds__(256) gs_insert_kernel(const float* __restrict_
     if (st) atomicOr(&status[1], st);
     const unsigned long long word = ((unsigned long long)b << GS_KEYBITS) | (key & GS_KEYMASK);
     unsigned long long h = gs_mix(word) & capmask;
-    for (;;) {
+    // linear probing, bounded: the table is sized for the caller's voxel capacity; more voxels than that fill it up and are
+    // reported (D3F_ST_OUT_OVERFLOW -> empty result, recomputed by the caller) instead of probing forever
+    bool placed = false;
+    for (int probe = 0; probe < GS_MAX_PROBE; ++probe) {
         unsigned long long prev = atomicCAS(&tkey[h], GS_EMPTY, word);
-        if (prev == GS_EMPTY || prev == word) break;
+        if (prev == GS_EMPTY || prev == word) { placed = true; break; }
         h = (h + 1) & capmask;
     }
+    if (!placed) atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
     atomicMin(&tfirst[h], (unsigned)i);
     slot[i] = (int)h;
 }
@@ -163,7 +168,7 @@ struct GsMoffsEpi {
         for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : d3f_scan_at(vscan, vbase, offs[b]);
         // More voxels than the caller's output rows (capacity mode): flag it and report an EMPTY result, so that every
         // downstream stage of a captured launch sequence runs on zero rows instead of on partially written ones.
-        bool over = M > out_cap;
+        bool over = M > out_cap || (__hip_atomic_load(&meta[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & D3F_ST_OUT_OVERFLOW);
         for (int b = 0; b < B; ++b) over = over || (moffs[b + 1] - moffs[b] > elem_cap);
         if (over) atomicOr(&meta[1], D3F_ST_OUT_OVERFLOW);
         for (int b = 0; b < B; ++b) {
@@ -534,10 +539,14 @@ struct GsLayout {
     size_t cap;
     long long bucket_total;
 };
-static GsLayout gs_layout(int N, int B) {
+// keys: the hash table holds one entry per VOXEL, so it is sized by the voxel capacity where the caller states one (capacity
+// mode: M_cap << N for the stage-0 call -- 155 k voxels of 1.26 M raw points -- a 6 MB table that stays in L2 instead of a
+// 50 MB one, for the three passes of random atomics / gathers that go through it); load factor <= 0.5 either way.
+static GsLayout gs_layout(int N, int B, int keys = -1) {
     GsLayout L;
     L.cap = 64;
-    while (L.cap < (size_t)2 * (size_t)(N > 0 ? N : 1)) L.cap <<= 1;
+    const size_t nk = (size_t)((keys > 0 && keys < N) ? keys : (N > 0 ? N : 1));
+    while (L.cap < (size_t)2 * nk) L.cap <<= 1;
     // sum_b chain_ge(len_b) <= chain_ge-ratio bound: every chain step is < 2.24x, so chain_ge(l) < 2.24*l + 13
     L.bucket_total = (long long)(2.24 * (double)N) + 16ll * B + 64;
     return L;
@@ -571,7 +580,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
                   int* sub_classes, int* sub_lens_dev, int* status_host, int* status_dev, void* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
     const bool async = status_dev != nullptr;
-    GsLayout L = gs_layout(N, B);
+    GsLayout L = gs_layout(N, B, async ? M_cap : -1);
     D3fArena ar(workspace, workspace_bytes);
     const size_t n = (size_t)N;
     int* offs = ar.take<int>(B + 1);

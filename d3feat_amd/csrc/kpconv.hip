@@ -346,11 +346,11 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     for (int k0 = 0; k0 < K; k0 += 16) {
         const int mine = (live && k0 + p < K) ? row[k0 + p] : -1;      // 16 indices per group load
         const int kn = min(16, K - k0);
-        for (int kk = 0; kk < kn; kk += 4) {                           // 4 neighbours in flight
-            int id[4];
-            float px[4], py[4], pz[4], fv[4];
+        for (int kk = 0; kk < kn; kk += 8) {                           // 8 neighbours in flight
+            int id[8];
+            float px[8], py[8], pz[8], fv[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 id[u] = __shfl(mine, min(kk + u, 15), 16);
                 const bool ok = kk + u < kn && id[u] >= 0 && id[u] < Ns;
                 if (!ok) id[u] = -1;
@@ -359,7 +359,7 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
                 fv[u] = ok ? f[(size_t)id[u] * ldf] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 if (id[u] < 0) continue;
                 if (p == 15) { acc += (fv[u] > 0.f) ? 1.f : 0.f; continue; }
                 const float dx = (px[u] - qx) - kx, dy = (py[u] - qy) - ky, dz = (pz[u] - qz) - kz;

@@ -347,18 +347,19 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;   // 32 indices per half-wave load
         const int kn = min(32, K - k0);
-        for (int kk = 0; kk < kn; kk += 8) {       // two loads (8 neighbour rows) in flight per lane
-            int id[2];
-            float4 v[2];
+        for (int kk = 0; kk < kn; kk += 16) {      // four loads (16 neighbour rows) in flight per lane, clamped addresses
+            int id[4];
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int kq = kk + u * 4 + slot;
                 id[u] = __shfl(mine, hbase + min(kq, 31), 64);
                 if (kq >= kn || id[u] < 0 || id[u] >= N) id[u] = -1;   // shadow row: zeros
-                v[u] = id[u] >= 0 ? *(const float4*)&x[(size_t)id[u] * ldx + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = *(const float4*)&x[(size_t)max(id[u], 0) * ldx + c4];
+                if (id[u] < 0) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 // neighbours of a point belong to the point's own cloud (the searches are per batch element): same den
                 const float4 y = make_float4(v[u].x * rden, v[u].y * rden, v[u].z * rden, v[u].w * rden);
                 sum.x += y.x; sum.y += y.y; sum.z += y.z; sum.w += y.w;
