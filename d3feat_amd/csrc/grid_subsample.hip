@@ -243,8 +243,11 @@ struct GsOrderArgs {
 // HBM every phase paid L2 round trips (225 us for the seven rounds of a 30 k-voxel cloud, on every fragment's critical path);
 // with LDS atomics a phase costs a few hundred cycles.  Only the final list (and the finished positions) go to memory.
 #define GS_SMALL_NB 1109   // D3F_CHAIN[GS_SMALL_LAST]
-__global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int small_last) {
-    __shared__ int wsum[16];
+// 256 threads, not 1024: a workgroup of 16 wavefronts + 44 KB of LDS has to wait for a CU that the other replays in flight have
+// left completely free (rocprof showed 190 us for 15 us of work); four wavefronts are placed at once
+#define GS_SMALL_T 256
+__global__ void __launch_bounds__(GS_SMALL_T) gs_order_small_kernel(GsOrderArgs A, int small_last) {
+    __shared__ int wsum[GS_SMALL_T / 64];
     __shared__ int sBF[GS_SMALL_NB], sBC[GS_SMALL_NB], sBH[GS_SMALL_NB], sNX[GS_SMALL_NB], sCD[GS_SMALL_NB], sBK[GS_SMALL_NB];
     __shared__ int sL[2][GS_SMALL_NB];
     __shared__ unsigned long long sKey[GS_SMALL_NB];
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
     int* VP = A.vpos + A.moffs[b];
     const long long bbase = A.el[b].bbase;
     if (small_last > GS_SMALL_LAST) small_last = GS_SMALL_LAST;     // the LDS arrays are sized for 1109 buckets
-    for (int t = tid; t < min(M, GS_SMALL_NB); t += 1024) sKey[t] = key[t];
+    for (int t = tid; t < min(M, GS_SMALL_NB); t += GS_SMALL_T) sKey[t] = key[t];
     int lo = 0, cur = 0;
     bool done = false;
     __syncthreads();
@@ -267,9 +270,9 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
         const int hi = last ? M : nb;
         const int* La = sL[cur];
         int* Lb = sL[cur ^ 1];
-        for (int t = tid; t < nb; t += 1024) { sBF[t] = 0x7fffffff; sBC[t] = 0; sBH[t] = -1; }
+        for (int t = tid; t < nb; t += GS_SMALL_T) { sBF[t] = 0x7fffffff; sBC[t] = 0; sBH[t] = -1; }
         __syncthreads();
-        for (int t = tid; t < hi; t += 1024) {
+        for (int t = tid; t < hi; t += GS_SMALL_T) {
             const int id = (t < lo) ? La[t] : t;
             const int bk = gs_mod(sKey[id], (unsigned)nb, inv_nb);
             atomicMin(&sBF[bk], t);
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
         }
         __syncthreads();
         int carry = 0;
-        for (int c0 = 0; c0 < hi; c0 += 1024) {
+        for (int c0 = 0; c0 < hi; c0 += GS_SMALL_T) {
             const int u = c0 + tid, t = hi - 1 - u;
             int c = 0;
             if (u < hi) {
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
             __syncthreads();
             int wbase = 0, tot = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < GS_SMALL_T / 64; ++q) {
                 int v = wsum[q];
                 if (q < w) wbase += v;
                 tot += v;
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
             carry += tot;
         }
         __syncthreads();
-        for (int t = tid; t < hi; t += 1024) {
+        for (int t = tid; t < hi; t += GS_SMALL_T) {
             const int id = (t < lo) ? La[t] : t;
             const int bk = sBK[t];
             int r = 0;
@@ -324,12 +327,12 @@ __global__ void __launch_bounds__(1024) gs_order_small_kernel(GsOrderArgs A, int
         // hand over to the first grid-wide round j: it reads the current list from P[j & 1] and expects clean bucket arrays
         const int j = small_last + 1;
         int* P = A.P[j & 1] + A.offs[b];
-        for (int t = tid; t < lo; t += 1024) P[t] = sL[cur][t];
+        for (int t = tid; t < lo; t += GS_SMALL_T) P[t] = sL[cur][t];
         const int nb = (int)D3F_CHAIN_DEV[j];
         int* BF = A.bf[j & 1] + bbase;
         int* BC = A.bc[j & 1] + bbase;
         int* BH = A.bh[j & 1] + bbase;
-        for (int t = tid; t < nb; t += 1024) { BF[t] = 0x7fffffff; BC[t] = 0; BH[t] = -1; }
+        for (int t = tid; t < nb; t += GS_SMALL_T) { BF[t] = 0x7fffffff; BC[t] = 0; BH[t] = -1; }
     }
 }
 
@@ -669,7 +672,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     // per fragment but was measured slower end to end, 580 vs 640 fragments/s: the serial rounds of the 30 k-voxel stage sit
     // on every fragment's critical path and four fragments in flight do not hide them.)
     const int small_last = GS_SMALL_LAST;
-    gs_order_small_kernel<<<B, 1024, 0, stream>>>(A, small_last);
+    gs_order_small_kernel<<<B, GS_SMALL_T, 0, stream>>>(A, small_last);
     for (int j = small_last + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
         const long long nbj = (long long)D3F_CHAIN_HOST[j];
         const int hi = (int)((long long)maxM < nbj ? (long long)maxM : nbj);
