@@ -192,7 +192,7 @@ def main():
                                 n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
                                 batch=args.batch, bf16=args.bf16)
     # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
-    shard = parallel.ShardCollector(rows_cap=(args.steps + 8) * 2 * int(n0_max * 1.02 + 64), width=36, device=device)
+    shard = parallel.ShardCollector(rows_cap=(args.steps + 8) * int(n0_max * 1.02 + 64), width=36, device=device)
 
     def run(nsteps, engine=engine, collect=None, pool=raws):
         """nsteps fragments through the hot path; every fragment's record block goes to `collect` (ShardCollector)."""
@@ -200,7 +200,7 @@ def main():
             for i in range(nsteps):
                 rec = step(pool[i % len(pool)])
                 if collect is not None:
-                    collect.add(rec)
+                    collect.add(rec[: rec.shape[0] // 2])
             return
         S, F = len(engine.slots), engine.F
         busy = [False] * S
@@ -208,7 +208,9 @@ def main():
         def drain(sl):
             for rec in engine.fetch(sl, packed=True):
                 if collect is not None:
-                    collect.add(rec)
+                    # a fragment's RESULT is the first cloud of its stacked self-pair: the rows utils/tester.py:208-229 keeps
+                    # (in_batches[0]); the second half is the same cloud again
+                    collect.add(rec[: rec.shape[0] // 2])
             busy[sl] = False
         i = k = 0
         while i < nsteps:                        # replays of up to F fragments each, round-robin over the slots
@@ -239,7 +241,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    npts = int(np.mean(shard.frag_rows)) // 2
+    npts = int(np.mean(shard.frag_rows))
     gathered_rows = [int(g[0].shape[0]) for g in gathered]
     gathered_frags = [len(g[1]) for g in gathered]
     del gathered
@@ -343,8 +345,9 @@ def main():
                        "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
                        "final_gather": {"ranks": len(gathered_rows), "fragments_per_rank": gathered_frags,
                                         "rows_per_rank": gathered_rows, "bytes_per_rank": [r * 144 for r in gathered_rows],
-                                        "what": "every rank's whole shard of [xyz | desc | score] records (144 B/point), "
-                                                "one padded all_gather inside the timed region"},
+                                        "what": "every rank's whole shard of [xyz | desc | score] records (144 B/point, the first cloud "
+                                                "of every stacked self-pair: what utils/tester.py:208-229 keeps per fragment), one "
+                                                "padded all_gather inside the timed region"},
                        "execution": ("eager op-by-op launches" if engine is None else
                                      "HIP-graph replay of %d stacked fragment(s), device-resident sizes, %d replays in flight%s"
                                      % (engine.F, len(engine.slots),

@@ -348,8 +348,11 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
 }
 
 // ------------------------------------------------------------------------------------------------
+// cells the grid may use: 4 per support (surface clouds occupy ~0.3 cells per point at cell edge = radius; a sparser cloud gets
+// larger cells).  The budget is what every build has to clear -- in capacity mode whatever the real cloud size -- so it is
+// kept tight: 16 per support meant 40 MB of fills per level-0 build.
 static long long nb_cell_budget(int Ns) {
-    long long b = 16ll * (long long)(Ns > 0 ? Ns : 1);
+    long long b = 4ll * (long long)(Ns > 0 ? Ns : 1);
     if (b < (1ll << 16)) b = 1ll << 16;
     if (b > (1ll << 28)) b = 1ll << 28;
     return b;

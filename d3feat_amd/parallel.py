@@ -101,33 +101,40 @@ class ShardCollector:
         return self.buf[: self.rows]
 
     def gather(self):
-        return gather_shard(self.records(), self.frag_rows)
+        return gather_shard(self.records(), self.frag_rows, backing=self.buf)
 
 
-def gather_shard(records, frag_rows):
+def gather_shard(records, frag_rows, backing=None):
     """Variable-length all_gather of every rank's WHOLE shard: records f32[rows, W] (rows differ per rank) and the
-    per-fragment row counts.  Sizes first, then ONE padded payload collective (RCCL all_gather over xGMI on GPUs, gloo on
-    CPU tensors).  -> list over ranks of (records f32[rows_r, W], frag_rows list)."""
+    per-fragment row counts.  Sizes first, then ONE payload collective into one [ranks * rows_max, W] tensor
+    (all_gather_into_tensor: RCCL over xGMI on GPUs, gloo on CPU tensors; no per-rank staging copies).  `backing`: the
+    buffer `records` is the head of -- when it holds rows_max rows the payload is sent from it in place (the rows past
+    this rank's count are never read by the receiver), otherwise the records are padded into a fresh buffer.
+    -> list over ranks of (records f32[rows_r, W], frag_rows list)."""
     rank, ws = world()
     if ws == 1:
         return [(records, list(frag_rows))]
     dev = records.device
     W = records.shape[1]
     meta = torch.tensor([records.shape[0], len(frag_rows)], dtype=torch.int64, device=dev)
-    metas = [torch.zeros_like(meta) for _ in range(ws)]
-    dist.all_gather(metas, meta)
-    metas = [[int(v) for v in m.tolist()] for m in metas]
-    rmax, fmax = max(m[0] for m in metas), max(m[1] for m in metas)
-    fr = torch.zeros((max(fmax, 1),), dtype=torch.int64, device=dev)
+    metas = torch.empty((ws * 2,), dtype=torch.int64, device=dev)        # concatenated along dim 0 (gloo chunks it that way)
+    dist.all_gather_into_tensor(metas, meta)
+    metas = [[int(v) for v in m] for m in metas.view(ws, 2).tolist()]
+    rmax, fmax = max(m[0] for m in metas), max(max(m[1] for m in metas), 1)
+    fr = torch.zeros((fmax,), dtype=torch.int64, device=dev)
     if frag_rows:
-        fr[: len(frag_rows)] = torch.tensor(list(frag_rows), dtype=torch.int64, device=dev)
-    frs = [torch.zeros_like(fr) for _ in range(ws)]
-    dist.all_gather(frs, fr)
+        fr[: len(frag_rows)] = torch.tensor(list(frag_rows), dtype=torch.int64).to(dev)
+    frs = torch.empty((ws * fmax,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(frs, fr)
+    frs = frs.view(ws, fmax).tolist()
     if rmax == records.shape[0] and records.is_contiguous():
         payload = records
+    elif backing is not None and backing.shape[0] >= rmax and backing.is_contiguous() and backing.data_ptr() == records.data_ptr():
+        payload = backing[:rmax]
     else:
         payload = torch.zeros((rmax, W), dtype=torch.float32, device=dev)
         payload[: records.shape[0]] = records
-    out = [torch.empty((rmax, W), dtype=torch.float32, device=dev) for _ in range(ws)]
-    dist.all_gather(out, payload)
-    return [(o[: m[0]], [int(v) for v in f[: m[1]].tolist()]) for o, m, f in zip(out, metas, frs)]
+    out = torch.empty((ws * rmax, W), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, payload)
+    out = out.view(ws, rmax, W)
+    return [(out[r, : m[0]], [int(v) for v in f[: m[1]]]) for r, (m, f) in enumerate(zip(metas, frs))]

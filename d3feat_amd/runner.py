@@ -44,13 +44,17 @@ def _gather_index_lists(mine, n_items, device):
 
 
 def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibrate, device, out_root=None, gather=True,
-                save=None, log=None):
+                save=None, log=None, keep="first"):
     """fragment_ids: list of id strings ('<scene>/cloud_bin_<k>.ply'); sizes: raw point count per fragment (all ranks pass the
     same lists); load(i) -> float32 [n,3] raw cloud of fragment i (called by the owner only).
     make_engine(config, weights, limits, raw_cap, n0_cap_hint) -> engine with .F, .slots, submit(slot, [raw...]),
     fetch(slot, packed=True) -> list of record tensors [2n, 36] (stacked self-pair) in submission order.
     calibrate(raws) -> int64 histograms [layers, bins] of this rank's fragments.
+    keep: what a fragment contributes to the shard that is gathered -- "first": the first cloud's records, which is what
+    utils/tester.py:208-229 keeps of a stacked self-pair; "pair": the whole stacked block (KITTI pairs).  `save` always
+    receives the whole block.
     -> dict(limits, mine, order (rank 0..W-1 -> fragment indices), shards (list over ranks of (records, frag_rows)) | None)."""
+    assert keep in ("first", "pair")
     rank, world = parallel.world()
     n = len(fragment_ids)
     mine = parallel.shard_fragments(n, rank, world, sizes=sizes)
@@ -72,7 +76,7 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
             if collector is None:
                 collector = parallel.ShardCollector(rows_cap=max(int(rec.shape[0]) * max(len(mine), 1), 1), width=rec.shape[1],
                                                     device=rec.device)
-            collector.add(rec)
+            collector.add(rec[: rec.shape[0] // 2] if keep == "first" else rec)
             produced.append(i)
             if save is not None:
                 save(fragment_ids[i], rec)

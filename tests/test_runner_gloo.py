@@ -92,7 +92,8 @@ def _worker(rank, world, port, out_dir):
             assert len(rows) == len(res["order"][r])
             o = 0
             for i, n in zip(res["order"][r], rows):
-                assert torch.equal(rec[o:o + n], _records(_load(i)))
+                full = _records(_load(i))
+                assert n == full.shape[0] // 2 and torch.equal(rec[o:o + n], full[:n])      # keep="first": the tester's rows
                 o += n
             assert o == rec.shape[0]
         # per-fragment files in the reference's layout
@@ -126,3 +127,5 @@ def test_sharded_runner_single_process():
     assert res["mine"] == list(range(N_FRAG)) and res["order"] == [list(range(N_FRAG))]
     rec, rows = res["shards"][0]
     assert len(rows) == N_FRAG and rec.shape[0] == sum(rows)
+    pair = runner.run_sharded(IDS, SIZES, _load, None, None, lambda c, w, l, r: _Engine(), _hist, torch.device("cpu"), keep="pair")
+    assert pair["shards"][0][1] == [2 * n for n in rows]
