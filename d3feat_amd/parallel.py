@@ -101,15 +101,23 @@ class ShardCollector:
         return self.buf[: self.rows]
 
     def gather(self):
-        return gather_shard(self.records(), self.frag_rows, backing=self.buf)
+        """-> list over ranks of (records, frag_rows).  The receive buffer is sized once for the collector's capacity and
+        kept (views of it are returned: valid until the next gather), so a timed gather allocates nothing."""
+        def receive(rows_total):
+            need = max(rows_total, world()[1] * self.buf.shape[0])
+            if getattr(self, "_recv", None) is None or self._recv.shape[0] < need:
+                self._recv = torch.empty((need, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
+            return self._recv[:rows_total]
+        return gather_shard(self.records(), self.frag_rows, backing=self.buf, receive=receive)
 
 
-def gather_shard(records, frag_rows, backing=None):
+def gather_shard(records, frag_rows, backing=None, receive=None):
     """Variable-length all_gather of every rank's WHOLE shard: records f32[rows, W] (rows differ per rank) and the
     per-fragment row counts.  Sizes first, then ONE payload collective into one [ranks * rows_max, W] tensor
     (all_gather_into_tensor: RCCL over xGMI on GPUs, gloo on CPU tensors; no per-rank staging copies).  `backing`: the
     buffer `records` is the head of -- when it holds rows_max rows the payload is sent from it in place (the rows past
-    this rank's count are never read by the receiver), otherwise the records are padded into a fresh buffer.
+    this rank's count are never read by the receiver), otherwise the records are padded into a fresh buffer.  `receive(rows)`
+    -> contiguous f32[rows, W] to receive into (default: a fresh tensor).
     -> list over ranks of (records f32[rows_r, W], frag_rows list)."""
     rank, ws = world()
     if ws == 1:
@@ -134,7 +142,7 @@ def gather_shard(records, frag_rows, backing=None):
     else:
         payload = torch.zeros((rmax, W), dtype=torch.float32, device=dev)
         payload[: records.shape[0]] = records
-    out = torch.empty((ws * rmax, W), dtype=torch.float32, device=dev)
+    out = receive(ws * rmax) if receive is not None else torch.empty((ws * rmax, W), dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(out, payload)
     out = out.view(ws, rmax, W)
     return [(out[r, : m[0]], [int(v) for v in f[: m[1]]]) for r, (m, f) in enumerate(zip(metas, frs))]
