@@ -56,8 +56,10 @@ def parse():
     ap.add_argument("--no-cpu-1thread", action="store_true", help="skip the 1-thread network row of the CPU baseline")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
     ap.add_argument("--slots", type=int, default=4, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
-    ap.add_argument("--batch", type=int, default=4,
-                    help="fragments stacked into one graph replay (FragmentEngine(batch=F)); a step is still ONE fragment")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="fragments stacked into one graph replay (FragmentEngine(batch=F)); a step is still ONE fragment.  "
+                         "0 = by job size: 4, or for a job shorter than 64 fragments ceil(steps / slots) (at most 8) so that the "
+                         "whole job is one round of replays, all in flight together, instead of a round plus a lone straggler")
     ap.add_argument("--eager", action="store_true", help="op-by-op eager path instead of the graph engine")
     ap.add_argument("--mirror", action="store_true",
                     help="headline run with the self-pair computed once and mirrored (default: the full stacked pair)")
@@ -124,6 +126,8 @@ def source_hash():
 
 def main():
     args = parse()
+    if args.batch <= 0:
+        args.batch = 4 if args.steps >= 64 else max(1, min(8, -(-args.steps // max(args.slots, 1))))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -192,7 +196,7 @@ def main():
                                 n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
                                 batch=args.batch, bf16=args.bf16)
     # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
-    shard = parallel.ShardCollector(rows_cap=(args.steps + 8) * int(n0_max * 1.02 + 64), width=36, device=device)
+    shard = parallel.ShardCollector(rows_cap=((max(args.steps, 128) if world == 1 else args.steps) + 8) * int(n0_max * 1.02 + 64), width=36, device=device)
 
     def run(nsteps, engine=engine, collect=None, pool=raws):
         """nsteps fragments through the hot path; every fragment's record block goes to `collect` (ShardCollector)."""
@@ -247,6 +251,9 @@ def main():
     del gathered
     shard.reset()
 
+    # the secondary measurements below are steady-state figures: never shorter than 128 fragments, whatever --steps the
+    # headline was asked for
+    sec_steps = max(args.steps, 128)
     # ---- secondary number (N = 1): PCIe-inclusive -- raw fragments start in pinned HOST memory, results end there -------
     pcie = None
     if rank == 0 and world == 1 and engine is not None and not args.no_pcie_extra:
@@ -280,10 +287,11 @@ def main():
             run_host(S * F)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
-            run_host(args.steps)
+            run_host(sec_steps)
             torch.cuda.synchronize(device)
             dt3 = time.perf_counter() - t1
-            pcie = {"value": round(args.steps / dt3, 3), "unit": "fragments/s", "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+            pcie = {"value": round(sec_steps / dt3, 3), "unit": "fragments/s", "ms_per_step": round(dt3 / sec_steps * 1e3, 4),
+                    "steps": sec_steps,
                     "h2d_bytes_per_fragment": int(np.mean([r.shape[0] for r in raws]) * 12),
                     "d2h_bytes_per_fragment": int(2 * npts * 36 * 4),
                     "note": "NOT the headline: raw clouds read from pinned host memory, the record blocks copied back "
@@ -300,11 +308,11 @@ def main():
         run(args.warmup, eng2)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        run(args.steps, eng2)
+        run(sec_steps, eng2)
         torch.cuda.synchronize(device)
         dt2 = time.perf_counter() - t1
-        mirror_extra = {"value": round(args.steps / dt2, 3), "unit": "fragments/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
-                        "engine_fallbacks": eng2.fallbacks,
+        mirror_extra = {"value": round(sec_steps / dt2, 3), "unit": "fragments/s", "ms_per_step": round(dt2 / sec_steps * 1e3, 4),
+                        "steps": sec_steps, "engine_fallbacks": eng2.fallbacks,
                         "note": "NOT the headline: the two halves of the reference's stacked self-pair are identical by construction "
                                 "(per-cloud searches and head normalisation), so this mode computes one copy and mirrors it into "
                                 "the stacked outputs (FragmentEngine(mirror_self_pair=True)); same results to fp32 summation order"}
@@ -322,7 +330,7 @@ def main():
     # (the replay keeps its shape: sizes are device-resident and do not depend on feature values; outputs are garbage).
     marginal = None
     if rank == 0 and world == 1 and engine is not None and fam_flops and not args.no_marginal and not args.ablate and not args.mirror and not args.bf16:
-        marginal = marginal_costs(args, cfg, W, limits, engine, run, shard, device, dt / args.steps * 1e3, fam_flops)
+        marginal = marginal_costs(args, cfg, W, limits, engine, run, shard, device, sec_steps, fam_flops)
 
     # ---- CPU baseline + parity at the benchmarked configuration (rank 0, N=1) ---------------------------------------------
     cpu = parity = None
@@ -374,25 +382,30 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def marginal_costs(args, cfg, W, limits, engine, run, shard, device, base_ms, flops):
+def marginal_costs(args, cfg, W, limits, engine, run, shard, device, nsteps, flops):
     import torch
     from d3feat_amd import _lib
     from d3feat_amd.engine import FragmentEngine
+
+    def timed(eng):
+        run(args.warmup, eng)
+        torch.cuda.synchronize(device)
+        t = time.perf_counter()
+        run(nsteps, eng, collect=shard)                  # same bookkeeping as the headline region
+        torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t) / nsteps * 1e3
+        shard.reset()
+        return ms
+    base_ms = timed(engine)
     out = {"method": "throughput of a second engine whose replays leave one op family's library calls out, same fragments, "
-                     "same F x slots; ms_per_fragment = base - ablated", "base_ms_per_fragment": round(base_ms, 4)}
+                     "same F x slots; ms_per_fragment = base - ablated", "steps": nsteps, "base_ms_per_fragment": round(base_ms, 4)}
     real_load = _lib.load
     try:
         for fam in ("gemm", "kpconv"):
             install_ablation([fam] + (["rowpos"] if fam == "kpconv" else []))
             eng = FragmentEngine(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, slots=len(engine.slots), device=device,
                                  n0_hint=engine.n0_hint, streams=[sl.stream for sl in engine.slots], batch=engine.F)
-            run(args.warmup, eng)
-            torch.cuda.synchronize(device)
-            t = time.perf_counter()
-            run(args.steps, eng, collect=shard)          # same bookkeeping as the headline region
-            torch.cuda.synchronize(device)
-            ms = (time.perf_counter() - t) / args.steps * 1e3
-            shard.reset()
+            ms = timed(eng)
             _lib.load = real_load
             d = base_ms - ms
             e = {"ablated_ms_per_fragment": round(ms, 4), "ms_per_fragment": round(d, 4)}
