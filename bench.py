@@ -60,6 +60,12 @@ def parse():
                     help="fragments stacked into one graph replay (FragmentEngine(batch=F)); a step is still ONE fragment.  "
                          "0 = by job size: 4, or for a job shorter than 64 fragments ceil(steps / slots) (at most 8) so that the "
                          "whole job is one round of replays, all in flight together, instead of a round plus a lone straggler")
+    ap.add_argument("--cap-factor", type=float, default=1.1,
+                    help="voxel capacity of a slot = this x the largest fragment of the pool.  Launches are sized by capacity, so slack "
+                         "costs idle workgroups (1.3 / 0.4 instead of 1.1 / 0.32: -2 %% fragments/s, profiles/r02_experiments.txt); a "
+                         "fragment beyond a capacity is flagged on the device and recomputed eagerly (engine_fallbacks in the line)")
+    ap.add_argument("--level-ratio", type=float, default=0.32,
+                    help="row capacity of pyramid level l+1 / level l (surface clouds keep 0.27-0.30 per level)")
     ap.add_argument("--eager", action="store_true", help="op-by-op eager path instead of the graph engine")
     ap.add_argument("--mirror", action="store_true",
                     help="headline run with the self-pair computed once and mirrored (default: the full stacked pair)")
@@ -191,8 +197,8 @@ def main():
         # the fragment engine: whole fragment = one replayed HIP graph with device-resident sizes, `slots` in flight
         from d3feat_amd.engine import FragmentEngine
         raw_cap = int(max(r.shape[0] for r in raws_all) * 1.05) + 1024
-        n0_cap = (int(n0_max * 1.3) + 1023) // 1024 * 1024
-        engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, slots=args.slots, device=device,
+        n0_cap = (int(n0_max * args.cap_factor) + 1023) // 1024 * 1024
+        engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, level_ratio=args.level_ratio, slots=args.slots, device=device,
                                 n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
                                 batch=args.batch, bf16=args.bf16)
     # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
@@ -303,7 +309,7 @@ def main():
     mirror_extra = None
     if rank == 0 and world == 1 and engine is not None and not args.mirror and not args.no_mirror_extra and not args.bf16:
         from d3feat_amd.engine import FragmentEngine as _FE
-        eng2 = _FE(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, slots=args.slots, device=device,
+        eng2 = _FE(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, level_ratio=engine.level_ratio, slots=args.slots, device=device,
                    n0_hint=engine.n0_hint, mirror_self_pair=True, streams=[sl.stream for sl in engine.slots], batch=args.batch)
         run(args.warmup, eng2)
         torch.cuda.synchronize(device)
@@ -361,6 +367,9 @@ def main():
                                      % (engine.F, len(engine.slots),
                                         "; self-pair computed once and mirrored" if args.mirror else "")),
                        "fragments_per_replay": (engine.F if engine is not None else 1),
+                       "capacities": (None if engine is None else
+                                      {"raw_points_per_fragment": engine.raw_cap, "voxels_per_cloud": engine.n0_cap,
+                                       "rows_per_level": [int(c) for c in engine.caps]}),
                        "engine_fallbacks": (engine.fallbacks if engine is not None else None)},
             "parity": parity, "roofline": roof, "rooflines": roofs, "marginal_cost": marginal, "kpconv_layers_ms": layers,
             "cpu_baseline": cpu,
@@ -403,7 +412,8 @@ def marginal_costs(args, cfg, W, limits, engine, run, shard, device, nsteps, flo
     try:
         for fam in ("gemm", "kpconv"):
             install_ablation([fam] + (["rowpos"] if fam == "kpconv" else []))
-            eng = FragmentEngine(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, slots=len(engine.slots), device=device,
+            eng = FragmentEngine(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, level_ratio=engine.level_ratio,
+                                 slots=len(engine.slots), device=device,
                                  n0_hint=engine.n0_hint, streams=[sl.stream for sl in engine.slots], batch=engine.F)
             ms = timed(eng)
             _lib.load = real_load

@@ -83,6 +83,7 @@ class FragmentEngine:
             raise ValueError("batch out of range")
         self.nin = self.F * (2 if self.two else 1)            # clouds handed to the stage-0 subsampling per replay
         clouds = self.F * (1 if (self.mirror or self.two) else 2)
+        self.level_ratio = float(level_ratio)
         self.caps = level_caps(n0_cap, config.num_layers, level_ratio, clouds)
         self.cap_units = clouds                                # a level's capacity is `clouds` per-fragment capacities
         self.n0_hint = int(n0_hint if n0_hint is not None else n0_cap / 1.3)
