@@ -247,15 +247,21 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
     constexpr bool ROWS = (EPI & 1) != 0, RES = (EPI & 2) != 0;
     M = d3f_dyn(M, M_dev);
     if ((int)(blockIdx.z * BM) >= M) return;
+    // live workgroups = the first contiguous run of the dispatch order (row tile is the slowest grid dimension); among them
+    // every XCD takes one contiguous run of (row tile, K slice, column tile) triples, so the column tiles of a row block --
+    // which read the same A rows -- meet in one L2 (common.h: d3f_xcd_tile)
+    const unsigned gx_ = gridDim.x, gxy_ = gridDim.x * gridDim.y;
+    const unsigned T_ = d3f_xcd_tile(blockIdx.x + gx_ * blockIdx.y + gxy_ * blockIdx.z, gxy_ * (unsigned)((M + BM - 1) / BM));
+    const unsigned bz = T_ / gxy_, by = (T_ % gxy_) / gx_, bx = T_ % gx_;
     extern __shared__ __attribute__((aligned(16))) float gf_smem[];
     float* As = gf_smem;                          // [2][BM][GF_S]
     float* Bt = gf_smem + 2 * BM * GF_S;          // [2][BN][GF_S]   B tile transposed: Bt[n][k]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.z * BM, n0 = blockIdx.x * BN;
+    const int m0 = bz * BM, n0 = bx * BN;
     const int nt_all = (K + GM_BK - 1) / GM_BK;
-    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_begin = by * tiles_per_split;
     const int t_end = min(nt_all, t_begin + tiles_per_split);
 
     // per-thread staging slots: A slot i = row (tid + 256 i) / 8, k offset 4 * ((tid + 256 i) % 8)
@@ -436,7 +442,7 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
                 for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));
                 o[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
-            float* dst = slab ? slab + ((size_t)blockIdx.y * Mcap + (mok ? gm : 0)) * N : C + (size_t)(mok ? gm : 0) * ldc;
+            float* dst = slab ? slab + ((size_t)by * Mcap + (mok ? gm : 0)) * N : C + (size_t)(mok ? gm : 0) * ldc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gn = n0 + (wn * TN + j) * 32 + 8 * q + 4 * (lane >> 5);
@@ -866,13 +872,19 @@ gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __r
     const int Mcap = M;
     M = d3f_dyn(M, M_dev);
     if ((int)(blockIdx.z * BM) >= M) return;   // capacity-sized grid (row tile = slowest dispatch dimension, as gemm_fast_kernel)
+    // live workgroups = the first contiguous run of the dispatch order (row tile is the slowest grid dimension); among them
+    // every XCD takes one contiguous run of (row tile, K slice, column tile) triples, so the column tiles of a row block --
+    // which read the same A rows -- meet in one L2 (common.h: d3f_xcd_tile)
+    const unsigned gx_ = gridDim.x, gxy_ = gridDim.x * gridDim.y;
+    const unsigned T_ = d3f_xcd_tile(blockIdx.x + gx_ * blockIdx.y + gxy_ * blockIdx.z, gxy_ * (unsigned)((M + BM - 1) / BM));
+    const unsigned bz = T_ / gxy_, by = (T_ % gxy_) / gx_, bx = T_ % gx_;
     __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * GB_LS];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * GB_LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.z * BM, n0 = blockIdx.x * BN;
+    const int m0 = bz * BM, n0 = bx * BN;
     const int nt_all = Kp / GB_BK;
-    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_begin = by * tiles_per_split;
     const int t_end = min(nt_all, t_begin + tiles_per_split);
     // staging roles: A tile 64 rows x 32 k fp32 = 512 float4 slots -> 2 per thread (row = slot / 8, k4 = slot % 8);
     //                W tile 64 rows x 32 k bf16 = 256 uint4 slots (8 bf16 each) -> 1 per thread (row = tid / 4, k8 = tid % 4)
@@ -947,7 +959,7 @@ gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __r
     for (int r = 0; r < 16; ++r) {
         const int gm = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (gm >= M) continue;
-        if (slab) { slab[((size_t)blockIdx.y * Mcap + gm) * N + gn] = acc[r]; continue; }
+        if (slab) { slab[((size_t)by * Mcap + gm) * N + gn] = acc[r]; continue; }
         float v = acc[r];
         if (E.row_scale) v *= E.row_scale[gm];
         v = v * cs + ch;

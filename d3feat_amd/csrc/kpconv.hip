@@ -132,6 +132,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
     if ((int)(blockIdx.x * TQ) >= Nq) return;   // capacity-sized grid: whole block beyond the real query count
+    const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + TQ - 1) / TQ));   // one contiguous run of tiles per XCD
     constexpr int KC = LQ;        // neighbours per chunk (TQ*KC = 256 pairs = one per thread)
     constexpr int WS = KC * 16 + 4;  // per-query stride in floats (+4: de-phase the b128 broadcasts of adjacent queries)
     __shared__ __attribute__((aligned(16))) float lw[TQ * WS];
@@ -141,7 +142,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
     const int ql = tid / LQ, cl = tid % LQ;  // query-in-block, channel group
     // q_order: a spatially coherent visiting order (cell-sorted): the TQ queries of a workgroup then share most of their
     // neighbours, whose feature rows are fetched once into L1 / L2 instead of TQ times from all over the cloud
-    const int qslot = blockIdx.x * TQ + ql;
+    const int qslot = tile * TQ + ql;
     const int qg = (q_order && qslot < Nq) ? q_order[qslot] : qslot;
     const int Cin = LQ * 4;
     if (tid < TQ) lcnt[tid] = 0;
@@ -327,12 +328,13 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
     if ((int)(blockIdx.x * 16) >= Nq) return;
+    const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + 15) / 16));   // one contiguous run of tiles per XCD
     __shared__ float skp[KP_MAXP * 3];
     __shared__ float sacc[16][17];
     __shared__ int sq[16];
     const int tid = threadIdx.x, p = tid & 15, ql = tid >> 4;
     if (tid < KP_MAXP * 3) skp[tid] = P.kp[tid];
-    const int qslot = blockIdx.x * 16 + ql;
+    const int qslot = tile * 16 + ql;
     const bool live = qslot < Nq;
     const int qi = live ? (q_order ? q_order[qslot] : qslot) : 0;
     if (p == 0) sq[ql] = live ? qi : -1;
@@ -518,6 +520,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
     if ((int)(blockIdx.x * KF_TQ) >= Nq) return;
+    const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + KF_TQ - 1) / KF_TQ));   // one contiguous run of tiles per XCD
     // One LDS region serves three lives: phase-A influences [32][132] during the neighbour loop, then the weighted-feature
     // tile [32][257] (8 kernel points at a time: MFMA A operand), then the four partial out tiles.  34 KB per workgroup
     // instead of 80 KB: the kernel is bound by dependent gathers, so resident workgroups per CU are what it needs.
@@ -529,7 +532,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     int* lq = lcnt + KF_TQ;                                 // [32] global query index of each tile row
     const int tid = threadIdx.x;
     const int ql = tid / KF_LQ, cl = tid % KF_LQ;
-    const int qslot = blockIdx.x * KF_TQ + ql;
+    const int qslot = tile * KF_TQ + ql;
     const int qg = (q_order && qslot < Nq) ? q_order[qslot] : qslot;
     if (tid < KF_TQ) lcnt[tid] = 0;
     if (cl == 0) lq[ql] = qslot < Nq ? qg : -1;
@@ -674,6 +677,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
     if ((int)(blockIdx.x * KG_TQ) >= Nq) return;
+    const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + KG_TQ - 1) / KG_TQ));   // one contiguous run of tiles per XCD
     __shared__ __attribute__((aligned(16))) float region[KG_TQ * KG_TS];   // influences, then the wf tile of each pass
     __shared__ int lidx[KG_TQ * KC];
     __shared__ int lcnt[KG_TQ];
@@ -682,7 +686,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     float* wft = region;
     const int tid = threadIdx.x;
     const int ql = tid / LQ, cl = tid % LQ;
-    const int qslot = blockIdx.x * KG_TQ + ql;
+    const int qslot = tile * KG_TQ + ql;
     const int qg = (q_order && qslot < Nq) ? q_order[qslot] : qslot;
     if (tid < KG_TQ) lcnt[tid] = 0;
     if (cl == 0) lq[ql] = qslot < Nq ? qg : -1;

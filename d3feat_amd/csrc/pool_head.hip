@@ -64,7 +64,9 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
     N1 = d3f_dyn(N1, N1_dev);
     N2 = d3f_dyn(N2, N2_dev);
     const int CV = C / VEC;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned nblk = (unsigned)(((long long)N2 * CV + 255) / 256);
+    if (blockIdx.x >= nblk) return;                          // capacity-sized grid
+    const long long t = (long long)d3f_xcd_tile(blockIdx.x, nblk) * 256 + threadIdx.x;   // one contiguous run of rows per XCD
     if (t >= (long long)N2 * CV) return;
     const int slot = (int)(t / CV), c = (int)(t % CV) * VEC;
     const int n = row_order ? row_order[slot] : slot;   // spatially coherent visiting order (see kpconv.hip)
@@ -231,8 +233,8 @@ head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __res
             const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
             float* __restrict__ score, const int* __restrict__ row_order) {
     N = min(N, offs[B]);   // N is the capacity, offs[B] the real point count
-    const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
-    if ((int)((blockIdx.x * blockDim.x) >> 5) >= N) return;
+    if ((int)(blockIdx.x * 8) >= N) return;                  // capacity-sized grid (8 rows per workgroup)
+    const int half = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((N + 7) / 8)) * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     const bool active = half < N;
     const int n = active ? (row_order ? row_order[half] : half) : 0;   // spatially coherent visiting order
     const int b = d3f_find_elem(offs, B, n);
@@ -329,8 +331,8 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
               const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
               float* __restrict__ score, const int* __restrict__ row_order) {
     N = min(N, offs[B]);
-    const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
-    if ((int)((blockIdx.x * blockDim.x) >> 5) >= N) return;
+    if ((int)(blockIdx.x * 8) >= N) return;                  // capacity-sized grid (8 rows per workgroup)
+    const int half = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((N + 7) / 8)) * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     const bool active = half < N;
     const int n = active ? (row_order ? row_order[half] : half) : 0;
     const int slot = l >> 3, c4 = (l & 7) << 2;     // row slot 0..3, first of this lane's 4 channels

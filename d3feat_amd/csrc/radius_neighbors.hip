@@ -195,7 +195,6 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     const unsigned long long gmask = (LPQ == 64) ? ~0ull : (((1ull << LPQ) - 1ull) << gshift);
     float* hd2 = (float*)smem + (size_t)grp * 2 * cap;
     int* hidx = (int*)hd2 + cap;
-    const int wq = blockIdx.x * QPB + grp;
     // the per-element grid geometry (a handful of 56-byte records) is staged in LDS by the workgroup's first lanes while the
     // queries' own first loads are in flight: el[b] then costs an LDS read instead of a dependent memory round trip
     __shared__ NbElem sel[NB_EL_LDS];
@@ -206,7 +205,11 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     }
     int nq_real = 0;
     for (int j = 0; j < B; ++j) nq_real += qlens[j];
-    if (wq >= min(Nq, nq_real)) return;   // Nq is the capacity, sum(qlens) the real number of queries
+    const int nq = min(Nq, nq_real);      // Nq is the capacity, sum(qlens) the real number of queries
+    if ((int)(blockIdx.x * QPB) >= nq) return;
+    // one contiguous run of query blocks per XCD (common.h): neighbouring blocks read the same candidate runs
+    const int wq = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((nq + QPB - 1) / QPB)) * QPB + grp;
+    if (wq >= nq) return;
     if (pad == D3F_PAD_NUM_SUPPORTS) pad = *ns_dev;
     // queries that ARE the supports are visited in cell order: neighbouring groups then share their candidate runs in L2;
     // the cell-sorted copy holds position AND index of the wq-th support in one 16-byte record, so the query needs no
