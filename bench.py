@@ -251,7 +251,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    npts = int(np.mean(shard.frag_rows))
+    npts = int(np.mean(shard.frag_rows)) if shard.frag_rows else 0
     gathered_rows = [int(g[0].shape[0]) for g in gathered]
     gathered_frags = [len(g[1]) for g in gathered]
     del gathered

@@ -209,7 +209,7 @@ class FragmentEngine:
             for p in parts:
                 if isinstance(p, ops.RawRecords):      # file records: bytes to the device, xyz decoded in place (stage-0 ingestion)
                     p.decode(self.device, out=sl.raw[o:o + p.shape[0]])
-                else:
+                elif p.data_ptr() != sl.raw[o:].data_ptr():     # a producer may have written straight into the slot's buffer
                     sl.raw[o:o + p.shape[0]].copy_(p, non_blocking=True)
                 o += int(p.shape[0])
             sl.raw_len.copy_(sl.host_n, non_blocking=True)
