@@ -122,6 +122,27 @@ __global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict_
     if (lane == 0) pos[row] = s > 0.0 ? 1 : 0;
 }
 
+// 16-byte loads, LPR lanes per row (64 / LPR rows per wavefront): for the narrow rows of the fine levels the one-row-per-
+// wavefront form spends its time in the 64-lane fp64 butterfly, not in the loads.  Same fp64 sum, another (equally exact) order.
+template <int LPR>
+__global__ void __launch_bounds__(256) kp_rowpos_vec_kernel(const float* __restrict__ f, int Ns, const int* __restrict__ Ns_dev,
+                                                            int ldf, int Cin, unsigned char* __restrict__ pos) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = t / LPR;
+    const int l = (int)(t % LPR);
+    const bool in = row < (long long)d3f_dyn(Ns, Ns_dev);
+    double s = 0.0;
+    if (in) {
+        for (int c = 4 * l; c < Cin; c += 4 * LPR) {
+            const float4 v = *(const float4*)&f[(size_t)row * ldf + c];
+            s += (double)v.x; s += (double)v.y; s += (double)v.z; s += (double)v.w;
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+    if (in && l == 0) pos[row] = s > 0.0 ? 1 : 0;
+}
+
 template <int LQ, bool FAST>  // lanes per query = Cin / 4; FAST: linear / sum / 15 kernel points (kp_influences_t)
 __global__ void __launch_bounds__(256)
 kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
@@ -320,6 +341,8 @@ kpconv_c1_fused_kernel(const float* __restrict__ q, int Nq, const float* __restr
 // kernel point only (lane 15 counts the positive neighbours), so no cross-lane reduction of 15 sums per query is needed
 // (the neighbour-lane form spends 90 shuffles per query on it).  The 15-term contraction with K_values[:,0,:] then runs over
 // an LDS copy of the 16 x 16 sums with lanes = output channels.
+#define C1_SC 64                    // neighbours staged per pass (4 per loader lane)
+#define C1_QS (C1_SC * 4 + 4)      // floats per query in LDS; +4 de-phases the four queries of a wavefront (b128 broadcasts)
 __global__ void __launch_bounds__(256)
 kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                     int ld_idx, int K, const float* __restrict__ f, int ldf, KpParams P, const float* __restrict__ W,
@@ -332,6 +355,7 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     __shared__ float skp[KP_MAXP * 3];
     __shared__ float sacc[16][17];
     __shared__ int sq[16];
+    __shared__ __attribute__((aligned(16))) float snb[16 * C1_QS];     // per query: C1_SC records {s - q, f}
     const int tid = threadIdx.x, p = tid & 15, ql = tid >> 4;
     if (tid < KP_MAXP * 3) skp[tid] = P.kp[tid];
     const int qslot = tile * 16 + ql;
@@ -345,33 +369,49 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     const int* row = idx + (size_t)qi * ld_idx;
     float acc = 0.f;       // lanes 0..14: sum_k h_p * f;  lane 15: number of neighbours with f > 0
     const float sig = P.extent * 0.3f, gden = 2.0f * sig * sig + 1e-9f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const int mine = (live && k0 + p < K) ? row[k0 + p] : -1;      // 16 indices per group load
-        const int kn = min(16, K - k0);
-        for (int kk = 0; kk < kn; kk += 8) {                           // 8 neighbours in flight
-            int id[8];
-            float px[8], py[8], pz[8], fv[8];
+    // The 16 lanes of a query first act as LOADERS: lane p fetches neighbours p, p + 16, p + 32, p + 48 of the pass (index,
+    // then position and feature, all four in flight) and parks (s - q, f) as one 16-byte record in LDS; then every lane walks
+    // the records (one broadcast ds_read_b128 per neighbour).  Before, every lane issued its own four dword loads per
+    // neighbour -- 16 identical addresses per instruction -- and the kernel was bound by the CU's address unit, not by bytes.
+    float4* mynb = (float4*)(snb + ql * C1_QS);
+    const int gshift = 16 * (ql & 3);                                  // this query's lanes inside the wavefront ballot
+    for (int k0 = 0; k0 < K; k0 += C1_SC) {
+        if (k0) __syncthreads();                                       // the previous pass is consumed by every lane
+        int id[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                id[u] = __shfl(mine, min(kk + u, 15), 16);
-                const bool ok = kk + u < kn && id[u] >= 0 && id[u] < Ns;
-                if (!ok) id[u] = -1;
-                const size_t o3 = 3 * (size_t)(ok ? id[u] : 0);
-                px[u] = s[o3]; py[u] = s[o3 + 1]; pz[u] = s[o3 + 2];
-                fv[u] = ok ? f[(size_t)id[u] * ldf] : 0.f;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + p + 16 * j;
+            id[j] = (live && k < K) ? row[k] : -1;
+        }
+        float px[4], py[4], pz[4], fv[4];
+        bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (id[u] < 0) continue;
-                if (p == 15) { acc += (fv[u] > 0.f) ? 1.f : 0.f; continue; }
-                const float dx = (px[u] - qx) - kx, dy = (py[u] - qy) - ky, dz = (pz[u] - qz) - kz;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                float h;
-                if (P.influence == 1) h = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2 + 1e-10f) * P.inv_2extent, 0.0f);
-                else if (P.influence == 0) h = 1.0f;
-                else h = expf(-d2 / gden);
-                acc = fmaf(h, fv[u], acc);
-            }
+        for (int j = 0; j < 4; ++j) {
+            ok[j] = id[j] >= 0 && id[j] < Ns;
+            const size_t o3 = 3 * (size_t)(ok[j] ? id[j] : 0);
+            px[j] = s[o3]; py[j] = s[o3 + 1]; pz[j] = s[o3 + 2];
+            fv[j] = ok[j] ? f[(size_t)id[j] * ldf] : 0.f;
+        }
+        unsigned long long valid = 0ull;                               // bit u: neighbour k0 + u of THIS query is real
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mynb[p + 16 * j] = make_float4(px[j] - qx, py[j] - qy, pz[j] - qz, fv[j]);
+            valid |= ((__ballot(ok[j]) >> gshift) & 0xFFFFull) << (16 * j);
+        }
+        __syncthreads();
+        const int kn = min(C1_SC, K - k0);
+#pragma unroll 4
+        for (int u = 0; u < kn; ++u) {
+            if (!((valid >> u) & 1ull)) continue;
+            const float4 v = mynb[u];
+            if (p == 15) { acc += (v.w > 0.f) ? 1.f : 0.f; continue; }
+            const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            float h;
+            if (P.influence == 1) h = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2 + 1e-10f) * P.inv_2extent, 0.0f);
+            else if (P.influence == 0) h = 1.0f;
+            else h = expf(-d2 / gden);
+            acc = fmaf(h, v.w, acc);
         }
     }
     sacc[ql][p] = (kp_lane || p == 15) ? acc : 0.f;
@@ -886,7 +926,18 @@ extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsign
     if (Ns < 0 || Cin < 1 || ldf < Cin) return D3F_ERR_ARG;
     if (Ns == 0) return D3F_OK;
     if (!f || !row_pos) return D3F_ERR_ARG;
-    kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, Ns_dev, ldf, Cin, row_pos);
+    if (Cin % 4 == 0 && ldf % 4 == 0 && ((uintptr_t)f & 15) == 0) {
+        const int q4 = Cin / 4;
+#define D3F_ROWPOS(LPR_) kp_rowpos_vec_kernel<LPR_><<<d3f_cdiv((long long)Ns * LPR_, 256), 256, 0, stream>>>(f, Ns, Ns_dev, ldf, Cin, row_pos)
+        if (q4 <= 4) D3F_ROWPOS(4);
+        else if (q4 <= 8) D3F_ROWPOS(8);
+        else if (q4 <= 16) D3F_ROWPOS(16);
+        else if (q4 <= 32) D3F_ROWPOS(32);
+        else D3F_ROWPOS(64);
+#undef D3F_ROWPOS
+    } else {
+        kp_rowpos_kernel<<<d3f_cdiv((long long)Ns * 64, 256), 256, 0, stream>>>(f, Ns, Ns_dev, ldf, Cin, row_pos);
+    }
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
