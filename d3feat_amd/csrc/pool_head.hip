@@ -185,39 +185,53 @@ extern "C" int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, con
 // C <= 32 (the shipped 32-d descriptor), generally ceil(C/32) channels per lane; each neighbour row is one
 // coalesced 128-byte read; channel reductions are 5-step xor shuffles inside the 32-lane half.
 // ------------------------------------------------------------------------------------------------
-__global__ void head_max_init_kernel(const int* __restrict__ lens, const int* __restrict__ include_zero_dev, int group, int B,
-                                     unsigned* __restrict__ mx, int* __restrict__ offs) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        // include_zero_dev == NULL: derive it from the lengths (datasets/common.py:453-496: a row of in_batches holds the
-        // shadow index iff the cloud is shorter than the longest one, or all clouds have the same length) -- inside every
-        // group of `group` consecutive clouds (one reference stack each; group <= 0: the whole stack is one)
-        const int g = group > 0 ? group : B;
-        int s = 0;
-        for (int b0 = 0; b0 < B; b0 += g) {
-            const int b1 = min(b0 + g, B);
-            int longest = 0, all_eq = 1;
-            for (int b = b0; b < b1; ++b) longest = max(longest, lens[b]);
-            for (int b = b0; b < b1; ++b) all_eq &= (lens[b] == longest);
-            for (int b = b0; b < b1; ++b) {
-                offs[b] = s;
-                s += lens[b];
-                const int inc = include_zero_dev ? include_zero_dev[b] : ((lens[b] < longest || all_eq) ? 1 : 0);
-                mx[b] = inc ? d3f_f2ord(0.f) : 0u;
-            }
-        }
-        offs[B] = s;
-    }
+__global__ void __launch_bounds__(256) head_max_init_kernel(const int* __restrict__ lens, const int* __restrict__ include_zero_dev,
+                                                            int group, int B, unsigned* __restrict__ mx, int* __restrict__ offs) {
+    // include_zero_dev == NULL: derive it from the lengths (datasets/common.py:453-496: a row of in_batches holds the
+    // shadow index iff the cloud is shorter than the longest one, or all clouds have the same length) -- inside every
+    // group of `group` consecutive clouds (one reference stack each; group <= 0: the whole stack is one).
+    // One workgroup, thread b = cloud b (B <= D3F_MAX_BATCH < 256): every length is ONE load into LDS, the rest reads LDS
+    // (a serial loop over the clouds is a chain of dependent memory round trips on every replay's critical path).
+    __shared__ int slen[256];
+    const int b = threadIdx.x;
+    const int len = b < B ? lens[b] : 0;
+    const int inc_in = (include_zero_dev && b < B) ? include_zero_dev[b] : 0;
+    slen[b] = len;
+    __syncthreads();
+    if (b >= B) return;
+    const int g = group > 0 ? group : B;
+    const int g0 = b / g * g, g1 = min(g0 + g, B);           // this cloud's group
+    int before = 0;
+    for (int j = 0; j < b; ++j) before += slen[j];
+    int longest = 0, all_eq = 1;
+    for (int j = g0; j < g1; ++j) longest = max(longest, slen[j]);
+    for (int j = g0; j < g1; ++j) all_eq &= (slen[j] == longest);
+    offs[b] = before;
+    const int inc = include_zero_dev ? inc_in : ((len < longest || all_eq) ? 1 : 0);
+    mx[b] = inc ? d3f_f2ord(0.f) : 0u;
+    if (b == B - 1) offs[B] = before + len;
 }
 
+// per-cloud maximum of x (ordered-uint atomicMax).  DENSE: ldx == C and 16-byte aligned -> the cloud's rows are one flat
+// float4 range (no index arithmetic per element)
+template <bool DENSE>
 __global__ void __launch_bounds__(256) head_max_kernel(const float* __restrict__ x, int N, int ldx, int C,
                                                        const int* __restrict__ offs, int B, unsigned* __restrict__ mx) {
     const int b = blockIdx.y;
     const long long lo = (long long)offs[b] * C, hi = (long long)offs[b + 1] * C;
     unsigned m = 0u;
-    for (long long t = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < hi; t += (long long)gridDim.x * blockDim.x) {
-        const long long r = t / C;
-        const int c = (int)(t % C);
-        m = max(m, d3f_f2ord(x[(size_t)r * ldx + c]));
+    if (DENSE) {
+        const long long lo4 = lo >> 2, hi4 = hi >> 2;        // C % 4 == 0, so both ends are float4 boundaries
+        for (long long t = lo4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < hi4; t += (long long)gridDim.x * blockDim.x) {
+            const float4 v = ((const float4*)x)[t];
+            m = max(max(m, d3f_f2ord(v.x)), max(d3f_f2ord(v.y), max(d3f_f2ord(v.z), d3f_f2ord(v.w))));
+        }
+    } else {
+        for (long long t = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < hi; t += (long long)gridDim.x * blockDim.x) {
+            const long long r = t / C;
+            const int c = (int)(t % C);
+            m = max(m, d3f_f2ord(x[(size_t)r * ldx + c]));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
@@ -408,11 +422,12 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     if (!x || !idx || !lens_dev || !desc || !score || !scratch_dev) return D3F_ERR_ARG;
     unsigned* mx = (unsigned*)scratch_dev;  // [B]
     int* offs = scratch_dev + B;            // [B+1]
-    head_max_init_kernel<<<1, 64, 0, stream>>>(lens_dev, include_zero_dev, stack_group, B, mx, offs);
+    head_max_init_kernel<<<1, 256, 0, stream>>>(lens_dev, include_zero_dev, stack_group, B, mx, offs);
     int chunks = d3f_cdiv((long long)N * C, 256 * 16);
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
-    head_max_kernel<<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
+    if (ldx == C && C % 4 == 0 && ((uintptr_t)x & 15) == 0) head_max_kernel<true><<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
+    else head_max_kernel<false><<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
     const int blocks = d3f_cdiv((long long)N * 32, 256);
     const bool vec32 = C == 32 && ldx % 4 == 0 && ldd % 4 == 0 && (((uintptr_t)x | (uintptr_t)desc) & 15) == 0;
     if (vec32) head32_kernel<<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
