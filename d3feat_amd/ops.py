@@ -325,12 +325,13 @@ def _kp_host(K_points):
     host; a caller-supplied device tensor is read back once per (storage, version), not once per call."""
     if isinstance(K_points, torch.Tensor):
         key = (K_points.data_ptr(), K_points._version, tuple(K_points.shape))
-        kp = _KP_HOST.get(key)
-        if kp is None:
+        hit = _KP_HOST.get(key)
+        if hit is None:
             if len(_KP_HOST) > 256:
                 _KP_HOST.clear()
-            kp = _KP_HOST[key] = np.ascontiguousarray(K_points.detach().cpu().numpy(), dtype=np.float32)
-        return kp
+            # the entry keeps the tensor alive: its address cannot be handed to another tensor while the key is in use
+            hit = _KP_HOST[key] = (K_points, np.ascontiguousarray(K_points.detach().cpu().numpy(), dtype=np.float32))
+        return hit[1]
     return np.ascontiguousarray(K_points, dtype=np.float32)
 
 
@@ -361,19 +362,21 @@ class bf16_contraction:
 
 
 def packed_bf16_weights(W):
-    """W f32[K,N] (contiguous rows) -> the bf16 [N][Kp] copy d3f_gemm_bf16 reads; made once per (storage, shape, version)."""
+    """W f32[K,N] (contiguous rows) -> the bf16 [N][Kp] copy d3f_gemm_bf16 reads; made once per (tensor, shape, version)."""
     key = (W.data_ptr(), tuple(W.shape), W.stride(0), W._version)
-    t = _BF16_PACKED.get(key)
-    if t is None:
+    hit = _BF16_PACKED.get(key)
+    if hit is None:
         lib = _lib.load()
         K, N = W.shape
         Kp = (K + 31) // 32 * 32
         t = torch.empty((N, Kp), dtype=torch.int16, device=W.device)
         _lib.check(lib.d3f_gemm_pack_bf16(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_bf16")
-        if len(_BF16_PACKED) > 4096:
+        if len(_BF16_PACKED) > 512:
             _BF16_PACKED.clear()
-        _BF16_PACKED[key] = t
-    return t
+        # the entry keeps W alive: while the key is in use no other tensor can be allocated at its address (a key of
+        # address + shape + version alone would hand a recycled address the previous owner's packed copy)
+        hit = _BF16_PACKED[key] = (W, t)
+    return hit[1]
 
 
 def _bf16_ok(*operands):

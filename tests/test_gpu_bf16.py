@@ -51,6 +51,27 @@ def test_gemm_bf16_is_exact_on_rounded_operands(device, M, K, N):
     assert 1e-4 * scale < np.abs(got - exact).max() < 3e-2 * scale
 
 
+def test_bf16_weight_cache_survives_address_reuse(device):
+    """The packed-weight cache is keyed by address + shape + version: a NEW weight tensor that the allocator places at a
+    freed tensor's address must not get the previous owner's packed copy."""
+    from d3feat_amd import ops
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((512, 64)).astype(np.float32)
+    At = _t(A, device)
+    seen = set()
+    for rep in range(6):
+        B = (rng.standard_normal((64, 32)) / 8).astype(np.float32)
+        Bt = _t(B, device)
+        seen.add(Bt.data_ptr())
+        with ops.bf16_contraction():
+            got = ops.gemm(At, Bt).cpu().numpy()
+        ref = _bf16_round(A).astype(np.float64) @ _bf16_round(B).astype(np.float64)
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), rep
+        del Bt
+    # (with the cache holding its weights alive every matrix of the loop necessarily sits at its own address)
+    assert len(seen) == 6
+
+
 def test_gemm_bf16_composite_operands(device):
     """decoder form [ x'[idx[:,0]] | skip ] @ W and the two-branch form [A1 | A2] @ W, as the fp32 entry points."""
     from d3feat_amd import ops
