@@ -596,6 +596,19 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                            K=infos[0]["K"], Cin=infos[0]["Cin"], fused=bool(infos[0].get("fused")), agg_ms=round(agg_ms, 4),
                            gemm_ms=round(g_ms, 4) if gem else None, total_ms=round(agg_ms + g_ms, 4),
                            fragments_per_launch=Fp, total_ms_per_fragment=round((agg_ms + g_ms) / Fp, 4)))
+    # the contraction launches one by one (launch order of a pass; mean over the passes): which shapes sit under which roof
+    if per_step_gemm and roof is not None:
+        shapes = []
+        for j, (g, _) in enumerate(per_step_gemm[-1]):
+            ms_j = float(np.mean([st[j][1] for st in per_step_gemm if len(st) == len(per_step_gemm[-1])]))
+            fl = 2.0 * g["M"] * g["N"] * g["K"]
+            by = 4.0 * (g["M"] * g["K"] + g["K"] * g["N"] + g["M"] * g["N"])
+            roof_ms = 1e3 * max(fl / (MFMA_F32_PEAK_TF * 1e12), by / (HBM_PEAK_GBS * 1e9))
+            shapes.append(dict(M=int(g["M"]), N=int(g["N"]), K=int(g["K"]), us=round(ms_j * 1e3, 1),
+                               tflops=round(fl / (ms_j * 1e-3) / 1e12, 1), gbs=round(by / (ms_j * 1e-3) / 1e9, 0),
+                               bound="mfma" if fl / (MFMA_F32_PEAK_TF * 1e12) > by / (HBM_PEAK_GBS * 1e9) else "hbm",
+                               frac_of_roof=round(roof_ms / ms_j, 3)))
+        roof["contraction_launches"] = shapes
     # algorithmic flops per fragment of the two matrix-pipe families, as launched (shapes of the instrumented pass)
     fam_flops = {"gemm": sum(v["flops"] for k, v in fam.items() if k.startswith("gemm")) / nprof,
                  "kpconv": sum(v["flops"] for k, v in fam.items() if k.startswith("kpconv")) / nprof}
