@@ -104,6 +104,21 @@ __device__ __forceinline__ void kp_load_w(const float* __restrict__ pair_base, i
     w[8] = w2.x; w[9] = w2.y; w[10] = w2.z; w[11] = w2.w; w[12] = w3.x; w[13] = w3.y; w[14] = w3.z; w[15] = w3.w;
 }
 
+// Neighbour count of a query (the reference's `sum_c f > 0` test, :250-252) in phase A, where LQ consecutive lanes hold LQ
+// neighbours of one query: one wavefront ballot and a popcount by the query's first lane -- the sole writer of lcnt[ql]
+// between two barriers -- instead of one LDS atomic per neighbour on a shared word.  Must be reached by every lane.
+template <int LQ>
+__device__ __forceinline__ void kp_count_positive(bool positive, int ql, int cl, int* __restrict__ lcnt) {
+    const unsigned long long m = __ballot(positive);
+    if (LQ >= 64) {
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&lcnt[ql], __popcll(m));      // a query spans LQ / 64 wavefronts
+    } else if (cl == 0) {
+        const int sh = (threadIdx.x & 63) & ~(LQ - 1);
+        const int c = __popcll((m >> sh) & ((1ull << (LQ & 63)) - 1ull));
+        if (c) lcnt[ql] += c;
+    }
+}
+
 // row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
 // the support row, so it is evaluated once per support instead of once per (query, neighbour).
 // The test is discontinuous: a row whose fp32 sum lies within rounding of 0 flips with the summation order, and the
@@ -180,15 +195,17 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
             int id = Ns;
             if (qg < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
+            bool positive = false;
             if (id >= 0 && id < Ns) {
                 const float rx = s[3 * (size_t)id] - qx, ry = s[3 * (size_t)id + 1] - qy, rz = s[3 * (size_t)id + 2] - qz;
                 kp_influences_t<FAST>(P, rx, ry, rz, w);
-                if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
+                positive = rowpos[id] != 0;
             } else {
                 id = -1;
 #pragma unroll
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
+            kp_count_positive<LQ>(positive, ql, cl, lcnt);
             lidx[ql * KC + cl] = id;
             kp_store_w(&lw[ql * WS + cl * 16], cl, w);
         }
@@ -588,14 +605,16 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
             int id = Ns;
             if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
+            bool positive = false;
             if (id >= 0 && id < Ns) {
                 kp_influences_t<FAST>(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
-                if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
+                positive = rowpos[id] != 0;
             } else {
                 id = -1;
 #pragma unroll
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
+            kp_count_positive<KF_LQ>(positive, ql, cl, lcnt);
             lidx[ql * KF_LQ + cl] = id;
             kp_store_w(&lw[ql * KF_WS + cl * 16], cl, w);
         }
@@ -742,14 +761,16 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             int id = Ns;
             if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
+            bool positive = false;
             if (id >= 0 && id < Ns) {
                 kp_influences_t<true>(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
-                if (rowpos[id]) atomicAdd(&lcnt[ql], 1);
+                positive = rowpos[id] != 0;
             } else {
                 id = -1;
 #pragma unroll
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
+            kp_count_positive<LQ>(positive, ql, cl, lcnt);
             lidx[ql * KC + cl] = id;
             kp_store_w(&lw[ql * WS + cl * 16], cl, w);
         }
