@@ -222,7 +222,17 @@ __global__ void __launch_bounds__(256) head_max_kernel(const float* __restrict__
     unsigned m = 0u;
     if (DENSE) {
         const long long lo4 = lo >> 2, hi4 = hi >> 2;        // C % 4 == 0, so both ends are float4 boundaries
-        for (long long t = lo4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < hi4; t += (long long)gridDim.x * blockDim.x) {
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        long long t = lo4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; t + 3 * stride < hi4; t += 4 * stride) {      // four independent loads in flight per lane
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ((const float4*)x)[t + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = max(max(m, d3f_f2ord(v[u].x)), max(d3f_f2ord(v[u].y), max(d3f_f2ord(v[u].z), d3f_f2ord(v[u].w))));
+        }
+        for (; t < hi4; t += stride) {
             const float4 v = ((const float4*)x)[t];
             m = max(max(m, d3f_f2ord(v.x)), max(d3f_f2ord(v.y), max(d3f_f2ord(v.z), d3f_f2ord(v.w))));
         }
@@ -423,8 +433,11 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     unsigned* mx = (unsigned*)scratch_dev;  // [B]
     int* offs = scratch_dev + B;            // [B+1]
     head_max_init_kernel<<<1, 256, 0, stream>>>(lens_dev, include_zero_dev, stack_group, B, mx, offs);
+    // workgroups per cloud: every one ends in an atomicMax on the cloud's word -- same-address atomics serialise in L2, so as few
+    // as still fill the chip (B x chunks ~ 512) rather than as many as the rows allow
     int chunks = d3f_cdiv((long long)N * C, 256 * 16);
-    if (chunks > 256) chunks = 256;
+    const int fill = d3f_cdiv(512, B);
+    if (chunks > fill) chunks = fill;
     if (chunks < 1) chunks = 1;
     if (ldx == C && C % 4 == 0 && ((uintptr_t)x & 15) == 0) head_max_kernel<true><<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
     else head_max_kernel<false><<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
