@@ -155,18 +155,24 @@ class FragmentEngine:
             sl.raw[: per * self.nin].copy_(warm)
             sl.raw_len.fill_(per)
             with ops.private_workspace():
-                self._sequence(sl)
+                _, _, _, w_status, w_lens = self._sequence(sl)
         sl.stream.synchronize()
+        # one packed read-back per replay: [n_total, status0(2), status(k,2)..., lens(nb)]; the packing copies are nodes of
+        # the graph (no host calls per replay), only the copy to the host follows the replay
+        sl.nl = w_lens.numel()
+        sl.nstat = 1 + 2 + 2 * w_status.shape[0]
+        sl.host_stat = torch.zeros((sl.nstat + sl.nl,), dtype=torch.int32).pin_memory()
+        sl.dev_stat = torch.zeros((sl.nstat + sl.nl,), dtype=torch.int32, device=dev)
         sl.graph = torch.cuda.CUDAGraph()
         with ops.private_workspace() as pw:
             with torch.cuda.graph(sl.graph, stream=sl.stream):
                 sl.pts, sl.desc, sl.score, sl.status, sl.lens = self._sequence(sl)
+                sl.dev_stat[0:1].copy_(sl.pts.n_dev)
+                sl.dev_stat[1:3].copy_(sl.status0)
+                sl.dev_stat[3:sl.nstat].copy_(sl.status.reshape(-1))
+                sl.dev_stat[sl.nstat:].copy_(sl.lens)
         sl.keep = pw.kept          # scratch buffers referenced by the graph
-        # one packed read-back per replay: [n_total, status0(2), status(k,2)..., lens(nb)]
-        sl.nl = sl.lens.numel()
-        sl.nstat = 1 + 2 + 2 * sl.status.shape[0]
-        sl.host_stat = torch.zeros((sl.nstat + sl.nl,), dtype=torch.int32).pin_memory()
-        sl.dev_stat = torch.zeros((sl.nstat + sl.nl,), dtype=torch.int32, device=dev)
+        assert sl.lens.numel() == sl.nl and 1 + 2 + 2 * sl.status.shape[0] == sl.nstat
         sl.done = torch.cuda.Event()
         return sl
 
@@ -213,12 +219,7 @@ class FragmentEngine:
                     sl.raw[o:o + p.shape[0]].copy_(p, non_blocking=True)
                 o += int(p.shape[0])
             sl.raw_len.copy_(sl.host_n, non_blocking=True)
-            sl.graph.replay()
-            # pack [n_total | status0 | statuses | lens] and bring it back with one small copy
-            sl.dev_stat[0:1].copy_(sl.pts.n_dev)
-            sl.dev_stat[1:3].copy_(sl.status0)
-            sl.dev_stat[3:sl.nstat].copy_(sl.status.reshape(-1))
-            sl.dev_stat[sl.nstat:].copy_(sl.lens)
+            sl.graph.replay()          # ends by packing [n_total | status0 | statuses | lens] into dev_stat
             sl.host_stat.copy_(sl.dev_stat, non_blocking=True)
             sl.done.record(sl.stream)
 
