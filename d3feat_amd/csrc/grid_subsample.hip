@@ -23,7 +23,37 @@
 //     (insert / tile scan + tile sums in its last workgroup / place);
 //   * 9 + 3*rounds launches per call (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
 //     (d3f_batch_grid_subsample_async) all sizes stay on the device and an overflowing call reports an empty result.
+#include <cstring>
+#include <map>
+#include <mutex>
 #include "prims.h"
+
+// rocPRIM's radix sort resets its block counter, look-back states and digit histogram with hipMemsetAsync before every digit
+// pass.  Captured into a large graph those memset NODES were not reliably ordered against the kernel nodes (second replay of the
+// whole launch sequence faulted; a graph of the sort alone did not), so inside this translation unit the resets are kernels,
+// like every other fill of this library.
+__global__ void __launch_bounds__(256) gs_wordfill_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void __launch_bounds__(256) gs_bytefill_kernel(unsigned char* __restrict__ p, size_t n, unsigned char v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static hipError_t gs_memset_as_kernel(void* p, int value, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const unsigned char b = (unsigned char)value;
+    if ((((uintptr_t)p | bytes) & 3) == 0) {
+        const size_t n = bytes / 4;
+        const size_t blocks = (n + 255) / 256;
+        gs_wordfill_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>((unsigned*)p, n, 0x01010101u * b);
+    } else {
+        const size_t blocks = (bytes + 255) / 256;
+        gs_bytefill_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>((unsigned char*)p, bytes, b);
+    }
+    return hipGetLastError();
+}
+#define hipMemsetAsync gs_memset_as_kernel
+#include <rocprim/device/device_radix_sort.hpp>
+#undef hipMemsetAsync
 
 #define GS_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GS_KEYBITS 56
@@ -482,6 +512,92 @@ __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int 
     }
 }
 
+// ---- sort form of the point -> voxel pass (capacity mode, large clouds: the stage-0 call) ---------------------------------
+// A STABLE radix sort of (element, voxel key) -> the points of a voxel become one run, in input order (what the in-order
+// barycentre needs), its first entry is the voxel's first occurrence.  Replaces hash insert / first-occurrence gather-scan /
+// chains / count scan / in-chain rank -- five passes of random atomics and gathers over every raw point -- by one key pass, the
+// sort (rocPRIM, 4 digit passes of coalesced traffic) and two light passes; results are identical (same voxel ids, keys,
+// counts, per-voxel point order).  The 32-bit sort key holds the element in its top bits and the voxel key below: a cloud with
+// more cells than fit raises D3F_ST_OUT_OVERFLOW (empty result; the caller's eager path uses the hash form, any key < 2^56).
+__global__ void __launch_bounds__(256) gs_sortkey_kernel(const float* __restrict__ pts, int N, const int* __restrict__ offs, int B,
+                                                         float dl, const GsElem* __restrict__ el, int kb,
+                                                         unsigned* __restrict__ skey, unsigned* __restrict__ sidx,
+                                                         int* __restrict__ status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    sidx[i] = (unsigned)i;
+    if (i >= offs[B]) { skey[i] = 0xFFFFFFFFu; return; }   // capacity tail: sorts behind every real key (element field < all ones)
+    const int b = d3f_find_elem(offs, B, i);
+    const GsElem e = el[b];
+    const float fx = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 0], e.org[0]), dl));
+    const float fy = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], e.org[1]), dl));
+    const float fz = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], e.org[2]), dl));
+    int st = 0;
+    if (fx < 0.f || fy < 0.f || fz < 0.f) st |= D3F_ST_NEG_CELL;
+    const unsigned long long ix = (unsigned long long)fmaxf(fx, 0.f), iy = (unsigned long long)fmaxf(fy, 0.f),
+                             iz = (unsigned long long)fmaxf(fz, 0.f);
+    const unsigned long long key = ix + e.NX * iy + e.NX * e.NY * iz;
+    if (key > GS_KEYMASK) st |= D3F_ST_KEY_RANGE;
+    if (key >> kb) st |= D3F_ST_OUT_OVERFLOW;              // does not fit the sort key: the hash form handles it
+    if (st) atomicOr(&status[1], st);
+    skey[i] = ((unsigned)b << kb) | (unsigned)(key & ((1ull << kb) - 1ull));
+}
+
+// run heads of the sorted keys: hpos[first point of the voxel] = position of the run + 1 (hpos is zero elsewhere)
+__global__ void __launch_bounds__(256) gs_heads_kernel(int N, const int* __restrict__ n_dev, const unsigned* __restrict__ skey_s,
+                                                       const unsigned* __restrict__ sidx_s, int* __restrict__ hpos) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= min(N, *n_dev)) return;
+    const unsigned k = skey_s[j];
+    if (j == 0 || skey_s[j - 1] != k) hpos[sidx_s[j]] = j + 1;
+}
+// first-occurrence flag of point i for the voxel-id scan (sort form)
+struct GsHeadIn {
+    const int* n_dev; const int* hpos;
+    __device__ __forceinline__ int operator()(int i) const { return (i < *n_dev && hpos[i] != 0) ? 1 : 0; }
+};
+// one thread per point, the first point of every voxel fills in the voxel's record: key, run start, run length
+__global__ void __launch_bounds__(256) gs_voxels_kernel(int N, const int* __restrict__ n_dev, const int* __restrict__ hpos,
+                                                        const int* __restrict__ vscan, const int* __restrict__ vbase,
+                                                        const unsigned* __restrict__ skey_s, int kb,
+                                                        unsigned long long* __restrict__ vkey, int* __restrict__ vst,
+                                                        int* __restrict__ vcnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(N, *n_dev);
+    if (i >= n) return;
+    const int h = hpos[i];
+    if (h == 0) return;
+    const int v = d3f_scan_at(vscan, vbase, i), j = h - 1;
+    const unsigned k = skey_s[j];
+    int c = 1;
+    while (j + c < n && skey_s[j + c] == k) ++c;
+    vkey[v] = (unsigned long long)(k & ((1u << kb) - 1u));
+    vst[v] = j;
+    vcnt[v] = c;
+}
+
+static size_t gs_sort_min() {
+    // tuning knob (read once): the sort form is used by capacity-mode calls of at least this many points (0: never).  Below
+    // it the sort's fixed ~110 us of digit passes costs more than the five hash passes it replaces.
+    static const long long v = [] { const char* e = getenv("D3F_GS_SORT_MIN"); return e ? atoll(e) : 600000ll; }();
+    return v > 0 ? (size_t)v : (size_t)-1;
+}
+static size_t gs_sort_temp_bytes(int N) {
+    if (N <= 0 || (size_t)N < gs_sort_min()) return 0;
+    // asked once per size (the workspace query and the eager warm-up come before any stream capture)
+    static std::mutex mu;
+    static std::map<int, size_t> known;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(N);
+    if (it != known.end()) return it->second;
+    size_t tb = 0;
+    unsigned* z = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, tb, z, z, z, z, (size_t)N, 0u, 32u, (hipStream_t)0) != hipSuccess) tb = 0;
+    else tb += 256;
+    known[N] = tb;
+    return tb;
+}
+
 // ---- per-voxel in-order accumulation + emit (grid_subsampling.cpp:63-70, :81-92) -----------------------
 __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__ pts, const float* __restrict__ feat,
                                                        int fdim, int* __restrict__ status,
@@ -493,7 +609,8 @@ __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= status[0]) return;
     const int b = d3f_find_elem(moffs, B, v);
-    const int n = vcnt[v], st = d3f_scan_at(vstart, sbase, v);
+    // sbase == NULL: vstart holds the run starts themselves (sort form); otherwise the tiled scan of the counts
+    const int n = vcnt[v], st = sbase ? d3f_scan_at(vstart, sbase, v) : vstart[v];
     const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
     if (dest >= (size_t)out_cap) {   // more voxels than the caller's output rows (capacity mode): report, never write
         atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
@@ -571,6 +688,7 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     bytes += 6 * d3f_align((size_t)L.bucket_total * sizeof(int));
     bytes += d3f_align((n / GS_TILE + B + 8) * sizeof(int));
     bytes += 2 * d3f_align(d3f_scan_base_ints(N) * sizeof(int)) + d3f_align((4 + D3F_NCHAIN * (size_t)B) * sizeof(unsigned));
+    bytes += d3f_align(gs_sort_temp_bytes(N));              // rocPRIM scratch of the sort form
     return bytes + 4096;
 }
 
@@ -621,7 +739,11 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     A.tsum = ar.take<int>(n / GS_TILE + B + 8);
     int* vbase = ar.take<int>(d3f_scan_base_ints(N));   // tile offsets of the voxel-id scan
     int* sbase = ar.take<int>(d3f_scan_base_ints(N));   // ... of the voxel-start scan
+    // sort form of the point -> voxel pass: capacity mode, points only, large calls (see gs_sortkey_kernel)
+    const size_t sort_tb = (async && !features && ldim == 0) ? gs_sort_temp_bytes(N) : 0;
+    char* sort_tmp = ar.take<char>(sort_tb);
     if (!ar.ok) return D3F_ERR_WORKSPACE;
+    const bool use_sort = sort_tb > 0;
     A.vkey = vkey; A.moffs = moffs; A.offs = offs; A.el = el;
     if (elem_cap <= 0 || elem_cap > M_cap) elem_cap = M_cap;
     if (elem_cap > N) elem_cap = N;
@@ -635,18 +757,45 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     const D3fFill none{nullptr, 0ull, 0u};
     const unsigned long long ones_words = (unsigned long long)((char*)(vhead + n) - (char*)tkey) / 4ull;
     const unsigned long long zero_words = (unsigned long long)((char*)(vcnt + n) - (char*)meta) / 4ull;
-    if ((rc = d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
-                               D3fFill{(unsigned*)meta, zero_words, 0u}, none, none, stream)) != D3F_OK) return rc;
+    // (sort form: only the run-head markers -- vhead's storage -- and the status words need clearing)
+    if ((rc = use_sort ? d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)vhead, (unsigned long long)n, 0u},
+                                          D3fFill{(unsigned*)meta, (unsigned long long)(B + 2), 0u}, none, none, stream)
+                       : d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
+                                          D3fFill{(unsigned*)meta, zero_words, 0u}, none, none, stream)) != D3F_OK) return rc;
     GsPrepEpi prep{bbox, offs, B, dl, el, meta};
     if ((rc = d3f_bbox_launch_t(points, offs, B, N, bbox, counters, prep, stream)) != D3F_OK) return rc;
     const int nblk = d3f_cdiv(N, 256);
+    GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap, async ? elem_cap : 0x7fffffff};
+    const int* run_start = vstart;      // what gs_accum_kernel reads: the tiled scan of the counts (+ sbase), or the run starts
+    const int* run_base = sbase;
+    const int* run_points = sorted;
+    int M, maxM;       // sizes of the voxel-indexed launches
+    if (use_sort) {
+        // storage reuse: sort keys in slot / pnext, point indices in pvid / sorted, head markers in vhead, run starts in vstart
+        unsigned *skey = (unsigned*)slot, *sidx = (unsigned*)pvid, *skey_s = (unsigned*)pnext, *sidx_s = (unsigned*)sorted;
+        int* hpos = vhead;
+        int ebits = 1;
+        while ((1 << ebits) <= B) ++ebits;           // element field: b <= B - 1 < 2^ebits - 1, so no real key is all ones
+        const int kb = 32 - ebits;
+        gs_sortkey_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, kb, skey, sidx, meta);
+        D3F_LAUNCH_CHECK();
+        size_t tb = sort_tb;
+        D3F_HIP_TRY(rocprim::radix_sort_pairs((void*)sort_tmp, tb, skey, skey_s, sidx, sidx_s, (size_t)N, 0u, 32u, stream));
+        gs_heads_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, skey_s, sidx_s, hpos);
+        D3F_LAUNCH_CHECK();
+        if ((rc = d3f_scan_fold_launch(GsHeadIn{offs + B, hpos}, N, offs + B, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
+            return rc;
+        gs_voxels_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, hpos, vscan, vbase, skey_s, kb, vkey, vstart, vcnt);
+        D3F_LAUNCH_CHECK();
+        run_base = nullptr;
+        M = N < M_cap ? N : M_cap;
+        maxM = elem_cap;
+    } else {
     gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
                                                slot, meta);
     D3F_LAUNCH_CHECK();
-    GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap, async ? elem_cap : 0x7fffffff};
     if ((rc = d3f_scan_fold_launch(GsMarkIn{offs + B, slot, tfirst}, N, offs + B, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
         return rc;
-    int M, maxM;       // sizes of the voxel-indexed launches
     if (!async) {
         // The output size is data dependent (as for the reference op, whose output tensor is allocated after the
         // computation): ONE host synchronisation here brings back M, the flags and the per-element counts; everything
@@ -667,6 +816,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     if ((rc = d3f_scan_fold_launch(D3fScanIn{vcnt}, async ? N : M, meta, vstart, sbase, counters + 2, D3fNoEpi{}, stream)) != D3F_OK)
         return rc;
     gs_rank_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, pvid, vhead, pnext, vstart, sbase, sorted);
+    }
     // ---- libstdc++ iteration order ----
     // Rounds > GS_SMALL_LAST are spread grid-wide.  (Keeping ALL rounds in the single workgroup per element saves ~50 launches
     // per fragment but was measured slower end to end, 580 vs 640 fragments/s: the serial rounds of the 30 k-voxel stage sit
@@ -681,8 +831,8 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j * B);
         gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
     }
-    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
-                                                                     vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
+    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, run_start, run_base,
+                                                                     vcnt, run_points, A.vpos, sub_points, sub_features, M_cap);
     if (ldim > 0) {
         const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);

@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from d3feat_amd import ops  # noqa: E402
 
 dev = torch.device("cuda", 0)

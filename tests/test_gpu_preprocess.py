@@ -143,3 +143,17 @@ def test_full_size_properties(device):
     d = np.where(valid, ((p[np.minimum(nb, 2 * n - 1)] - p[:, None]) ** 2).sum(-1), np.inf)
     assert np.all(np.diff(d, axis=1)[valid[:, 1:]] >= -1e-9)
     assert np.all(d[valid] < 0.075 ** 2 * 1.0001)
+
+
+def test_sort_form_of_the_subsampler_equals_the_hash_form():
+    """Capacity-mode calls of >= D3F_GS_SORT_MIN points (default 600 k: the stage-0 call of a batched replay) use a stable radix
+    sort instead of the hash table; forced on for every size in a subprocess, it must reproduce the synchronous (hash) call
+    bit for bit on ragged stacks, duplicates, one-point clouds and a capacity tail."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, D3F_GS_SORT_MIN="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "gs_sort_path_check.py")], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "SORT-PATH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
