@@ -508,7 +508,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
             key = "nb_grid_build (5 launches)"
             nbytes = (12.0 + 16.0 + 4.0) * info["Ns"]
         elif name == "grid_subsample":  # 12 N + 12 M
-            key = "grid_subsample (9 + 3 rounds launches)"
+            key = "grid_subsample (hash form: 9 + 3 rounds launches; stage-0 call: sort form)"
             nbytes = 12.0 * info["N"] + 12.0 * (info["M"] or 0)
         elif name == "ind_max_pool":    # index matrix + every finer-level row once + the pooled rows
             key = "maxpool_kernel"
