@@ -200,3 +200,48 @@ def test_kitti_bin_reader_and_result_files(tmp_path):
         "descriptors/7-scenes-redkitchen/cloud_bin_12.D3Feat.npy", "keypoints/7-scenes-redkitchen/cloud_bin_12.npy",
         "scores/7-scenes-redkitchen/cloud_bin_12.npy"]
     assert np.array_equal(np.load(paths[0]), ft) and np.array_equal(np.load(paths[1]), kp) and np.array_equal(np.load(paths[2]), sc)
+
+
+def test_sort_form_of_the_voxel_pass_equals_the_reference(coracle):
+    """The stage-0 subsampler's sort form (csrc/grid_subsample.hip: gs_sortkey / stable radix sort / gs_heads / gs_voxels /
+    gs_accum) restated in numpy: a STABLE sort of the voxel keys makes every voxel one run in input order, the run's head is the
+    voxel's first occurrence, voxel ids are the ranks of the heads in input order.  Its voxels, barycentres (in-order fp32 sums x
+    float(1 / count)) and first-occurrence numbering must be exactly the reference's (grid_subsampling.cpp:24-94); the output
+    ROW order is then derived from the keys in that numbering by the same order rounds as in the hash form."""
+    rng = np.random.default_rng(17)
+    for n, dl, spread in [(20000, 0.05, 1.0), (5000, 0.03, 0.4), (1, 0.1, 1.0), (300, 0.5, 1.0)]:
+        pts = (rng.random((n, 3)) * spread + rng.uniform(-2, 2, 3)).astype(np.float32)
+        pts[: min(n, 7)] = pts[0]
+        dlf = np.float32(dl)
+        inv = np.float32(1.0) / dlf
+        org = (np.floor(pts.min(0) * inv) * dlf).astype(np.float32)
+        nx = np.floor((pts.max(0)[0] - org[0]) / dlf).astype(np.int64) + 1
+        ny = np.floor((pts.max(0)[1] - org[1]) / dlf).astype(np.int64) + 1
+        ijk = np.floor((pts - org) / dlf).astype(np.int64)
+        key = ijk[:, 0] + nx * ijk[:, 1] + nx * ny * ijk[:, 2]
+        order = np.argsort(key, kind="stable")                       # the radix sort: runs in input order
+        ks = key[order]
+        head = np.concatenate([[True], ks[1:] != ks[:-1]])
+        starts = np.flatnonzero(head)
+        counts = np.diff(np.concatenate([starts, [n]]))
+        first = order[starts]                                        # first occurrence of every voxel (stable => smallest index)
+        vid = np.argsort(np.argsort(first))                          # voxel id = rank of the head in input order (the scan)
+        bary = np.empty((len(starts), 3), np.float32)
+        for r, (s0, c) in enumerate(zip(starts, counts)):
+            acc = np.zeros(3, np.float32)
+            for i in order[s0:s0 + c]:
+                acc = (acc + pts[i]).astype(np.float32)
+            bary[vid[r]] = acc * np.float32(1.0 / float(c))
+        want = coracle.grid_subsampling(pts, dl)
+        assert want.shape == bary.shape
+        canon = lambda a: a[np.lexsort((a.view(np.uint32)[:, 2], a.view(np.uint32)[:, 1], a.view(np.uint32)[:, 0]))]
+        assert np.array_equal(canon(want).view(np.uint32), canon(bary).view(np.uint32))
+        # first-occurrence numbering: voxel v's first point is the v-th distinct key met when walking the input
+        seen, walk = set(), []
+        for k in key:
+            if int(k) not in seen:
+                seen.add(int(k))
+                walk.append(int(k))
+        keys_by_vid = np.empty(len(starts), np.int64)
+        keys_by_vid[vid] = ks[starts]
+        assert keys_by_vid.tolist() == walk
