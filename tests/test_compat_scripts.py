@@ -6,8 +6,10 @@ compat/ tree.
     are parsed where /root/reference is present -- this container -- and compared with the frozen list of SURVEY.md §8b
     everywhere); the compat tree shadows nothing else.
   * GPU: tests/compat_caller_demo.py (the same API calls as the reference demo, in the same order) runs end to end on
-    synthetic clouds with a real TensorFlow checkpoint bundle on disk; its .npz outputs equal the direct engine path.  Where
-    the reference checkout is present AND a GPU is visible, the reference's own demo_registration.py is executed as it is.
+    synthetic clouds with a real TensorFlow checkpoint bundle on disk; its .npz outputs equal the direct engine path.
+    The reference's own demo_registration.py and test_3dmatch.py are executed AS THEY ARE (byte for byte; sha256 logged) from
+    /root/reference or from the scratch mirror .ref_scratch/ (tools/make_ref_scratch.py) and their outputs are compared with
+    the direct engine path; stdout of both runs is kept under gpurun_out/ref_scripts/ (copied to profiles/ as evidence).
 """
 import ast
 import json
@@ -20,7 +22,11 @@ import pytest
 
 from conftest import GOLDEN, ROOT, write_tf_bundle
 
-REF = "/root/reference"
+# the reference's caller files: the checkout itself (build container) or the scratch mirror staged by tools/make_ref_scratch.py
+# right before a GPU visit (the GPU box has no /root/reference; .ref_scratch/ travels with gpurun's snapshot, is git-ignored)
+REF = next((d for d in ("/root/reference", os.path.join(ROOT, ".ref_scratch"))
+            if os.path.isfile(os.path.join(d, "demo_registration.py"))), "/root/reference")
+EVIDENCE = os.path.join(ROOT, "gpurun_out", "ref_scripts")
 COMPAT = os.path.join(ROOT, "compat")
 
 # the exhaustive symbol list of the two drop-in scripts (+ utils/tester.py's ModelTester, evaluate.py's RANSAC call)
@@ -204,17 +210,129 @@ def test_demo_like_caller_through_compat(device, tmp_path):
     assert 0.0 <= reg["fitness"] <= 1.0 and np.asarray(reg["transformation"]).shape == (4, 4)
 
 
+def _keep_evidence(name, script, r, extra=""):
+    import hashlib
+    os.makedirs(EVIDENCE, exist_ok=True)
+    with open(os.path.join(EVIDENCE, name + ".log"), "w") as f:
+        f.write("script %s\nsha256 %s\nreturncode %d\n%s\n---- stdout ----\n%s\n---- stderr (tail) ----\n%s\n"
+                % (script, hashlib.sha256(open(script, "rb").read()).hexdigest(), r.returncode, extra, r.stdout, r.stderr[-4000:]))
+
+
+needs_ref_scripts = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "demo_registration.py")),
+                                       reason="neither /root/reference nor .ref_scratch/ (tools/make_ref_scratch.py) present")
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "demo_registration.py")), reason="reference checkout not present")
+@needs_ref_scripts
 def test_reference_demo_script_runs_unchanged(device, tmp_path):
-    """/root/reference/demo_registration.py itself, byte for byte, in a scratch mirror of its checkout (inputs symlinked,
-    outputs local); the public checkout lacks the checkpoint's tensor data, so the initial weights are kept (flag)."""
+    """The reference's demo_registration.py itself, byte for byte, in a scratch mirror of its checkout (inputs symlinked,
+    outputs local), on the reference's own demo clouds (BASELINE configs[0]: 258 342 / 268 967 raw points).  The public checkout
+    lacks the checkpoint's tensor data, so the initialised weights (reference initialisers, seed 42) are kept -- names / shapes
+    are still validated against the real snap-54.index.  Checked: stage 0 of BOTH clouds == the reference's own
+    grid_subsampling (golden fixtures), the .npz files == the direct engine path, the script reaches its last line."""
     from d3feat_amd import compat_run
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    from d3feat_amd.utils.ply import read_ply_xyz
     cwd = tmp_path / "mirror"
     compat_run._mirror(REF, str(cwd))
-    r = _run_script(os.path.join(REF, "demo_registration.py"), cwd, {"D3FEAT_COMPAT_ALLOW_MISSING_CHECKPOINT": "1"})
+    script = os.path.join(REF, "demo_registration.py")
+    r = _run_script(script, cwd, {"D3FEAT_COMPAT_ALLOW_MISSING_CHECKPOINT": "1"})
+    _keep_evidence("demo_registration", script, r)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Model restored from results/Log_contraloss/snapshots/snap-54" in r.stdout and "RegistrationResult" in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("draw_geometries") == 4          # the script ran to its last statement (demo_registration.py:246-270)
+    clouds = [read_ply_xyz(os.path.join(REF, "demo_data", "cloud_bin_%d.ply" % i)) for i in (0, 1)]
     for i in (0, 1):
         z = np.load(cwd / "demo_data" / ("cloud_bin_%d.npz" % i))
-        assert z["features"].shape[1] == 32 and np.allclose(np.linalg.norm(z["features"], axis=1), 1.0, atol=1e-4)
+        want = np.load(os.path.join(GOLDEN, "demo_bin%d_sub003.npy" % i))
+        assert z["features"].shape == (len(want), 32) and np.allclose(np.linalg.norm(z["features"], axis=1), 1.0, atol=1e-4)
+        # same point SET as the reference's own subsampler produced (rows are in ascending-score order in the file)
+        assert np.array_equal(np.sort(z["keypts"].view([("", np.float32)] * 3), axis=0), np.sort(want.view([("", np.float32)] * 3), axis=0))
+    # the real 258 k / 269 k-point stage-0 calls, values AND row order (libstdc++ iteration order) against the reference's output
+    import torch
+    from d3feat_amd import tf_custom_ops as tfo
+    for i in (0, 1):
+        got = tfo.grid_subsampling(torch.from_numpy(clouds[i]).to(device), 0.03).cpu().numpy()
+        want = np.load(os.path.join(GOLDEN, "demo_bin%d_sub003.npy" % i))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "stage 0 of cloud_bin_%d" % i
+    W = build_variables(threedmatch_config(), seed=42).values
+    _check_npz_against_direct_path(cwd, W, clouds, device)
+
+
+def _scene_checkout(tmp_path, seed=5):
+    """A working directory shaped like the reference checkout for test_3dmatch.py: data/3DMatch/fragments/<8 scenes>/ with three
+    synthetic fragments in two of them (fragment numbers out of lexical order: 2, 10 -> sorted by int, ThreeDMatch.py:346), a log
+    folder with the reference's parameters.txt and a REAL checkpoint bundle, an older second log that must not be chosen."""
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    from d3feat_amd.utils.ply import write_ply
+    from d3feat_amd.utils.synthetic import room_fragment
+    scenes = ['7-scenes-redkitchen', 'sun3d-home_at-home_at_scan1_2013_jan_1', 'sun3d-home_md-home_md_scan9_2012_sep_30',
+              'sun3d-hotel_uc-scan3', 'sun3d-hotel_umd-maryland_hotel1', 'sun3d-hotel_umd-maryland_hotel3',
+              'sun3d-mit_76_studyroom-76-1studyroom2', 'sun3d-mit_lab_hj-lab_hj_tea_nov_2_2012_scan1_erika']
+    root = tmp_path / "checkout3dm"
+    frags = {}
+    for sc in scenes:
+        (root / "data" / "3DMatch" / "fragments" / sc).mkdir(parents=True)
+    for k, (sc, num, edge) in enumerate(((scenes[0], 10, 1.1), (scenes[0], 2, 0.9), (scenes[3], 0, 1.0))):
+        raw = room_fragment(seed + k, n_raw=50000, edge=edge)
+        assert write_ply(str(root / "data" / "3DMatch" / "fragments" / sc / ("cloud_bin_%d.ply" % num)), [raw], ["x", "y", "z"])
+        frags[(sc, num)] = raw
+    (root / "data" / "3DMatch" / "fragments" / scenes[0] / "cloud_bin_2.info.txt").write_text("not a ply\n")
+    params = open(os.path.join(GOLDEN, "parameters_3dmatch.txt")).read()
+    W = build_variables(threedmatch_config(), seed=seed, randomize_bn=True).values
+    for log in ("Log_contraloss",):
+        snaps = root / "results" / log / "snapshots"
+        snaps.mkdir(parents=True)
+        (root / "results" / log / "parameters.txt").write_text(params)
+        write_tf_bundle(str(snaps / "snap-54"), {"KernelPointNetwork/" + k: v for k, v in W.items()}, crc=False)
+        (snaps / "snap-54.meta").write_bytes(b"")
+    (root / "geometric_registration").mkdir()
+    return root, W, frags, scenes
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@needs_ref_scripts
+def test_reference_test_3dmatch_script_runs_unchanged(device, tmp_path):
+    """The reference's test_3dmatch.py itself (test_3dmatch.py:22-94 -> ModelTester / ThreeDMatchDataset of the compat tree) on a
+    synthetic 3-fragment scene folder with a real TensorFlow checkpoint bundle: the three .npy files per fragment of
+    utils/tester.py:215-229 -- rows of the FIRST cloud, ascending score, the `[:-1]` quirk of `in_batches[0]` -- equal the
+    direct library path (stage-0 subsample, calibration over the three self-pairs, exact-shape pyramid, model)."""
+    import torch
+    from d3feat_amd import tf_custom_ops as tfo
+    from d3feat_amd.datasets.common import FragmentDataset
+    from d3feat_amd.models.KPFCNN_model import KernelPointFCNN
+    from d3feat_amd.utils.config import threedmatch_config
+    root, W, frags, scenes = _scene_checkout(tmp_path)
+    script = os.path.join(REF, "test_3dmatch.py")
+    r = _run_script(script, root)
+    _keep_evidence("test_3dmatch", script, r)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Model restored from results/Log_contraloss/snapshots/snap-54" in r.stdout
+    out = root / "geometric_registration" / "D3Feat_contralo-54-pred"      # utils/tester.py:163,173
+    order = [(scenes[0], 2), (scenes[0], 10), (scenes[3], 0)]               # scene list order, fragments by number
+    gen_lines = [l for l in r.stdout.splitlines() if l.startswith("Generate cloud_bin_")]
+    assert gen_lines == ["Generate cloud_bin_%d for %s" % (n, sc) for sc, n in order], gen_lines
+    cfg = threedmatch_config()
+    subs = [tfo.grid_subsampling(torch.from_numpy(frags[k]).to(device), 0.03).cpu().numpy() for k in order]
+    ds = FragmentDataset(subs, fast=False)
+    ds.device = device
+    ds.init_test_input_pipeline(cfg)
+    model = KernelPointFCNN(ds.flat_inputs, cfg, weights=W, device=device)
+    ds.test_init_op()
+    for (sc, num), sub in zip(order, subs):
+        d, s = (t.cpu().numpy() for t in model.run())
+        n = len(sub)
+        desc = np.load(out / "descriptors" / sc / ("cloud_bin_%d.D3Feat.npy" % num))
+        kp = np.load(out / "keypoints" / sc / ("cloud_bin_%d.npy" % num))
+        score = np.load(out / "scores" / sc / ("cloud_bin_%d.npy" % num))
+        assert desc.dtype == kp.dtype == score.dtype == np.float32
+        assert desc.shape == (n, 32) and kp.shape == (n, 3) and score.shape == (n, 1)
+        o = np.argsort(s[:n, 0], kind="stable")
+        assert np.all(np.diff(score[:, 0]) >= 0)
+        assert np.array_equal(kp, sub[o]) and np.array_equal(desc, d[:n][o]) and np.array_equal(score, s[:n][o])
+    files = sorted(str(p.relative_to(out)) for p in out.rglob("*.npy"))
+    assert len(files) == 9, files

@@ -94,8 +94,9 @@ def test_config2_full_size_engine_vs_oracle(device, coracle):
     assert c["points_equal"] and c["desc_max_abs"] <= TOL and c["score_max_abs"] <= TOL, c
 
 
-def test_demo_self_pair_full_forward_vs_oracle(device, coracle):
-    """BASELINE configs[0] geometry: the reference's own subsampling of its demo cloud, as a self-pair, limits from the golden
+@pytest.mark.parametrize("which", [0, 1])
+def test_demo_self_pair_full_forward_vs_oracle(device, coracle, which):
+    """BASELINE configs[0] geometry: the reference's own subsampling of its demo clouds (both), each as a self-pair, limits from the golden
     calibration of the demo pair; exact-shape eager path (the reference's tensor shapes) and the graph engine."""
     from d3feat_amd.datasets.common import FragmentDataset
     from d3feat_amd.engine import FragmentEngine
@@ -105,7 +106,8 @@ def test_demo_self_pair_full_forward_vs_oracle(device, coracle):
     from oracle import parity as par
     cfg = threedmatch_config()
     W = build_variables(cfg, seed=3, randomize_bn=True).values
-    sub = np.load(os.path.join(GOLDEN, "demo_bin0_sub003.npy"))
+    sub = np.load(os.path.join(GOLDEN, "demo_bin%d_sub003.npy" % which))
+    assert len(sub) == (14007, 13530)[which]
     limits = np.load(os.path.join(GOLDEN, "preprocess.npz"))["calib_limits_demo_pair"].astype(np.int32)
     assert limits.tolist() == [37, 35, 36, 38, 38]
     ref = par.fragment_reference(cfg, W, None, limits, co=coracle, clouds=[sub, sub])

@@ -13,6 +13,7 @@ Contents of tests/golden/:
   demo_bin0_head.npy        f32[20000,3]  first 20 000 raw points of demo_data/cloud_bin_0.ply (input fixture)
   demo_bin0_sub003.npy      f32[14007,3]  reference grid_subsampling(cloud_bin_0, 0.03): real 3DMatch geometry at the
                                           network's input resolution (input fixture for the neighbour / network tests)
+  demo_bin1_sub003.npy      f32[13530,3]  the same for cloud_bin_1 (config #1's second cloud)
   preprocess.npz            reference outputs (see keys below)
   checkpoint_index.json     variable names / shapes / offsets decoded from results/Log_contraloss/snapshots/snap-54.index
   parameters_3dmatch.txt    results/Log_contraloss/parameters.txt (config data, for the Config.load round trip)
@@ -76,6 +77,7 @@ def main():
     sub0 = ref.grid_subsampling(raw0, 0.03)
     sub1 = ref.grid_subsampling(raw1, 0.03)
     np.save(os.path.join(OUT, "demo_bin0_sub003.npy"), sub0)
+    np.save(os.path.join(OUT, "demo_bin1_sub003.npy"), sub1)
     g["demo_raw_counts"] = np.asarray([len(raw0), len(raw1)], np.int64)
     g["demo_sub_counts"] = np.asarray([len(sub0), len(sub1)], np.int64)
     g["demo_bin1_sub003_sha256"] = np.frombuffer(bytes.fromhex(sha(sub1)), np.uint8)
