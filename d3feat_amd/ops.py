@@ -41,6 +41,11 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def trace_marker(ident, device):
+    """One named one-thread kernel on the current stream: cuts a rocprofv3 kernel trace at the ends of a timed region."""
+    _lib.check(_lib.load().d3f_trace_marker(int(ident), _stream(device)), "trace_marker")
+
+
 # ---- device-resident sizes ------------------------------------------------------------------------------------------
 # A tensor whose row count is only an upper bound carries the real count as the attribute `n_dev` (int32[1] on the
 # device); every op forwards it to the kernels (the `*_dev` arguments of include/d3feat_amd.h) and tags its outputs.

@@ -44,6 +44,10 @@ extern "C" {
 
 int d3f_version(void);
 
+/* Measurement aid (no reference counterpart): launches the one-thread kernel `d3f_trace_marker_kernel` on `stream`, so that
+ * a kernel trace of a run can be cut at the ends of a timed region (bench.py; tools/rocpd_summary.py --timed-region). */
+int d3f_trace_marker(int id, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Device-resident sizes ("capacity mode").  The reference's ops have data-dependent output sizes, which costs a host
  * round trip per op (5 per fragment on this path).  Every entry point below therefore also works with sizes that live

@@ -245,3 +245,34 @@ def test_sort_form_of_the_voxel_pass_equals_the_reference(coracle):
         keys_by_vid = np.empty(len(starts), np.int64)
         keys_by_vid[vid] = ks[starts]
         assert keys_by_vid.tolist() == walk
+
+
+def test_bench_roofline_selection_never_picks_a_multi_launch_group():
+    """bench.py's headline `roofline` object: families are tagged multi-launch by the op RECORD NAME, the
+    dominant family is the largest SINGLE-kernel one, whatever the labels look like and however large the launch-gap-dominated
+    groups time."""
+    import bench
+    from d3feat_amd.utils.config import threedmatch_config
+    cfg = threedmatch_config()
+    timed = []
+    for _ in range(2):      # two passes: the subsampling group is the largest "time", then the grid builds, then the contractions
+        timed += [("grid_subsample", dict(N=1200000, M=117000), 2.0)] * 5
+        timed += [("nb_grid_build", dict(Ns=235000), 0.9)] * 5
+        timed += [("gemm_f32", dict(M=235000, N=64, K=128), 0.06)] * 26
+        timed += [("kpconv_fused32", dict(Nq=235000, Ns=235000, K=42, Cin=32, Cout=32), 0.4)] * 2
+        timed += [("nb_search", dict(Nq=235000, Ns=235000, width=42, first_only=False), 0.12)] * 9
+        timed += [("unknown_record", {}, 50.0)]
+    fam = bench.accumulate_families(cfg, timed)
+    assert "unknown_record" not in fam
+    assert fam["grid_subsample"]["multi"] and fam["nb_grid_build"]["multi"]
+    assert not any(v["multi"] for k, v in fam.items() if k not in ("grid_subsample", "nb_grid_build"))
+    order, dominant = bench.select_dominant(fam)
+    assert order[0] == "grid_subsample" and order[1] == "nb_grid_build"
+    assert dominant == "gemm_fast_kernel", dominant                    # 2 x 26 x 0.06 = 3.12 ms
+    # the searches: 2 x 9 x 0.12 = 2.16 ms < 3.12 ms; a label that happens to contain "launches)" changes nothing
+    fam["weird (9 launches)"] = dict(fam["gemm_fast_kernel"], ms=100.0, multi=False)
+    assert bench.select_dominant(fam)[1] == "weird (9 launches)"
+    g = fam["gemm_fast_kernel"]
+    assert g["launches"] == 52 and abs(g["flops"] - 52 * 2.0 * 235000 * 64 * 128) < 1
+    # a run made of groups only has no headline kernel rather than a wrong one
+    assert bench.select_dominant({k: v for k, v in fam.items() if v["multi"]})[1] is None

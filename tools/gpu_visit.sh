@@ -36,7 +36,12 @@ prof)
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 64 --warmup 8 $LEAN > $OUT/prof_bench.json 2> $OUT/prof.err
   cd $REPO
   DB=$(ls $OUT/prof/*/*_results.db 2>/dev/null | head -1)
-  if [ -n "$DB" ]; then python tools/rocpd_summary.py $DB > $OUT/kernel_stats.csv; head -28 $OUT/kernel_stats.csv | cut -c1-150; fi
+  if [ -n "$DB" ]; then
+    python tools/rocpd_summary.py $DB > $OUT/kernel_stats.csv
+    python tools/rocpd_summary.py --timed-region --fragments 64 $DB > $OUT/kernel_stats_timed_region.csv
+    head -32 $OUT/kernel_stats_timed_region.csv | cut -c1-150
+    python tools/timeline_summary.py $DB > $OUT/timeline.json 2>/dev/null
+  fi
   rm -rf $OUT/prof/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
 pmc)
   cd /tmp
