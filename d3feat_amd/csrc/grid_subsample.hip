@@ -23,37 +23,9 @@
 //     (insert / tile scan + tile sums in its last workgroup / place);
 //   * 9 + 3*rounds launches per call (csrc/prims.h: fused reset, boxes + geometry, one-launch scans); in capacity mode
 //     (d3f_batch_grid_subsample_async) all sizes stay on the device and an overflowing call reports an empty result.
-#include <cstring>
-#include <map>
-#include <mutex>
+#include <cstdlib>
 #include "prims.h"
-
-// rocPRIM's radix sort resets its block counter, look-back states and digit histogram with hipMemsetAsync before every digit
-// pass.  Captured into a large graph those memset NODES were not reliably ordered against the kernel nodes (second replay of the
-// whole launch sequence faulted; a graph of the sort alone did not), so inside this translation unit the resets are kernels,
-// like every other fill of this library.
-__global__ void __launch_bounds__(256) gs_wordfill_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-__global__ void __launch_bounds__(256) gs_bytefill_kernel(unsigned char* __restrict__ p, size_t n, unsigned char v) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-static hipError_t gs_memset_as_kernel(void* p, int value, size_t bytes, hipStream_t stream) {
-    if (bytes == 0) return hipSuccess;
-    const unsigned char b = (unsigned char)value;
-    if ((((uintptr_t)p | bytes) & 3) == 0) {
-        const size_t n = bytes / 4;
-        const size_t blocks = (n + 255) / 256;
-        gs_wordfill_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>((unsigned*)p, n, 0x01010101u * b);
-    } else {
-        const size_t blocks = (bytes + 255) / 256;
-        gs_bytefill_kernel<<<(int)(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>((unsigned char*)p, bytes, b);
-    }
-    return hipGetLastError();
-}
-#define hipMemsetAsync gs_memset_as_kernel
-#include <rocprim/device/device_radix_sort.hpp>
-#undef hipMemsetAsync
+#include "radix_sort.h"
 
 #define GS_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define GS_KEYBITS 56
@@ -68,7 +40,7 @@ __constant__ unsigned long long D3F_CHAIN_DEV[D3F_NCHAIN] = {
 struct GsElem {
     float org[3];
     int pad0;
-    unsigned long long NX, NY;
+    unsigned long long NX, NY, NZ;
     long long bbase;  // base of this element's bucket scratch
 };
 
@@ -84,45 +56,83 @@ __device__ __forceinline__ unsigned long long gs_mix(unsigned long long x) {
 }
 
 // ---- per-element origin / grid dims (grid_subsampling.cpp:24-30), one thread per element -------------
+// Also the description of the stage-0 sort (smeta != NULL): the sort key is (element << kb) | voxel key, kb = bits of the
+// largest cell count of any element, so only kb + bits(B - 1) key bits are significant -- 21 for four 3DMatch rooms (3 digit
+// passes), 27 for a KITTI pair (4).  A key wider than 32 bits is reported (D3F_ST_KEY_WIDTH) with an empty result; the
+// caller's synchronous path (hash form, any key < 2^56) takes it.
+__device__ __forceinline__ int gs_bits(unsigned long long x) {   // bits needed to hold values 0..x
+    int b = 0;
+    while (x) { ++b; x >>= 1; }
+    return b;
+}
 __device__ __forceinline__ void gs_prep(const unsigned* __restrict__ bbox, const int* __restrict__ offs, int B, float dl,
-                                        GsElem* __restrict__ el, int* __restrict__ status) {
+                                        GsElem* __restrict__ el, int* __restrict__ status, RsMeta* __restrict__ smeta,
+                                        int n_cap) {
+    __shared__ unsigned long long sCells[256];
     const int b = threadIdx.x;   // run by ONE 256-thread workgroup (B <= 255)
-    if (b >= B) return;
-    GsElem e;
-    e.pad0 = 0;
-    const int len = offs[b + 1] - offs[b];
-    if (len <= 0) {
-        atomicOr(&status[1], D3F_ST_EMPTY_ELEMENT);
-        e.org[0] = e.org[1] = e.org[2] = 0.f;
-        e.NX = e.NY = 1;
-    } else {
-        const float inv = __fdiv_rn(1.0f, dl);  // `1/sampleDl`
-        float mx[3];
+    unsigned long long cells = 0ull;
+    if (b < B) {
+        GsElem e;
+        e.pad0 = 0;
+        const int len = offs[b + 1] - offs[b];
+        if (len <= 0) {
+            atomicOr(&status[1], D3F_ST_EMPTY_ELEMENT);
+            e.org[0] = e.org[1] = e.org[2] = 0.f;
+            e.NX = e.NY = e.NZ = 1;
+        } else {
+            const float inv = __fdiv_rn(1.0f, dl);  // `1/sampleDl`
+            float mx[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float mn = d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            mx[d] = d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            e.org[d] = __fmul_rn(floorf(__fmul_rn(mn, inv)), dl);
+            for (int d = 0; d < 3; ++d) {
+                float mn = d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                mx[d] = d3f_ord2f(__hip_atomic_load(&bbox[b * 6 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                e.org[d] = __fmul_rn(floorf(__fmul_rn(mn, inv)), dl);
+            }
+            e.NX = (unsigned long long)fmaxf(floorf(__fdiv_rn(__fsub_rn(mx[0], e.org[0]), dl)), 0.f) + 1ull;
+            e.NY = (unsigned long long)fmaxf(floorf(__fdiv_rn(__fsub_rn(mx[1], e.org[1]), dl)), 0.f) + 1ull;
+            e.NZ = (unsigned long long)fmaxf(floorf(__fdiv_rn(__fsub_rn(mx[2], e.org[2]), dl)), 0.f) + 1ull;
         }
-        e.NX = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(mx[0], e.org[0]), dl)) + 1ull;
-        e.NY = (unsigned long long)floorf(__fdiv_rn(__fsub_rn(mx[1], e.org[1]), dl)) + 1ull;
+        // bucket scratch base: prefix over elements of chain_ge(len)
+        long long base = 0;
+        for (int j = 0; j < b; ++j) {
+            long long l = offs[j + 1] - offs[j];
+            unsigned long long nb = D3F_CHAIN_DEV[D3F_NCHAIN - 1];
+            for (int c = 0; c < D3F_NCHAIN; ++c)
+                if ((long long)D3F_CHAIN_DEV[c] >= l) { nb = D3F_CHAIN_DEV[c]; break; }
+            base += (long long)nb;
+        }
+        e.bbase = base;
+        el[b] = e;
+        // cells of the element's grid, saturated (each factor < 2^32 only when the product is meaningful as a sort key)
+        const double c = (double)e.NX * (double)e.NY * (double)e.NZ;
+        cells = c >= 1.8e19 ? 0xFFFFFFFFFFFFFFFFull : e.NX * e.NY * e.NZ;
     }
-    // bucket scratch base: prefix over elements of chain_ge(len)
-    long long base = 0;
-    for (int j = 0; j < b; ++j) {
-        long long l = offs[j + 1] - offs[j];
-        unsigned long long nb = D3F_CHAIN_DEV[D3F_NCHAIN - 1];
-        for (int c = 0; c < D3F_NCHAIN; ++c)
-            if ((long long)D3F_CHAIN_DEV[c] >= l) { nb = D3F_CHAIN_DEV[c]; break; }
-        base += (long long)nb;
+    if (!smeta) return;
+    sCells[threadIdx.x] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long mx = 1ull;
+        for (int j = 0; j < B; ++j) mx = sCells[j] > mx ? sCells[j] : mx;
+        int kb = gs_bits(mx - 1ull);
+        if (kb < 1) kb = 1;
+        const int eb = gs_bits((unsigned long long)(B - 1));
+        RsMeta m;
+        m.n = min(offs[B], n_cap);
+        m.kb = kb;
+        m.bits = kb + eb;
+        if (m.bits > 32) {      // does not fit the 32-bit sort key: nothing is sorted, the result is reported empty
+            atomicOr(&status[1], D3F_ST_KEY_WIDTH);
+            m.n = 0;
+            m.bits = 8;
+        }
+        m.npass = (m.bits + 7) / 8;
+        *smeta = m;
     }
-    e.bbase = base;
-    el[b] = e;
 }
 // epilogue of the bounding-box kernel (last workgroup): origin / grid dims of every element from the finished boxes
 struct GsPrepEpi {
-    const unsigned* bbox; const int* offs; int B; float dl; GsElem* el; int* status;
-    __device__ __forceinline__ void operator()() const { gs_prep(bbox, offs, B, dl, el, status); }
+    const unsigned* bbox; const int* offs; int B; float dl; GsElem* el; int* status; RsMeta* smeta; int n_cap;
+    __device__ __forceinline__ void operator()() const { gs_prep(bbox, offs, B, dl, el, status, smeta, n_cap); }
 };
 
 // ---- voxel key per point + hash insert (grid_subsampling.cpp:49-59) ----------------------------------

@@ -1,0 +1,204 @@
+// Stable LSD radix sort of (u32 key, u32 payload) pairs for gfx950, hand written for the stage-0 voxel pass
+// (grid_subsample.hip): 8-bit digits, two launches per digit pass, every size read from HBM.
+//
+//   * The number of items n and the number of significant key bits live on the DEVICE (`RsMeta`): a captured launch
+//     sequence always issues RS_MAX_PASSES passes; a pass whose digit lies above the significant bits returns at once,
+//     so a 21-bit key (3DMatch room: 18 voxel-key bits + 3 element bits) costs 3 real passes, a KITTI sweep 4.
+//   * Pass p reads buffer (p & 1) and writes buffer ((p + 1) & 1); the sorted data end up in buffer (npass & 1).
+//     Pass 0 takes the payload to be the item's position (no index array is read).
+//   * rs_hist_kernel: one 4096-item tile per workgroup, digit histogram in LDS -> hist[tile][256] (tile-major rows of 1 KB).
+//     The histogram of pass 0 is produced by the caller's key kernel (`rs_tile_histogram`), which has the keys in
+//     registers anyway.
+//   * rs_scatter_kernel: thread d sums column d of the (tiles x 256) matrix -- everything before its own tile and the
+//     column total, <= 300 coalesced 1 KB rows out of L2 -- which replaces a separate scan launch and any
+//     cross-workgroup hand-off; digit bases by one 256-wide scan.  Ranking is wave-local and stable: a wave owns 1024
+//     consecutive items and walks them in 16 rounds of 64; the lanes of a round that hold the same digit find each other
+//     with 8 wavefront ballots (one per digit bit), rank = popcount of the peers below, and the per-wave digit counter in
+//     LDS advances by the peer count (the wave's LDS accesses are in program order: all peers read the counter, then the
+//     lowest peer writes it).  Order inside a digit = (tile, wave, round, lane) = input order.
+//   * No resets between passes or replays: every word of `hist` that a pass reads was written by the same pass.
+#pragma once
+#include "common.h"
+
+#define RS_THREADS 256
+#define RS_ROUNDS 16
+#define RS_TILE (RS_THREADS * RS_ROUNDS)   // 4096 items per workgroup
+#define RS_WAVE_ITEMS (64 * RS_ROUNDS)     // 1024 consecutive items per wave
+#define RS_MAX_PASSES 4
+
+struct RsMeta {       // device-resident description of one sort (written by the caller's prologue kernel)
+    int n;            // items
+    int bits;         // significant key bits (1..32)
+    int npass;        // ceil(bits / 8)
+    int kb;           // caller's field: bit position of the element field inside the key
+};
+
+static inline int rs_tiles(int n_cap) { return d3f_cdiv(n_cap > 0 ? n_cap : 1, RS_TILE); }
+static inline size_t rs_hist_words(int n_cap) { return (size_t)rs_tiles(n_cap) * 256; }
+
+#ifdef __HIPCC__
+// digit histogram of one tile from registers: key[r] is the item at tile position w * 1024 + r * 64 + lane (valid[r] = it
+// exists).  sHist: 256 words of LDS.  All RS_THREADS threads of the workgroup call this.
+__device__ __forceinline__ void rs_tile_histogram(const unsigned (&key)[RS_ROUNDS], unsigned valid_mask, int shift,
+                                                  unsigned* __restrict__ sHist, unsigned* __restrict__ hist_row) {
+    sHist[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r)
+        if (valid_mask & (1u << r)) atomicAdd(&sHist[(key[r] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist_row[threadIdx.x] = sHist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const RsMeta* __restrict__ meta, int pass,
+                                                             const unsigned* __restrict__ key0,
+                                                             const unsigned* __restrict__ key1,
+                                                             unsigned* __restrict__ hist) {
+    __shared__ unsigned sHist[256];
+    const int n = meta->n;
+    if (pass >= meta->npass) return;
+    const int tile = blockIdx.x;
+    if ((long long)tile * RS_TILE >= (long long)n) return;
+    const unsigned* __restrict__ src = (pass & 1) ? key1 : key0;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int base = tile * RS_TILE + w * RS_WAVE_ITEMS + lane;
+    unsigned key[RS_ROUNDS], vm = 0u;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int pos = base + r * 64;
+        key[r] = 0u;
+        if (pos < n) { key[r] = src[pos]; vm |= 1u << r; }
+    }
+    rs_tile_histogram(key, vm, pass * 8, sHist, hist + (size_t)tile * 256);
+}
+
+__global__ void __launch_bounds__(RS_THREADS) rs_scatter_kernel(const RsMeta* __restrict__ meta, int pass,
+                                                                unsigned* __restrict__ key0, unsigned* __restrict__ key1,
+                                                                unsigned* __restrict__ val0, unsigned* __restrict__ val1,
+                                                                const unsigned* __restrict__ hist) {
+    __shared__ unsigned sCnt[RS_THREADS / 64][256];   // per wave: running digit counters, then the wave's base inside the tile
+    __shared__ unsigned sBase[256];                   // global position of this tile's first item of each digit
+    __shared__ unsigned sScan[RS_THREADS / 64];
+    const int n = meta->n;
+    if (pass >= meta->npass) return;
+    const int tile = blockIdx.x;
+    if ((long long)tile * RS_TILE >= (long long)n) return;
+    const int live = (n + RS_TILE - 1) / RS_TILE;
+    const unsigned* __restrict__ ksrc = (pass & 1) ? key1 : key0;
+    const unsigned* __restrict__ vsrc = (pass & 1) ? val1 : val0;
+    unsigned* __restrict__ kdst = (pass & 1) ? key0 : key1;
+    unsigned* __restrict__ vdst = (pass & 1) ? val0 : val1;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int shift = pass * 8;
+
+    // the items first: their loads are in flight while the histogram columns are summed
+    const int base = tile * RS_TILE + w * RS_WAVE_ITEMS + lane;
+    unsigned key[RS_ROUNDS], val[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int pos = base + r * 64;
+        key[r] = 0u;
+        val[r] = (unsigned)pos;
+        if (pos < n) {
+            key[r] = ksrc[pos];
+            if (pass > 0) val[r] = vsrc[pos];
+        }
+    }
+    // column tid of the histogram matrix: items of digit tid in the tiles before this one, and in all tiles
+    unsigned before = 0u, total = 0u;
+    {
+        const unsigned* __restrict__ col = hist + tid;
+        int t = 0;
+        for (; t + 4 <= live; t += 4) {
+            const unsigned a = col[(size_t)t * 256], b = col[(size_t)(t + 1) * 256], c = col[(size_t)(t + 2) * 256],
+                           d = col[(size_t)(t + 3) * 256];
+            before += (t < tile ? a : 0u) + (t + 1 < tile ? b : 0u) + (t + 2 < tile ? c : 0u) + (t + 3 < tile ? d : 0u);
+            total += a + b + c + d;
+        }
+        for (; t < live; ++t) {
+            const unsigned a = col[(size_t)t * 256];
+            before += (t < tile) ? a : 0u;
+            total += a;
+        }
+    }
+    // exclusive scan of the column totals over the 256 digits
+    {
+        unsigned x = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = (unsigned)__shfl_up((int)x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) sScan[w] = x;
+#pragma unroll
+        for (int q = 0; q < RS_THREADS / 64; ++q) sCnt[q][tid] = 0u;
+        __syncthreads();
+        unsigned wb = 0u;
+#pragma unroll
+        for (int q = 0; q < RS_THREADS / 64; ++q) wb += (q < w) ? sScan[q] : 0u;
+        sBase[tid] = wb + x - total + before;
+    }
+    // wave-local stable ranks
+    // (volatile: the counters are shared between the lanes of the wave, the compiler must not forward a lane's earlier load)
+    unsigned rank[RS_ROUNDS];
+    volatile unsigned* myCnt = sCnt[w];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const bool valid = (base + r * 64) < n;
+        const unsigned dg = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (dg >> bit) & 1u;
+            const unsigned long long m = __ballot(one);
+            peers &= one ? m : ~m;
+        }
+        rank[r] = 0u;
+        if (valid) {
+            const unsigned prev = myCnt[dg];                                  // every peer reads the counter ...
+            const unsigned below = (unsigned)__popcll(peers & d3f_lanemask_lt());
+            rank[r] = prev + below;
+            __builtin_amdgcn_wave_barrier();
+            if (below == 0u) myCnt[dg] = prev + (unsigned)__popcll(peers);    // ... then the lowest peer advances it
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // the waves' counts of digit tid -> each wave's base inside the tile's run of that digit
+    {
+        unsigned run = sBase[tid];
+#pragma unroll
+        for (int q = 0; q < RS_THREADS / 64; ++q) {
+            const unsigned c = sCnt[q][tid];
+            sCnt[q][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        if ((base + r * 64) < n) {
+            const unsigned dg = (key[r] >> shift) & 255u;
+            const unsigned dest = myCnt[dg] + rank[r];
+            kdst[dest] = key[r];
+            vdst[dest] = val[r];
+        }
+    }
+}
+#endif
+
+// Passes 1 .. RS_MAX_PASSES-1 histogram + every scatter; the caller has launched its key kernel (keys in key0, histogram of
+// digit 0 in hist) before.  n_cap sizes the grids.
+static inline int rs_sort_launch(const RsMeta* meta, int n_cap, unsigned* key0, unsigned* key1, unsigned* val0, unsigned* val1,
+                                 unsigned* hist, hipStream_t stream) {
+    const int tiles = rs_tiles(n_cap);
+    for (int p = 0; p < RS_MAX_PASSES; ++p) {
+        if (p > 0) {
+            rs_hist_kernel<<<tiles, RS_THREADS, 0, stream>>>(meta, p, key0, key1, hist);
+            D3F_LAUNCH_CHECK();
+        }
+        rs_scatter_kernel<<<tiles, RS_THREADS, 0, stream>>>(meta, p, key0, key1, val0, val1, hist);
+        D3F_LAUNCH_CHECK();
+    }
+    return D3F_OK;
+}
