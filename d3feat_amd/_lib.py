@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("D3FEAT_AMD_LIB") or os.path.join(_HERE, "lib", "libd3
 
 D3F_OK = 0
 ERRORS = {-1: "HIP runtime / kernel launch failure", -2: "workspace too small", -3: "invalid argument"}
-ST_EMPTY_ELEMENT, ST_NEG_CELL, ST_KEY_RANGE, ST_HIT_OVERFLOW, ST_OUT_OVERFLOW = 1, 2, 4, 8, 16
+ST_EMPTY_ELEMENT, ST_NEG_CELL, ST_KEY_RANGE, ST_HIT_OVERFLOW, ST_OUT_OVERFLOW, ST_KEY_WIDTH = 1, 2, 4, 8, 16, 32
 PAD_NUM_SUPPORTS = -2147483648
 NEIGHBOR_CAP = 1024
 MAX_BATCH = 255

@@ -195,9 +195,23 @@ __global__ void __launch_bounds__(256) gs_chain_kernel(int N, const int* __restr
     atomicAdd(&vcnt[v], 1);
 }
 
+// number of voxels created by the points before point p: hash form = the first-occurrence scan itself; sort form = the
+// first-occurrence flags are BITS (one word per 32 points), scanned by popcount
+struct GsRankScan {
+    const int* vscan; const int* vbase;
+    __device__ __forceinline__ int operator()(int p) const { return d3f_scan_at(vscan, vbase, p); }
+};
+struct GsRankBits {
+    const unsigned* fbits; const int* wscan; const int* wbase;
+    __device__ __forceinline__ int operator()(int p) const {
+        const int w = p >> 5;
+        return d3f_scan_at(wscan, wbase, w) + __popc(fbits[w] & ((1u << (p & 31)) - 1u));
+    }
+};
 // epilogue of the voxel-id scan (last workgroup, total = M): per-element voxel offsets, the reported lengths and status
+template <class Rank>
 struct GsMoffsEpi {
-    const int* offs; int B; const int* vscan; const int* vbase; int* meta; int* moffs; int* sub_lens; int* status_dev;
+    const int* offs; int B; Rank rank; int* meta; int* moffs; int* sub_lens; int* status_dev;
     int out_cap;
     int elem_cap;   // capacity mode: no element may hold more voxels than this (the order rounds are launched for it)
     __device__ __forceinline__ void operator()(int M) const {
@@ -205,12 +219,14 @@ struct GsMoffsEpi {
         meta[0] = M;
         const int N = offs[B];
         // scan value at offs[b] = number of voxels created by points before element b (empty tail -> M)
-        for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : d3f_scan_at(vscan, vbase, offs[b]);
+        for (int b = 0; b <= B; ++b) moffs[b] = (b == B || offs[b] >= N) ? M : rank(offs[b]);
         // More voxels than the caller's output rows (capacity mode): flag it and report an EMPTY result, so that every
         // downstream stage of a captured launch sequence runs on zero rows instead of on partially written ones.
-        bool over = M > out_cap || (__hip_atomic_load(&meta[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & D3F_ST_OUT_OVERFLOW);
+        bool over = M > out_cap ||
+                    (__hip_atomic_load(&meta[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (D3F_ST_OUT_OVERFLOW | D3F_ST_KEY_WIDTH));
         for (int b = 0; b < B; ++b) over = over || (moffs[b + 1] - moffs[b] > elem_cap);
-        if (over) atomicOr(&meta[1], D3F_ST_OUT_OVERFLOW);
+        if (over && !(__hip_atomic_load(&meta[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & D3F_ST_KEY_WIDTH))
+            atomicOr(&meta[1], D3F_ST_OUT_OVERFLOW);
         for (int b = 0; b < B; ++b) {
             const int l = over ? 0 : moffs[b + 1] - moffs[b];
             meta[2 + b] = l;
@@ -267,9 +283,9 @@ struct GsOrderArgs {
     const int* offs;
     const GsElem* el;
     int* P[2];      // list buffers, element b at + offs[b]
-    int* nx;        // chain links, per position
+    int* nx[2];     // chain links, per position (parity sets: place(j) reads round j's while inserting round j + 1's)
     int* cd;        // reverse-scan values, per position
-    int* bkt;       // bucket of the element at a position
+    int* bkt[2];    // bucket of the element at a position (parity sets)
     int* bf[2];     // per bucket: first insertion position   (parity sets, element b at + el[b].bbase)
     int* bc[2];     // per bucket: size
     int* bh[2];     // per bucket: chain head (last insertion)
@@ -400,8 +416,8 @@ __global__ void __launch_bounds__(256) gs_order_insert_kernel(GsOrderArgs A, int
     const int bk = gs_mod(A.vkey[A.moffs[b] + id], (unsigned)nb, 1.0 / (double)nb);
     atomicMin(&A.bf[j & 1][bbase + bk], t);
     atomicAdd(&A.bc[j & 1][bbase + bk], 1);
-    A.nx[o + t] = atomicExch(&A.bh[j & 1][bbase + bk], t);
-    A.bkt[o + t] = bk;
+    A.nx[j & 1][o + t] = atomicExch(&A.bh[j & 1][bbase + bk], t);
+    A.bkt[j & 1][o + t] = bk;
 }
 
 // exclusive scan of one element's tile sums (run by ONE workgroup of 256 threads)
@@ -453,13 +469,24 @@ __global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A,
         const int o = A.offs[b];
         const long long bbase = A.el[b].bbase;
         const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+        if (!last && j + 1 < D3F_NCHAIN) {
+            // clear the other parity's bucket arrays: round j + 1 is inserted by this round's place kernel (nb_next < 2.24 hi;
+            // they were last read by round j - 1's place kernel, which has finished)
+            const int nbn = (int)D3F_CHAIN_DEV[j + 1];
+            const int stride = ((hi + GS_TILE - 1) / GS_TILE) * 256;
+            for (int i = tile * 256 + tid; i < nbn; i += stride) {
+                A.bf[(j + 1) & 1][bbase + i] = 0x7fffffff;
+                A.bc[(j + 1) & 1][bbase + i] = 0;
+                A.bh[(j + 1) & 1][bbase + i] = -1;
+            }
+        }
         int c[4], s = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int u = tile * GS_TILE + tid * 4 + k, t = hi - 1 - u;
             c[k] = 0;
             if (u < hi) {
-                const int bk = A.bkt[o + t];
+                const int bk = A.bkt[j & 1][o + t];
                 c[k] = (A.bf[j & 1][bbase + bk] == t) ? A.bc[j & 1][bbase + bk] : 0;
             }
             s += c[k];
@@ -492,6 +519,9 @@ __global__ void __launch_bounds__(256) gs_order_scan_tiles_kernel(GsOrderArgs A,
     gs_order_scan_sums(A, j, b, wsum);
 }
 
+// Placement of round j -- and, for an element that goes on, the INSERTION of round j + 1 in the same launch: the element placed
+// at `dest` is position `dest` of the next round's sequence, the new voxels nb_j .. hi' - 1 follow at their own positions
+// (two launches per grid-wide round instead of three).
 __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int j) {
     const int b = blockIdx.y;
     int M, lo, hi, nb;
@@ -500,112 +530,165 @@ __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int 
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int o = A.offs[b];
     const long long bbase = A.el[b].bbase;
+    const bool next = !last && j + 1 < D3F_NCHAIN;
+    const int nbn = next ? (int)D3F_CHAIN_DEV[j + 1] : 1;
+    int id = -1, pos = -1;          // what this thread inserts into round j + 1: voxel `id` at position `pos`
     if (t < hi) {
-        const int id = (t < lo) ? A.P[j & 1][o + t] : t;
-        const int bk = A.bkt[o + t];
+        id = (t < lo) ? A.P[j & 1][o + t] : t;
+        const int bk = A.bkt[j & 1][o + t];
         int r = 0;
-        for (int q = A.bh[j & 1][bbase + bk]; q >= 0; q = A.nx[o + q]) r += (q > t) ? 1 : 0;
+        for (int q = A.bh[j & 1][bbase + bk]; q >= 0; q = A.nx[j & 1][o + q]) r += (q > t) ? 1 : 0;
         const int f = A.bf[j & 1][bbase + bk];
         const int dest = A.cd[o + f] + A.tsum[o / GS_TILE + b + (hi - 1 - f) / GS_TILE] + r;
         A.P[(j + 1) & 1][o + dest] = id;
         if (last) A.vpos[A.moffs[b] + id] = dest;
+        pos = dest;
+    } else if (next && t < min(M, nbn)) {
+        id = pos = t;               // (hi == nb_j here: the voxels created after the rehash)
     }
-    if (!last && j + 1 < D3F_NCHAIN) {
-        // clear the other parity's bucket arrays for the next round (nb_next < 2.24 * hi)
-        const int nbn = (int)D3F_CHAIN_DEV[j + 1];
-        const int stride = gridDim.x * 256;
-        for (int i = t; i < nbn; i += stride) {
-            A.bf[(j + 1) & 1][bbase + i] = 0x7fffffff;
-            A.bc[(j + 1) & 1][bbase + i] = 0;
-            A.bh[(j + 1) & 1][bbase + i] = -1;
-        }
+    if (next && id >= 0) {
+        const int bk = gs_mod(A.vkey[A.moffs[b] + id], (unsigned)nbn, 1.0 / (double)nbn);
+        atomicMin(&A.bf[(j + 1) & 1][bbase + bk], pos);
+        atomicAdd(&A.bc[(j + 1) & 1][bbase + bk], 1);
+        A.nx[(j + 1) & 1][o + pos] = atomicExch(&A.bh[(j + 1) & 1][bbase + bk], pos);
+        A.bkt[(j + 1) & 1][o + pos] = bk;
     }
 }
 
 // ---- sort form of the point -> voxel pass (capacity mode, large clouds: the stage-0 call) ---------------------------------
 // A STABLE radix sort of (element, voxel key) -> the points of a voxel become one run, in input order (what the in-order
 // barycentre needs), its first entry is the voxel's first occurrence.  Replaces hash insert / first-occurrence gather-scan /
-// chains / count scan / in-chain rank -- five passes of random atomics and gathers over every raw point -- by one key pass, the
-// sort (rocPRIM, 4 digit passes of coalesced traffic) and two light passes; results are identical (same voxel ids, keys,
-// counts, per-voxel point order).  The 32-bit sort key holds the element in its top bits and the voxel key below: a cloud with
-// more cells than fit raises D3F_ST_OUT_OVERFLOW (empty result; the caller's eager path uses the hash form, any key < 2^56).
-__global__ void __launch_bounds__(256) gs_sortkey_kernel(const float* __restrict__ pts, int N, const int* __restrict__ offs, int B,
-                                                         float dl, const GsElem* __restrict__ el, int kb,
-                                                         unsigned* __restrict__ skey, unsigned* __restrict__ sidx,
-                                                         int* __restrict__ status) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    sidx[i] = (unsigned)i;
-    if (i >= offs[B]) { skey[i] = 0xFFFFFFFFu; return; }   // capacity tail: sorts behind every real key (element field < all ones)
-    const int b = d3f_find_elem(offs, B, i);
-    const GsElem e = el[b];
-    const float fx = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 0], e.org[0]), dl));
-    const float fy = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], e.org[1]), dl));
-    const float fz = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], e.org[2]), dl));
+// chains / count scan / in-chain rank / accumulation -- six passes of random atomics and gathers over every raw point -- by:
+//   gs_sortkey_kernel   keys from the coordinates + digit-0 histogram of the tile            (reads 12 B, writes 4 B per point)
+//   rs_* (radix_sort.h) 3 digit passes for a 21-bit key (2 launches each, 16 B per point and pass)
+//   gs_heads_kernel     run heads of the sorted keys -> first-occurrence BITS (one atomicOr per voxel)
+//   scan_fold           popcount scan of the bit words = voxel ids in insertion order; offsets / lengths / status in its epilogue
+//   gs_runs_kernel      the head of a run walks it: in-order fp32 sum, barycentre, voxel key -> per-voxel records
+//   (iteration-order rounds on the voxel keys, as in the hash form)
+//   gs_emit_kernel      barycentres to their rows
+// Results are identical to the hash form (same voxel ids, keys, per-voxel point order).
+__global__ void __launch_bounds__(RS_THREADS) gs_sortkey_kernel(const float* __restrict__ pts, const int* __restrict__ offs, int B,
+                                                                float dl, const GsElem* __restrict__ el,
+                                                                const RsMeta* __restrict__ smeta, unsigned* __restrict__ skey,
+                                                                unsigned* __restrict__ hist, int* __restrict__ status) {
+    __shared__ unsigned sHist[256];
+    __shared__ int sOffs[D3F_MAX_BATCH + 1];
+    __shared__ GsElem sEl[D3F_MAX_BATCH];
+    const int n = smeta->n, kb = smeta->kb;
+    const int tile = blockIdx.x;
+    if ((long long)tile * RS_TILE >= (long long)n) return;
+    // the element table goes through LDS: a per-point search through `offs` in memory was a chain of dependent loads
+    for (int t = threadIdx.x; t <= B; t += RS_THREADS) sOffs[t] = offs[t];
+    for (int t = threadIdx.x; t < B; t += RS_THREADS) sEl[t] = el[t];
+    __syncthreads();
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int base = tile * RS_TILE + w * RS_WAVE_ITEMS + lane;
+    // the wave's 1024 consecutive points usually belong to one cloud: one search for the wave, a per-point search otherwise
+    const int wlo = tile * RS_TILE + w * RS_WAVE_ITEMS, whi = min(wlo + RS_WAVE_ITEMS, n) - 1;
+    int b0 = 0;
+    while (b0 + 1 < B && wlo >= sOffs[b0 + 1]) ++b0;
+    const bool one_cloud = (b0 + 1 >= B) || whi < sOffs[b0 + 1];
+    unsigned key[RS_ROUNDS], vm = 0u;
     int st = 0;
-    if (fx < 0.f || fy < 0.f || fz < 0.f) st |= D3F_ST_NEG_CELL;
-    const unsigned long long ix = (unsigned long long)fmaxf(fx, 0.f), iy = (unsigned long long)fmaxf(fy, 0.f),
-                             iz = (unsigned long long)fmaxf(fz, 0.f);
-    const unsigned long long key = ix + e.NX * iy + e.NX * e.NY * iz;
-    if (key > GS_KEYMASK) st |= D3F_ST_KEY_RANGE;
-    if (key >> kb) st |= D3F_ST_OUT_OVERFLOW;              // does not fit the sort key: the hash form handles it
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int i = base + r * 64;
+        key[r] = 0u;
+        if (i < n) {
+            int b = b0;
+            if (!one_cloud)
+                while (b + 1 < B && i >= sOffs[b + 1]) ++b;
+            const float ox = sEl[b].org[0], oy = sEl[b].org[1], oz = sEl[b].org[2];
+            // 32-bit index arithmetic: this kernel only runs when NX NY NZ <= 2^kb <= 2^32 (gs_prep; otherwise n == 0), and
+            // the bounding box keeps every index below its dimension
+            const unsigned NX = (unsigned)sEl[b].NX, NY = (unsigned)sEl[b].NY;
+            const float fx = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 0], ox), dl));
+            const float fy = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], oy), dl));
+            const float fz = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], oz), dl));
+            if (fx < 0.f || fy < 0.f || fz < 0.f) st |= D3F_ST_NEG_CELL;
+            const unsigned ix = (unsigned)fmaxf(fx, 0.f), iy = (unsigned)fmaxf(fy, 0.f), iz = (unsigned)fmaxf(fz, 0.f);
+            const unsigned k = ix + NX * (iy + NY * iz);                 // < NX NY NZ <= 2^kb
+            key[r] = (kb < 32 ? ((unsigned)b << kb) : 0u) | (kb < 32 ? (k & ((1u << kb) - 1u)) : k);
+            skey[i] = key[r];
+            vm |= 1u << r;
+        }
+    }
     if (st) atomicOr(&status[1], st);
-    skey[i] = ((unsigned)b << kb) | (unsigned)(key & ((1ull << kb) - 1ull));
+    rs_tile_histogram(key, vm, 0, sHist, hist + (size_t)tile * 256);
 }
 
-// run heads of the sorted keys: hpos[first point of the voxel] = position of the run + 1 (hpos is zero elsewhere)
-__global__ void __launch_bounds__(256) gs_heads_kernel(int N, const int* __restrict__ n_dev, const unsigned* __restrict__ skey_s,
-                                                       const unsigned* __restrict__ sidx_s, int* __restrict__ hpos) {
+// run heads of the sorted keys: bit i of fbits <- point i is the first point of its voxel (the sort is stable)
+__global__ void __launch_bounds__(256) gs_heads_kernel(int N, const RsMeta* __restrict__ smeta, const unsigned* __restrict__ key0,
+                                                       const unsigned* __restrict__ key1, const unsigned* __restrict__ val0,
+                                                       const unsigned* __restrict__ val1, unsigned* __restrict__ fbits) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= min(N, *n_dev)) return;
-    const unsigned k = skey_s[j];
-    if (j == 0 || skey_s[j - 1] != k) hpos[sidx_s[j]] = j + 1;
+    if (j >= min(N, smeta->n)) return;
+    const unsigned* __restrict__ ks = (smeta->npass & 1) ? key1 : key0;
+    const unsigned* __restrict__ vs = (smeta->npass & 1) ? val1 : val0;
+    const unsigned k = ks[j];
+    if (j == 0 || ks[j - 1] != k) {
+        const unsigned i = vs[j];
+        atomicOr(&fbits[i >> 5], 1u << (i & 31u));
+    }
 }
-// first-occurrence flag of point i for the voxel-id scan (sort form)
-struct GsHeadIn {
-    const int* n_dev; const int* hpos;
-    __device__ __forceinline__ int operator()(int i) const { return (i < *n_dev && hpos[i] != 0) ? 1 : 0; }
+// input of the voxel-id scan: first occurrences per word of 32 points
+struct GsBitsIn {
+    const unsigned* fbits;
+    __device__ __forceinline__ int operator()(int w) const { return __popc(fbits[w]); }
 };
-// one thread per point, the first point of every voxel fills in the voxel's record: key, run start, run length
-__global__ void __launch_bounds__(256) gs_voxels_kernel(int N, const int* __restrict__ n_dev, const int* __restrict__ hpos,
-                                                        const int* __restrict__ vscan, const int* __restrict__ vbase,
-                                                        const unsigned* __restrict__ skey_s, int kb,
-                                                        unsigned long long* __restrict__ vkey, int* __restrict__ vst,
-                                                        int* __restrict__ vcnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = min(N, *n_dev);
-    if (i >= n) return;
-    const int h = hpos[i];
-    if (h == 0) return;
-    const int v = d3f_scan_at(vscan, vbase, i), j = h - 1;
-    const unsigned k = skey_s[j];
+// one thread per sorted position; the head of a run owns the voxel: id by bit rank, key, in-order barycentre
+// (grid_subsampling.cpp:63-70, :81-92: fp32 sum in input order x (float)(1.0 / count))
+__global__ void __launch_bounds__(256) gs_runs_kernel(int N, const RsMeta* __restrict__ smeta, const unsigned* __restrict__ key0,
+                                                      const unsigned* __restrict__ key1, const unsigned* __restrict__ val0,
+                                                      const unsigned* __restrict__ val1, GsRankBits rank,
+                                                      const float* __restrict__ pts, unsigned long long* __restrict__ vkey,
+                                                      float* __restrict__ bary) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(N, smeta->n);
+    if (j >= n) return;
+    const unsigned* __restrict__ ks = (smeta->npass & 1) ? key1 : key0;
+    const unsigned* __restrict__ vs = (smeta->npass & 1) ? val1 : val0;
+    const unsigned k = ks[j];
+    if (j != 0 && ks[j - 1] == k) return;
+    size_t i = vs[j];
+    const int v = rank((int)i);
+    float sx = pts[3 * i + 0], sy = pts[3 * i + 1], sz = pts[3 * i + 2];
     int c = 1;
-    while (j + c < n && skey_s[j + c] == k) ++c;
-    vkey[v] = (unsigned long long)(k & ((1u << kb) - 1u));
-    vst[v] = j;
-    vcnt[v] = c;
+    while (j + c < n && ks[j + c] == k) {
+        i = vs[j + c];
+        sx = __fadd_rn(sx, pts[3 * i + 0]);
+        sy = __fadd_rn(sy, pts[3 * i + 1]);
+        sz = __fadd_rn(sz, pts[3 * i + 2]);
+        ++c;
+    }
+    const float sc = (float)(1.0 / (double)c);  // `1.0 / v.second.count` is a double, narrowed by operator*(PointXYZ, float)
+    vkey[v] = (unsigned long long)(smeta->kb < 32 ? (k & ((1u << smeta->kb) - 1u)) : k);
+    bary[3 * (size_t)v + 0] = __fmul_rn(sx, sc);
+    bary[3 * (size_t)v + 1] = __fmul_rn(sy, sc);
+    bary[3 * (size_t)v + 2] = __fmul_rn(sz, sc);
+}
+// barycentre of voxel v -> output row (element offset + iteration-order position)
+__global__ void __launch_bounds__(256) gs_emit_kernel(int* __restrict__ status, const int* __restrict__ moffs, int B,
+                                                      const int* __restrict__ vpos, const float* __restrict__ bary,
+                                                      float* __restrict__ out_p, int out_cap) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= status[0]) return;
+    const int b = d3f_find_elem(moffs, B, v);
+    const size_t dest = (size_t)moffs[b] + (size_t)vpos[v];
+    if (dest >= (size_t)out_cap) {   // (cannot happen once the epilogue has checked M: kept as the last line of defence)
+        atomicOr(&status[1], D3F_ST_OUT_OVERFLOW);
+        return;
+    }
+    out_p[3 * dest + 0] = bary[3 * (size_t)v + 0];
+    out_p[3 * dest + 1] = bary[3 * (size_t)v + 1];
+    out_p[3 * dest + 2] = bary[3 * (size_t)v + 2];
 }
 
 static size_t gs_sort_min() {
-    // tuning knob (read once): the sort form is used by capacity-mode calls of at least this many points (0: never).  Below
-    // it the sort's fixed ~110 us of digit passes costs more than the five hash passes it replaces.
-    static const long long v = [] { const char* e = getenv("D3F_GS_SORT_MIN"); return e ? atoll(e) : 600000ll; }();
+    // the sort form is used by capacity-mode calls of at least this many points; below it the hash form's five passes over
+    // a few ten thousand points are cheaper than three digit passes (measured: profiles/r03_experiments.txt)
+    static const long long v = [] { const char* e = getenv("D3F_GS_SORT_MIN"); return e ? atoll(e) : 1ll; }();
     return v > 0 ? (size_t)v : (size_t)-1;
-}
-static size_t gs_sort_temp_bytes(int N) {
-    if (N <= 0 || (size_t)N < gs_sort_min()) return 0;
-    // asked once per size (the workspace query and the eager warm-up come before any stream capture)
-    static std::mutex mu;
-    static std::map<int, size_t> known;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = known.find(N);
-    if (it != known.end()) return it->second;
-    size_t tb = 0;
-    unsigned* z = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, tb, z, z, z, z, (size_t)N, 0u, 32u, (hipStream_t)0) != hipSuccess) tb = 0;
-    else tb += 256;
-    known[N] = tb;
-    return tb;
 }
 
 // ---- per-voxel in-order accumulation + emit (grid_subsampling.cpp:63-70, :81-92) -----------------------
@@ -694,11 +777,13 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     bytes += d3f_align(L.cap * sizeof(unsigned long long)); // tkey
     bytes += d3f_align(L.cap * sizeof(int));                // tfirst
     bytes += d3f_align(n * sizeof(unsigned long long));     // vkey
-    bytes += 14 * d3f_align(n * sizeof(int));               // slot vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx cd bkt
+    bytes += 16 * d3f_align(n * sizeof(int));               // slot vscan pvid vhead vcnt pnext vstart sorted vpos L0 L1 nx(2) cd bkt(2)
     bytes += 6 * d3f_align((size_t)L.bucket_total * sizeof(int));
     bytes += d3f_align((n / GS_TILE + B + 8) * sizeof(int));
     bytes += 2 * d3f_align(d3f_scan_base_ints(N) * sizeof(int)) + d3f_align((4 + D3F_NCHAIN * (size_t)B) * sizeof(unsigned));
-    bytes += d3f_align(gs_sort_temp_bytes(N));              // rocPRIM scratch of the sort form
+    // sort form: digit histograms, first-occurrence bits, per-voxel barycentres, the sort's description
+    bytes += d3f_align(rs_hist_words(N) * sizeof(unsigned)) + d3f_align((n / 32 + 2) * sizeof(unsigned)) +
+             d3f_align(3 * n * sizeof(float)) + d3f_align(sizeof(RsMeta));
     return bytes + 4096;
 }
 
@@ -738,9 +823,11 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     A.vpos = ar.take<int>(n);
     A.P[0] = ar.take<int>(n);
     A.P[1] = ar.take<int>(n);
-    A.nx = ar.take<int>(n);
+    A.nx[0] = ar.take<int>(n);
+    A.nx[1] = ar.take<int>(n);
     A.cd = ar.take<int>(n);
-    A.bkt = ar.take<int>(n);
+    A.bkt[0] = ar.take<int>(n);
+    A.bkt[1] = ar.take<int>(n);
     for (int k = 0; k < 2; ++k) {
         A.bf[k] = ar.take<int>((size_t)L.bucket_total);
         A.bc[k] = ar.take<int>((size_t)L.bucket_total);
@@ -750,10 +837,12 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     int* vbase = ar.take<int>(d3f_scan_base_ints(N));   // tile offsets of the voxel-id scan
     int* sbase = ar.take<int>(d3f_scan_base_ints(N));   // ... of the voxel-start scan
     // sort form of the point -> voxel pass: capacity mode, points only, large calls (see gs_sortkey_kernel)
-    const size_t sort_tb = (async && !features && ldim == 0) ? gs_sort_temp_bytes(N) : 0;
-    char* sort_tmp = ar.take<char>(sort_tb);
+    const bool use_sort = async && !features && ldim == 0 && (size_t)N >= gs_sort_min();
+    unsigned* rs_hist = ar.take<unsigned>(rs_hist_words(N));
+    unsigned* fbits = ar.take<unsigned>(n / 32 + 2);
+    float* bary = ar.take<float>(3 * n);
+    RsMeta* smeta = ar.take<RsMeta>(1);
     if (!ar.ok) return D3F_ERR_WORKSPACE;
-    const bool use_sort = sort_tb > 0;
     A.vkey = vkey; A.moffs = moffs; A.offs = offs; A.el = el;
     if (elem_cap <= 0 || elem_cap > M_cap) elem_cap = M_cap;
     if (elem_cap > N) elem_cap = N;
@@ -767,40 +856,34 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     const D3fFill none{nullptr, 0ull, 0u};
     const unsigned long long ones_words = (unsigned long long)((char*)(vhead + n) - (char*)tkey) / 4ull;
     const unsigned long long zero_words = (unsigned long long)((char*)(vcnt + n) - (char*)meta) / 4ull;
-    // (sort form: only the run-head markers -- vhead's storage -- and the status words need clearing)
-    if ((rc = use_sort ? d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)vhead, (unsigned long long)n, 0u},
+    // (sort form: only the first-occurrence bits and the status words need clearing)
+    if ((rc = use_sort ? d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{fbits, (unsigned long long)(n / 32 + 2), 0u},
                                           D3fFill{(unsigned*)meta, (unsigned long long)(B + 2), 0u}, none, none, stream)
                        : d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
                                           D3fFill{(unsigned*)meta, zero_words, 0u}, none, none, stream)) != D3F_OK) return rc;
-    GsPrepEpi prep{bbox, offs, B, dl, el, meta};
+    GsPrepEpi prep{bbox, offs, B, dl, el, meta, use_sort ? smeta : nullptr, N};
     if ((rc = d3f_bbox_launch_t(points, offs, B, N, bbox, counters, prep, stream)) != D3F_OK) return rc;
     const int nblk = d3f_cdiv(N, 256);
-    GsMoffsEpi mepi{offs, B, vscan, vbase, meta, moffs, sub_lens_dev, status_dev, M_cap, async ? elem_cap : 0x7fffffff};
-    const int* run_start = vstart;      // what gs_accum_kernel reads: the tiled scan of the counts (+ sbase), or the run starts
-    const int* run_base = sbase;
-    const int* run_points = sorted;
+    const int elem_lim = async ? elem_cap : 0x7fffffff;
     int M, maxM;       // sizes of the voxel-indexed launches
     if (use_sort) {
-        // storage reuse: sort keys in slot / pnext, point indices in pvid / sorted, head markers in vhead, run starts in vstart
-        unsigned *skey = (unsigned*)slot, *sidx = (unsigned*)pvid, *skey_s = (unsigned*)pnext, *sidx_s = (unsigned*)sorted;
-        int* hpos = vhead;
-        int ebits = 1;
-        while ((1 << ebits) <= B) ++ebits;           // element field: b <= B - 1 < 2^ebits - 1, so no real key is all ones
-        const int kb = 32 - ebits;
-        gs_sortkey_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, kb, skey, sidx, meta);
+        // storage reuse: sort keys in slot / pnext, point indices in pvid / sorted, word scan in vscan / vbase
+        unsigned *key0 = (unsigned*)slot, *key1 = (unsigned*)pnext, *val0 = (unsigned*)pvid, *val1 = (unsigned*)sorted;
+        gs_sortkey_kernel<<<rs_tiles(N), RS_THREADS, 0, stream>>>(points, offs, B, dl, el, smeta, key0, rs_hist, meta);
         D3F_LAUNCH_CHECK();
-        size_t tb = sort_tb;
-        D3F_HIP_TRY(rocprim::radix_sort_pairs((void*)sort_tmp, tb, skey, skey_s, sidx, sidx_s, (size_t)N, 0u, 32u, stream));
-        gs_heads_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, skey_s, sidx_s, hpos);
+        if ((rc = rs_sort_launch(smeta, N, key0, key1, val0, val1, rs_hist, stream)) != D3F_OK) return rc;
+        gs_heads_kernel<<<nblk, 256, 0, stream>>>(N, smeta, key0, key1, val0, val1, fbits);
         D3F_LAUNCH_CHECK();
-        if ((rc = d3f_scan_fold_launch(GsHeadIn{offs + B, hpos}, N, offs + B, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
+        const GsRankBits rank{fbits, vscan, vbase};
+        GsMoffsEpi<GsRankBits> mepi{offs, B, rank, meta, moffs, sub_lens_dev, status_dev, M_cap, elem_lim};
+        if ((rc = d3f_scan_fold_launch(GsBitsIn{fbits}, N / 32 + 1, nullptr, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
             return rc;
-        gs_voxels_kernel<<<nblk, 256, 0, stream>>>(N, offs + B, hpos, vscan, vbase, skey_s, kb, vkey, vstart, vcnt);
+        gs_runs_kernel<<<nblk, 256, 0, stream>>>(N, smeta, key0, key1, val0, val1, rank, points, vkey, bary);
         D3F_LAUNCH_CHECK();
-        run_base = nullptr;
         M = N < M_cap ? N : M_cap;
         maxM = elem_cap;
     } else {
+    GsMoffsEpi<GsRankScan> mepi{offs, B, GsRankScan{vscan, vbase}, meta, moffs, sub_lens_dev, status_dev, M_cap, elem_lim};
     gs_insert_kernel<<<nblk, 256, 0, stream>>>(points, N, offs, B, dl, el, tkey, tfirst, (unsigned long long)L.cap - 1ull,
                                                slot, meta);
     D3F_LAUNCH_CHECK();
@@ -836,13 +919,20 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     for (int j = small_last + 1; j < D3F_NCHAIN && (long long)D3F_CHAIN_HOST[j - 1] < (long long)maxM; ++j) {
         const long long nbj = (long long)D3F_CHAIN_HOST[j];
         const int hi = (int)((long long)maxM < nbj ? (long long)maxM : nbj);
-        dim3 g(d3f_cdiv(hi, 256), B), gt(d3f_cdiv(hi, GS_TILE), B);
-        gs_order_insert_kernel<<<g, 256, 0, stream>>>(A, j);
+        // the place kernel of a round also inserts the next round (when there is one): its grid covers that round's positions
+        const bool more = j + 1 < D3F_NCHAIN && nbj < (long long)maxM;
+        const long long nbn = more ? (long long)D3F_CHAIN_HOST[j + 1] : 0;
+        const int hin = more ? (int)((long long)maxM < nbn ? (long long)maxM : nbn) : hi;
+        dim3 g(d3f_cdiv(hi, 256), B), gt(d3f_cdiv(hi, GS_TILE), B), gp(d3f_cdiv(hin > hi ? hin : hi, 256), B);
+        if (j == small_last + 1) gs_order_insert_kernel<<<g, 256, 0, stream>>>(A, j);
         gs_order_scan_tiles_kernel<<<gt, 256, 0, stream>>>(A, j, B, counters + 4 + j * B);
-        gs_order_place_kernel<<<g, 256, 0, stream>>>(A, j);
+        gs_order_place_kernel<<<gp, 256, 0, stream>>>(A, j);
     }
-    gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, run_start, run_base,
-                                                                     vcnt, run_points, A.vpos, sub_points, sub_features, M_cap);
+    if (use_sort)
+        gs_emit_kernel<<<d3f_cdiv(M, 256), 256, 0, stream>>>(meta, moffs, B, A.vpos, bary, sub_points, M_cap);
+    else
+        gs_accum_kernel<<<d3f_cdiv(async ? N : M, 256), 256, 0, stream>>>(points, features, fdim, meta, moffs, B, vstart, sbase,
+                                                                         vcnt, sorted, A.vpos, sub_points, sub_features, M_cap);
     if (ldim > 0) {
         const size_t tot = (size_t)M * (size_t)ldim;
         gs_fill_kernel<<<d3f_cdiv((long long)tot, 256), 256, 0, stream>>>(sub_classes, tot, (int)0x80000000);

@@ -150,6 +150,8 @@ def _raise_flags(flags, what):
             msgs.append("a query has more than %d in-radius supports" % _lib.NEIGHBOR_CAP)
         if flags & _lib.ST_OUT_OVERFLOW:
             msgs.append("more output rows than the capacity of the output buffer")
+        if flags & _lib.ST_KEY_WIDTH:
+            msgs.append("(element, voxel key) wider than the 32-bit sort key of the capacity-mode subsampling")
         raise _lib.D3FeatLibraryError("d3feat_amd.%s: %s" % (what, "; ".join(msgs)))
     return 0
 

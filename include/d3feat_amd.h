@@ -32,6 +32,8 @@ extern "C" {
 #define D3F_ST_KEY_RANGE 4       /* voxel key >= 2^56 */
 #define D3F_ST_HIT_OVERFLOW 8    /* a query has more in-radius supports than D3F_NEIGHBOR_CAP */
 #define D3F_ST_OUT_OVERFLOW 16   /* capacity mode: more output rows than the caller's buffer holds (nothing is written out of bounds) */
+#define D3F_ST_KEY_WIDTH 32      /* capacity mode of the grid subsampling: (element, voxel key) needs more than the 32 bits of the
+                                    stage-0 sort key (a grid of > 2^32 / B cells): empty result, the synchronous call handles it */
 
 /* pad_value of the neighbour searches meaning "the number of supports as known on the DEVICE" (sum of s_lens_dev) --
  * what BatchOrderedNeighbors pads with (neighbors.cpp:324) when the host only knows an upper bound of Ns */

@@ -1,35 +1,57 @@
 """Run as a subprocess with D3F_GS_SORT_MIN=1 (tests/test_gpu_preprocess.py): the capacity-mode subsampler then takes its
-SORT form for every size, and must return bit for bit what the synchronous call (always the hash form) returns."""
+SORT form (csrc/radix_sort.h + the gs_sortkey / gs_heads / gs_runs / gs_emit kernels) for every size, and must return bit for
+bit what the ORACLE (oracle/d3f_oracle.c, pinned to the reference's C++) and the synchronous call (always the hash form)
+return: ragged stacks, duplicates, one-point clouds, sizes around the 4096-item sort tile, 100 clouds per stack, a grid that
+needs 4 digit passes, a capacity tail -- and a grid too wide for the 32-bit sort key is REPORTED (D3F_ST_KEY_WIDTH), empty."""
+import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from d3feat_amd import ops  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from d3feat_amd import _lib, ops  # noqa: E402
+from oracle.clib import COracle  # noqa: E402
 
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(3)
+co = COracle()
 cases = []
+#        B   points/cloud  dl    spread
 for B, n, dl, spread in [(1, 5000, 0.05, 1.0), (4, 20000, 0.03, 2.2), (8, 3000, 0.1, 1.0), (3, 40000, 0.02, 0.5), (2, 1, 0.05, 1.0),
-                         (5, 700, 0.5, 1.0)]:
-    lens = [max(1, int(n * f)) for f in rng.uniform(0.5, 1.0, B)]
+                         (5, 700, 0.5, 1.0), (1, 4096, 0.05, 1.0), (1, 4097, 0.05, 1.0), (2, 8192, 0.04, 1.5), (100, 300, 0.1, 1.0),
+                         (2, 60000, 0.3, 150.0), (4, 300000, 0.03, 1.68), (1, 1, 0.03, 1.0)]:
+    lens = [max(1, int(n * f)) for f in rng.uniform(0.5, 1.0, B)] if n > 1 else [1] * B
     pts = [((rng.random((l, 3)) * spread) + rng.uniform(-3, 3, 3)).astype(np.float32) for l in lens]
     pts[0][: min(10, lens[0])] = pts[0][0]            # duplicates: a crowded voxel
     cases.append((np.concatenate(pts), lens, dl))
 for pts, lens, dl in cases:
     P = torch.from_numpy(pts).to(dev)
+    lens_np = np.asarray(lens, np.int32)
+    ora_p, ora_l = co.batch_grid_subsampling(pts, lens_np, dl)                         # the oracle (plain C restatement)
     want_p, want_l, _, _ = ops.batch_grid_subsample(P, lens, dl)                       # hash form, one host sync
     cap = P.shape[0] + 1000                                                            # capacity > real size: exercises the tail
-    Pc = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    Pc = torch.full((cap, 3), 1e30, dtype=torch.float32, device=dev)                   # (garbage beyond the real points)
     Pc[: P.shape[0]] = P
     lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
-    got_p, got_l, st = ops.batch_grid_subsample_async(Pc, lens_dev, dl, cap, elem_cap=max(lens))
-    torch.cuda.synchronize()
-    stl = st.tolist()
-    assert stl[1] == 0, stl
-    m = stl[0]
-    assert m == want_p.shape[0], (m, want_p.shape)
-    assert torch.equal(got_l.cpu(), want_l.cpu())
-    assert torch.equal(got_p[:m].cpu(), want_p.cpu()), "sort form differs from the hash form"
+    for rep in range(2):                                                               # the second call reuses the workspace as it was left
+        got_p, got_l, st = ops.batch_grid_subsample_async(Pc, lens_dev, dl, cap, elem_cap=max(lens))
+        torch.cuda.synchronize()
+        stl = st.tolist()
+        assert stl[1] == 0, stl
+        m = stl[0]
+        assert m == ora_p.shape[0] == want_p.shape[0], (m, ora_p.shape, want_p.shape)
+        assert np.array_equal(got_l.cpu().numpy(), ora_l), (got_l.cpu().numpy(), ora_l)
+        g = got_p[:m].cpu().numpy()
+        assert np.array_equal(g.view(np.uint32), ora_p.view(np.uint32)), "sort form differs from the oracle (B=%d n=%d)" % (len(lens), len(pts))
+        assert torch.equal(got_p[:m].cpu(), want_p.cpu()), "sort form differs from the hash form"
+# a grid whose (element, voxel key) does not fit 32 bits: flagged, empty -- and the synchronous (hash) call still answers
+wide = (rng.random((5000, 3)) * 2000.0).astype(np.float32)
+Pw = torch.from_numpy(wide).to(dev)
+_, _, st = ops.batch_grid_subsample_async(Pw, torch.tensor([5000], dtype=torch.int32, device=dev), 0.05, 5000)
+torch.cuda.synchronize()
+assert st.tolist() == [0, _lib.ST_KEY_WIDTH], st.tolist()
+wp, wl, _, _ = ops.batch_grid_subsample(Pw, [5000], 0.05)
+op, ol = co.batch_grid_subsampling(wide, np.asarray([5000], np.int32), 0.05)
+assert np.array_equal(wp.cpu().numpy().view(np.uint32), op.view(np.uint32))
 print("SORT-PATH-OK", len(cases))

@@ -43,6 +43,18 @@ prof)
     python tools/timeline_summary.py $DB > $OUT/timeline.json 2>/dev/null
   fi
   rm -rf $OUT/prof/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
+prof1)   # ONE replay in flight: kernel durations without the other streams' kernels competing for the CUs (with several
+         # replays in flight a kernel's duration in the trace includes the time its workgroups wait for a free CU)
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof1 -- python $REPO/bench.py --steps 32 --warmup 8 --slots 1 --batch 4 $LEAN > $OUT/prof1_bench.json 2> $OUT/prof1.err
+  cd $REPO
+  DB=$(ls $OUT/prof1/*/*_results.db 2>/dev/null | head -1)
+  if [ -n "$DB" ]; then
+    python tools/rocpd_summary.py --timed-region --fragments 32 $DB > $OUT/kernel_stats_one_replay_in_flight.csv
+    head -40 $OUT/kernel_stats_one_replay_in_flight.csv | cut -c1-150
+    python tools/gs_timeline.py $DB 2 34
+  fi
+  rm -rf $OUT/prof1/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
 pmc)
   cd /tmp
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_fetch.err
