@@ -555,6 +555,8 @@ __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int 
     }
 }
 
+#include "gs_small.h"
+
 // ---- sort form of the point -> voxel pass (capacity mode, large clouds: the stage-0 call) ---------------------------------
 // A STABLE radix sort of (element, voxel key) -> the points of a voxel become one run, in input order (what the in-order
 // barycentre needs), its first entry is the voxel's first occurrence.  Replaces hash insert / first-occurrence gather-scan /
@@ -684,12 +686,6 @@ __global__ void __launch_bounds__(256) gs_emit_kernel(int* __restrict__ status, 
     out_p[3 * dest + 2] = bary[3 * (size_t)v + 2];
 }
 
-static size_t gs_sort_min() {
-    // the sort form is used by capacity-mode calls of at least this many points; below it the hash form's five passes over
-    // a few ten thousand points are cheaper than three digit passes (measured: profiles/r03_experiments.txt)
-    static const long long v = [] { const char* e = getenv("D3F_GS_SORT_MIN"); return e ? atoll(e) : 1ll; }();
-    return v > 0 ? (size_t)v : (size_t)-1;
-}
 
 // ---- per-voxel in-order accumulation + emit (grid_subsampling.cpp:63-70, :81-92) -----------------------
 __global__ void __launch_bounds__(256) gs_accum_kernel(const float* __restrict__ pts, const float* __restrict__ feat,
@@ -784,7 +780,46 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
     // sort form: digit histograms, first-occurrence bits, per-voxel barycentres, the sort's description
     bytes += d3f_align(rs_hist_words(N) * sizeof(unsigned)) + d3f_align((n / 32 + 2) * sizeof(unsigned)) +
              d3f_align(3 * n * sizeof(float)) + d3f_align(sizeof(RsMeta));
+    // one-workgroup form: staging blocks [B][min(N, 16384)][3] + per-cloud counts / flags
+    bytes += d3f_align(7 * (size_t)B * (n < 16384 ? n : 16384) * sizeof(float)) + 256 + 2 * d3f_align(B * sizeof(int));
     return bytes + 4096;
+}
+
+// One-workgroup-per-cloud form (gs_small.h): every cloud of the stack has at most `pc` <= 16384 points.
+template <int T, int R>
+static int gs_small_launch(const GsSmallArgs& A, float* sub_points, int* sub_lens_dev, int* status_dev, hipStream_t stream) {
+    static std::atomic<unsigned long long> lds_done{0ull};
+    const void* const fns[] = {(const void*)gs_small_kernel<T, R>};
+    if (d3f_opt_in_lds(lds_done, fns, (int)gss_lds_bytes<T, R>(GSS_NB_MAX)) != D3F_OK) return D3F_ERR_HIP;
+    gs_small_kernel<T, R><<<A.B, T, gss_lds_bytes<T, R>(A.nbmax), stream>>>(A);
+    D3F_LAUNCH_CHECK();
+    gs_small_pack_kernel<<<d3f_cdiv(A.out_cap, 256), 256, 0, stream>>>(A, sub_points, sub_lens_dev, status_dev);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+static int gs_run_small(const float* points, int N, const int* lens_dev, int B, float dl, float* sub_points, int M_cap, int elem_cap,
+                        int pc, int* sub_lens_dev, int* status_dev, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (elem_cap <= 0 || elem_cap > M_cap) elem_cap = M_cap;
+    if (elem_cap > pc) elem_cap = pc;                   // voxels <= points
+    D3fArena ar(workspace, workspace_bytes);
+    GsSmallArgs A;
+    A.stage = ar.take<float>(3 * (size_t)B * (size_t)elem_cap);
+    A.recs = ar.take<float>(4 * (size_t)B * (size_t)elem_cap);
+    A.mcount = ar.take<int>(B);
+    A.cflags = ar.take<int>(B);
+    if (!ar.ok) return D3F_ERR_WORKSPACE;
+    A.pts = points; A.lens = lens_dev; A.B = B; A.dl = dl; A.elem_cap = elem_cap; A.out_cap = M_cap;
+    // the largest iteration-order round that has to fit the workgroup's LDS: the first chain value >= the voxel capacity
+    A.nbmax = GSS_NB_MAX;
+    for (int j = 0; j < D3F_NCHAIN; ++j)
+        if ((long long)D3F_CHAIN_HOST[j] >= (long long)elem_cap) { A.nbmax = (int)D3F_CHAIN_HOST[j]; break; }
+    if (A.nbmax > GSS_NB_MAX) A.nbmax = GSS_NB_MAX;      // (a cloud with more voxels is reported: D3F_ST_OUT_OVERFLOW)
+    if (A.nbmax < 1109) A.nbmax = 1109;
+    if (pc <= 2048) return gs_small_launch<256, 8>(A, sub_points, sub_lens_dev, status_dev, stream);
+    if (pc <= 4096) return gs_small_launch<512, 8>(A, sub_points, sub_lens_dev, status_dev, stream);
+    if (pc <= 8192) return gs_small_launch<1024, 8>(A, sub_points, sub_lens_dev, status_dev, stream);
+    if (pc <= 12288) return gs_small_launch<1024, 12>(A, sub_points, sub_lens_dev, status_dev, stream);
+    return gs_small_launch<1024, 16>(A, sub_points, sub_lens_dev, status_dev, stream);
 }
 
 // Shared implementation.  sync mode (status_host != NULL): ONE host synchronisation after the voxel count is known,
@@ -792,10 +827,19 @@ extern "C" size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int
 // capacities, the real sizes live in HBM (lens_dev -> offs[B]; M -> status_dev[0]) and every kernel bounds itself by them,
 // so the call can be captured in a HIP graph and replayed for clouds of any size up to the capacity.
 static int gs_run(const float* points, int N, const int* lens_dev, int B, float dl, const float* features, int fdim,
-                  const int* classes, int ldim, float* sub_points, int M_cap, int elem_cap, float* sub_features,
+                  const int* classes, int ldim, float* sub_points, int M_cap, int elem_cap, int elem_points, float* sub_features,
                   int* sub_classes, int* sub_lens_dev, int* status_host, int* status_dev, void* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
     const bool async = status_dev != nullptr;
+    if (async && !features && ldim == 0) {
+        // one workgroup per cloud when the caller's capacities fit it: every cloud <= 16384 points and <= 5087 voxels (a cloud
+        // beyond its stated capacity is reported by either form, so the choice adds no failure mode)
+        const int pc = (elem_points > 0 && elem_points < N) ? elem_points : N;
+        int ec = (elem_cap > 0 && elem_cap < M_cap) ? elem_cap : M_cap;
+        if (ec > pc) ec = pc;
+        if (pc <= 16384 && ec <= GSS_NB_MAX) return gs_run_small(points, N, lens_dev, B, dl, sub_points, M_cap, elem_cap, pc, sub_lens_dev, status_dev,
+                                             workspace, workspace_bytes, stream);
+    }
     GsLayout L = gs_layout(N, B, async ? M_cap : -1);
     D3fArena ar(workspace, workspace_bytes);
     const size_t n = (size_t)N;
@@ -837,7 +881,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
     int* vbase = ar.take<int>(d3f_scan_base_ints(N));   // tile offsets of the voxel-id scan
     int* sbase = ar.take<int>(d3f_scan_base_ints(N));   // ... of the voxel-start scan
     // sort form of the point -> voxel pass: capacity mode, points only, large calls (see gs_sortkey_kernel)
-    const bool use_sort = async && !features && ldim == 0 && (size_t)N >= gs_sort_min();
+    const bool use_sort = async && !features && ldim == 0;     // capacity mode: always the sort form (or gs_run_small above)
     unsigned* rs_hist = ar.take<unsigned>(rs_hist_words(N));
     unsigned* fbits = ar.take<unsigned>(n / 32 + 2);
     float* bary = ar.take<float>(3 * n);
@@ -952,19 +996,19 @@ extern "C" int d3f_batch_grid_subsample(const float* points, int N, const int* l
     if ((fdim > 0 && (!features || !sub_features)) || (ldim > 0 && (!classes || !sub_classes))) return D3F_ERR_ARG;
     for (int i = 0; i < B + 2; ++i) status_host[i] = 0;
     if (N == 0) return d3f_fill_u32(sub_lens_dev, B, 0u, stream);
-    return gs_run(points, N, lens_dev, B, dl, features, fdim, classes, ldim, sub_points, N, N, sub_features, sub_classes,
+    return gs_run(points, N, lens_dev, B, dl, features, fdim, classes, ldim, sub_points, N, N, 0, sub_features, sub_classes,
                   sub_lens_dev, status_host, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* lens_dev, int B, float dl,
-                                              float* sub_points, int M_cap, int elem_cap, int* sub_lens_dev,
+                                              float* sub_points, int M_cap, int elem_cap, int elem_points_cap, int* sub_lens_dev,
                                               int* status_dev, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (N_cap < 1 || N_cap > (1 << 30) || M_cap < 1 || elem_cap < 0 || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f))
+    if (N_cap < 1 || N_cap > (1 << 30) || M_cap < 1 || elem_cap < 0 || elem_points_cap < 0 || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f))
         return D3F_ERR_ARG;
     if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
-    return gs_run(points, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, elem_cap, nullptr, nullptr,
-                  sub_lens_dev, nullptr, status_dev, workspace, workspace_bytes, stream);
+    return gs_run(points, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, elem_cap, elem_points_cap, nullptr,
+                  nullptr, sub_lens_dev, nullptr, status_dev, workspace, workspace_bytes, stream);
 }
 
 // np.concatenate([pts, pts]) of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:

@@ -165,7 +165,8 @@ class Dataset:
                     pool_p, pool_b, _ = ops.batch_grid_subsample_async(stacked_points, stacked_lengths, dl, caps[layer + 1],
                                                                        status=status_all[len(pending)],
                                                                        m_hint=hints[layer + 1] if hints else 0,
-                                                                       elem_cap=-(-caps[layer + 1] // units))
+                                                                       elem_cap=-(-caps[layer + 1] // units),
+                                                                       elem_points=-(-caps[layer] // units))
                     pending.append(status_all[len(pending)])
                 else:
                     pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)

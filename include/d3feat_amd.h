@@ -80,12 +80,14 @@ int d3f_trace_marker(int id, void* stream);
 size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int ldim);
 /* Capacity-mode form (points only): no host synchronisation.  `points` has N_cap rows of which sum(lens_dev) are valid;
  * sub_points has M_cap rows; elem_cap bounds the voxels of any ONE batch element (0: M_cap) -- the iteration-order rounds
- * are launched for that size, so a stack of B similar clouds should pass its per-cloud capacity; status_dev i32[2]
- * (DEVICE) = [M, OR of D3F_ST_* flags]; M > M_cap or an element above elem_cap raises D3F_ST_OUT_OVERFLOW (empty result).
+ * are launched for that size, so a stack of B similar clouds should pass its per-cloud capacity; elem_points_cap bounds the
+ * POINTS of any one batch element (0: N_cap): when it is at most 16384 every cloud is subsampled by ONE workgroup out of LDS
+ * (two launches per call instead of ~25: the coarse pyramid levels); status_dev i32[2] (DEVICE) = [M, OR of D3F_ST_* flags];
+ * M > M_cap, an element above elem_cap or above elem_points_cap raises D3F_ST_OUT_OVERFLOW (empty result).
  * Workspace: d3f_grid_subsample_workspace_bytes(N_cap, B, 0, 0). */
 int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* lens_dev, int B, float dl,
-                                   float* sub_points, int M_cap, int elem_cap, int* sub_lens_dev, int* status_dev,
-                                   void* workspace, size_t workspace_bytes, void* stream);
+                                   float* sub_points, int M_cap, int elem_cap, int elem_points_cap, int* sub_lens_dev,
+                                   int* status_dev, void* workspace, size_t workspace_bytes, void* stream);
 /* The self-pair stacking of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:72-79:
  * np.concatenate([pts, pts])) for B stacked clouds whose row counts live in HBM (lens_in_dev i32[B]): cloud b is written
  * twice in a row -- out f32[2*M_cap,3] = [c_0; c_0; c_1; c_1; ...], lens_out_dev i32[2B] = [m_0, m_0, m_1, m_1, ...],

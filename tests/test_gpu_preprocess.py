@@ -145,15 +145,14 @@ def test_full_size_properties(device):
     assert np.all(d[valid] < 0.075 ** 2 * 1.0001)
 
 
-def test_sort_form_of_the_subsampler_equals_the_hash_form():
-    """Capacity-mode calls of >= D3F_GS_SORT_MIN points (default 600 k: the stage-0 call of a batched replay) use a stable radix
-    sort instead of the hash table; forced on for every size in a subprocess, it must reproduce the synchronous (hash) call
-    bit for bit on ragged stacks, duplicates, one-point clouds and a capacity tail."""
+def test_capacity_mode_forms_of_the_subsampler_equal_the_oracle():
+    """The capacity-mode subsampler (no hash table: stable radix sort, csrc/radix_sort.h; clouds of at most 16384 points: one
+    workgroup per cloud out of LDS, csrc/gs_small.h) against the ORACLE and the synchronous (hash) call, bit for bit: ragged
+    stacks, duplicates, one-point clouds, sizes around the sort tile, 100 clouds per stack, 4-pass keys, capacity tails, and the
+    reported limits (key wider than 32 bits, cloud above its point capacity, more voxels than the LDS rounds hold)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, D3F_GS_SORT_MIN="1")
     here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, "gs_sort_path_check.py")], env=env, capture_output=True, text=True,
-                         timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(here, "gs_sort_path_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SORT-PATH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
