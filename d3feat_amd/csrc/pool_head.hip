@@ -350,10 +350,31 @@ head_kernel(const float* __restrict__ x, int N, int ldx, int C, const int* __res
 // C == 32 (the shipped descriptor width): 8 lanes x float4 per row, so one half-wave instruction fetches FOUR neighbour rows
 // (4 row slots x 8 lanes) instead of one; the per-row sum for the non-zero count is a 3-step shuffle per four rows instead
 // of a 5-step one per row.  Same arithmetic per element as head_kernel except y = v * (1 / den) (reciprocal multiply).
+// "Does this row count as a neighbour": sum_c y[n, c] != 0 (models/D3Feat.py:94-96 counts the non-zero neighbour-feature sums).
+// A property of the ROW, so it is evaluated once per row -- with exactly the summation tree head32_kernel used per (point,
+// neighbour) pair: lane j of a row held channels 4j..4j+3, s_j = (y0 + y1) + (y2 + y3), then xor-shuffle sums over 1, 2, 4 --
+// instead of 42 times per row inside the gather loop (three shuffles + adds + a compare per neighbour row and lane).
+__global__ void __launch_bounds__(256) head32_rowflag_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict__ offs,
+                                                             int B, const unsigned* __restrict__ mx, unsigned char* __restrict__ nz) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= min(N, offs[B])) return;
+    const int b = d3f_find_elem(offs, B, n);
+    const float rden = 1.0f / (d3f_ord2f(mx[b]) + 1e-6f);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = *(const float4*)&x[(size_t)n * ldx + 4 * j];
+        s[j] = (v.x * rden + v.y * rden) + (v.z * rden + v.w * rden);
+    }
+    const float t0 = s[0] + s[1], t1 = s[2] + s[3], t2 = s[4] + s[5], t3 = s[6] + s[7];
+    const float rs = (t0 + t1) + (t2 + t3);
+    nz[n] = rs != 0.f ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256)
 head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict__ idx, int ld_idx, int K,
-              const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, float* __restrict__ desc, int ldd,
-              float* __restrict__ score, const int* __restrict__ row_order) {
+              const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, const unsigned char* __restrict__ nz,
+              float* __restrict__ desc, int ldd, float* __restrict__ score, const int* __restrict__ row_order) {
     N = min(N, offs[B]);
     if ((int)(blockIdx.x * 8) >= N) return;                  // capacity-sized grid (8 rows per workgroup)
     const int half = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((N + 7) / 8)) * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
@@ -371,7 +392,11 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
     int cnt = 0;
     const int hbase = threadIdx.x & 32;
     for (int k0 = 0; k0 < K; k0 += 32) {
-        const int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;   // 32 indices per half-wave load
+        int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;   // 32 indices per half-wave load
+        if (mine < 0 || mine >= N) mine = -1;                                // shadow row: zeros, never counted
+        // neighbour count: the row flags of these 32 neighbours, one byte load per lane, one ballot per chunk
+        const bool counts = mine >= 0 && nz[mine] != 0;
+        cnt += __popcll((__ballot(counts) >> hbase) & 0xFFFFFFFFull);
         const int kn = min(32, K - k0);
         for (int kk = 0; kk < kn; kk += 16) {      // four loads (16 neighbour rows) in flight per lane, clamped addresses
             int id[4];
@@ -380,27 +405,21 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
             for (int u = 0; u < 4; ++u) {
                 const int kq = kk + u * 4 + slot;
                 id[u] = __shfl(mine, hbase + min(kq, 31), 64);
-                if (kq >= kn || id[u] < 0 || id[u] >= N) id[u] = -1;   // shadow row: zeros
+                if (kq >= kn) id[u] = -1;
                 v[u] = *(const float4*)&x[(size_t)max(id[u], 0) * ldx + c4];
                 if (id[u] < 0) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 // neighbours of a point belong to the point's own cloud (the searches are per batch element): same den
-                const float4 y = make_float4(v[u].x * rden, v[u].y * rden, v[u].z * rden, v[u].w * rden);
-                sum.x += y.x; sum.y += y.y; sum.z += y.z; sum.w += y.w;
-                float rs = (y.x + y.y) + (y.z + y.w);
-                rs += __shfl_xor(rs, 1, 64); rs += __shfl_xor(rs, 2, 64); rs += __shfl_xor(rs, 4, 64);
-                cnt += (id[u] >= 0 && rs != 0.f) ? 1 : 0;
+                sum.x += v[u].x * rden; sum.y += v[u].y * rden; sum.z += v[u].z * rden; sum.w += v[u].w * rden;
             }
         }
     }
     // combine the four row slots (lanes l, l^8, l^16, l^24 hold the same channels)
     sum.x += __shfl_xor(sum.x, 8, 64); sum.y += __shfl_xor(sum.y, 8, 64); sum.z += __shfl_xor(sum.z, 8, 64); sum.w += __shfl_xor(sum.w, 8, 64);
     sum.x += __shfl_xor(sum.x, 16, 64); sum.y += __shfl_xor(sum.y, 16, 64); sum.z += __shfl_xor(sum.z, 16, 64); sum.w += __shfl_xor(sum.w, 16, 64);
-    cnt += __shfl_xor(cnt, 8, 64);
-    cnt += __shfl_xor(cnt, 16, 64);
-    const float fc = (float)max(cnt, 1);
+    const float fc = (float)max(cnt, 1);        // (cnt is already the half-wave's total: counted by ballot)
     float ymax = fmaxf(fmaxf(yv.x, yv.y), fmaxf(yv.z, yv.w));
     ymax = fmaxf(ymax, __shfl_xor(ymax, 1, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, 2, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, 4, 64));
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, ss[4] = {sum.x, sum.y, sum.z, sum.w};
@@ -443,7 +462,12 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
     else head_max_kernel<false><<<dim3(chunks, B), 256, 0, stream>>>(x, N, ldx, C, offs, B, mx);
     const int blocks = d3f_cdiv((long long)N * 32, 256);
     const bool vec32 = C == 32 && ldx % 4 == 0 && ldd % 4 == 0 && (((uintptr_t)x | (uintptr_t)desc) & 15) == 0;
-    if (vec32) head32_kernel<<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
+    if (vec32) {
+        // one flag byte per row, behind the 2 B + 2 scratch words
+        unsigned char* nz = (unsigned char*)(scratch_dev + 2 * B + 2);
+        head32_rowflag_kernel<<<d3f_cdiv(N, 256), 256, 0, stream>>>(x, N, ldx, offs, B, mx, nz);
+        head32_kernel<<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
+    }
     else if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     else if (C <= 64) head_kernel<2><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     else head_kernel<4><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);

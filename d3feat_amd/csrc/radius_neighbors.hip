@@ -181,13 +181,13 @@ __device__ __forceinline__ void nb_bitonic64(int lane, unsigned& h0, unsigned& l
 #undef NB_STAGE
 }
 
-template <bool FIRST_ONLY, int LPQ>
+template <bool FIRST_ONLY, int LPQ, bool HINT>
 __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
 nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                  const float4* __restrict__ sorted,
                  const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
-                 int ld, int width, int cap, int* __restrict__ status, int want_kmax) {
+                 int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QPB = 64 * NB_WAVES_PER_BLOCK / LPQ;   // queries per workgroup
     const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
@@ -231,13 +231,32 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
     cx = min(max(cx, -2), e.dims[0] + 1);
     cy = min(max(cy, -2), e.dims[1] + 1);
     cz = min(max(cz, -2), e.dims[2] + 1);
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, e.dims[0] - 1);
+    // Stencil: the 3 x 3 x 3 cells around the query's.  FIRST_ONLY with nn_hint > 0 (the caller expects the nearest support
+    // within that distance -- the upsampling matrices: a point's own voxel barycentre is at most sqrt(3) dl away): the first
+    // attempt only visits the cells that the ball of radius nn_hint touches (8 of 27 when nn_hint < cell / 2 ... 0.7 cell) and
+    // is accepted when it finds a support within nn_hint -- then nothing closer can lie outside those cells.  Otherwise the
+    // full stencil is searched: the result never depends on the hint.
+    int n = 0;  // group-uniform hit count
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    float bd2 = 3.4e38f;
+    int bidx = 0x7fffffff;
+    auto scan = [&](bool restricted) {
+    int xl = cx - 1, xh = cx + 1, yl = cy - 1, yh = cy + 1, zl = cz - 1, zh = cz + 1;
+    if (restricted) {
+        // cells touched by the ball, in the grid's own fp64 index arithmetic (monotone, so a support within nn_hint of the
+        // query lies in [lo, hi] on every axis)
+        const double h = (double)nn_hint;
+        xl = max(xl, (int)floor(((double)qx - h - e.mn[0]) * e.inv_h)); xh = min(xh, (int)floor(((double)qx + h - e.mn[0]) * e.inv_h));
+        yl = max(yl, (int)floor(((double)qy - h - e.mn[1]) * e.inv_h)); yh = min(yh, (int)floor(((double)qy + h - e.mn[1]) * e.inv_h));
+        zl = max(zl, (int)floor(((double)qz - h - e.mn[2]) * e.inv_h)); zh = min(zh, (int)floor(((double)qz + h - e.mn[2]) * e.inv_h));
+    }
+    const int x0 = max(xl, 0), x1 = min(xh, e.dims[0] - 1);
     // lanes 0..8: run start, lanes 9..17: run end, of the 9 (y,z) rows of the stencil
     int bound = 0;
     if (lane < 18) {
         const int j = lane < 9 ? lane : lane - 9;
         const int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
-        if (x0 <= x1 && y >= 0 && y < e.dims[1] && z >= 0 && z < e.dims[2]) {
+        if (x0 <= x1 && y >= max(yl, 0) && y <= min(yh, e.dims[1] - 1) && z >= max(zl, 0) && z <= min(zh, e.dims[2] - 1)) {
             const int rowbase = e.cbase + e.dims[0] * (y + e.dims[1] * z);
             bound = d3f_scan_at(cell_start, cell_base, rowbase + (lane < 9 ? x0 : x1 + 1));
         }
@@ -256,10 +275,9 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
         pre[j + 1] = pre[j] + ln_j;
     }
     const int T = pre[9];
-    int n = 0;  // group-uniform hit count
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    float bd2 = 3.4e38f;
-    int bidx = 0x7fffffff;
+    n = 0;
+    bd2 = 3.4e38f;
+    bidx = 0x7fffffff;
     // four candidate loads in flight per lane (a typical query's ~120 candidates in ONE round trip): the loads of consecutive
     // steps are independent, only the hit compaction is sequential.  Straight-line loads: a lane beyond the list re-reads
     // the list's first candidate (address clamp) instead of branching around the load.
@@ -294,13 +312,6 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
             n += __popcll(m);
         }
     }
-    if (lane == 0) {
-        // one shared word: an unconditional atomic per query serialises at ~12 ns each in L2 (60k queries = 0.7 ms);
-        // read first, update only when this query raises the maximum (a handful of times per launch)
-        if (want_kmax && n > __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[0], n);
-        if (!FIRST_ONLY && n > cap) atomicOr(&status[1], D3F_ST_HIT_OVERFLOW);
-    }
-    int* row = out + (size_t)qi * ld;
     if (FIRST_ONLY) {
         // lexicographic (d2, index) minimum over the group
 #pragma unroll
@@ -309,6 +320,24 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
             const int oi = __shfl_xor(bidx, o, LPQ);
             if (od < bd2 || (od == bd2 && oi < bidx)) { bd2 = od; bidx = oi; }
         }
+    }
+    };
+    if (FIRST_ONLY && HINT) {
+        scan(true);
+        // (group-uniform) the restricted scan stands when its nearest support lies within the hint (0.998: the fp32 d2 of a
+        // support just outside the visited cells can round below that of one just inside the ball); else: the full stencil
+        if (!(n > 0 && bd2 <= 0.998f * nn_hint * nn_hint)) scan(false);
+    } else {
+        scan(false);
+    }
+    if (lane == 0) {
+        // one shared word: an unconditional atomic per query serialises at ~12 ns each in L2 (60k queries = 0.7 ms);
+        // read first, update only when this query raises the maximum (a handful of times per launch)
+        if (want_kmax && n > __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[0], n);
+        if (!FIRST_ONLY && n > cap) atomicOr(&status[1], D3F_ST_HIT_OVERFLOW);
+    }
+    int* row = out + (size_t)qi * ld;
+    if (FIRST_ONLY) {
         if (lane == 0 && width > 0) row[0] = (n > 0) ? bidx : pad;
         for (int j = 1 + lane; j < width; j += LPQ) row[j] = pad;
         return;
@@ -443,9 +472,10 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
 extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
                                         const int* q_lens_dev, int B, float radius, int queries_are_supports,
                                         int* out, int ld, int width, int pad_value, int cap, int first_only,
-                                        int reset_status, int* status_dev, void* stream_) {
+                                        float nn_hint, int reset_status, int* status_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
+    if (!(nn_hint >= 0.f) || nn_hint >= radius) nn_hint = 0.f;        // a hint only helps below the radius
     if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
     if (!grid || !status_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
     if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
@@ -467,9 +497,14 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     const size_t lds = first_only ? 0 : (size_t)qpb * cap * 2 * sizeof(float);
     const int kcap = first_only ? 1 : cap;
 #define D3F_NB(FO_, LPQ_)                                                                                              \
-    nb_search_kernel<FO_, LPQ_><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                                      \
+    if (FO_ && nn_hint > 0.f)                                                                                          \
+        nb_search_kernel<FO_, LPQ_, FO_><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                             \
+            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
+            kcap, status_dev, want_kmax, nn_hint);                                                                     \
+    else                                                                                                               \
+    nb_search_kernel<FO_, LPQ_, false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                               \
         queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
-        kcap, status_dev, want_kmax)
+        kcap, status_dev, want_kmax, nn_hint)
     if (first_only) { if (lpq == 64) D3F_NB(true, 64); else D3F_NB(true, 32); }
     else { if (lpq == 64) D3F_NB(false, 64); else D3F_NB(false, 32); }
 #undef D3F_NB
@@ -566,5 +601,5 @@ extern "C" int d3f_batch_radius_neighbors(const float* queries, int Nq, const fl
     int rc = d3f_neighbor_grid_build(supports, Ns, s_lens_dev, B, radius, workspace, gb, stream_);
     if (rc != D3F_OK) return rc;
     return d3f_neighbor_grid_search(workspace, gb, Ns, queries, Nq, q_lens_dev, B, radius, 0, out, ld, width, pad_value,
-                                    D3F_NEIGHBOR_CAP, 0, 1, status_dev, stream_);
+                                    D3F_NEIGHBOR_CAP, 0, 0.f, 1, status_dev, stream_);
 }

@@ -122,8 +122,11 @@ class Dataset:
         cap = getattr(self, '_neighbor_cap', 192)
         grids = {}
 
-        def search(q, s, ql, sl, r, layer, first_only=False):
+        def search(q, s, ql, sl, r, layer, first_only=False, nn_hint=0.0):
             lim = int(self.neighborhood_limits[layer])
+            if first_only and not exact_shapes:
+                lim = 1     # only the nearest support is computed AND stored: closest_pool reads column 0 (network_blocks.py:81);
+                            # a full-width row of padding per point was 39 MB of writes per level-0 launch
             if exact_shapes:
                 full = tf_batch_neighbors(q, s, ql, sl, r)
                 return full[:, :lim]
@@ -135,7 +138,7 @@ class Dataset:
                 if getattr(s, 'order', None) is None:
                     s.order = grid.order   # cell-sorted visiting order of this level's points (ops._order)
             out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)],
-                                      reset_status=False, want_kmax=False)
+                                      reset_status=False, want_kmax=False, nn_hint=nn_hint)
             pending.append(status)
             return out
 
@@ -175,8 +178,10 @@ class Dataset:
                 else:
                     r = r_normal
                 pool_i = search(pool_p, stacked_points, pool_b, stacked_lengths, r, layer)
+                # the supports of up_i are the voxel barycentres (edge dl) of the queries themselves: every query has one within
+                # sqrt(3) dl -- a hint for the nearest-only search (8 cells instead of 27), never a constraint
                 up_i = search(stacked_points, pool_p, stacked_lengths, pool_b, 2 * r, layer,
-                              first_only=up_first_column_only)
+                              first_only=up_first_column_only, nn_hint=1.75 * dl)
             else:
                 pool_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
                 pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)

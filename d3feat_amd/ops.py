@@ -275,10 +275,11 @@ class NeighborGrid:
         self.order = self.mem[off: off + 4 * max(self.Ns, 1)].view(torch.int32)
 
     def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None,
-               reset_status=True, want_kmax=True):
+               reset_status=True, want_kmax=True, nn_hint=0.0):
         """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation.  reset_status=False: the caller has
         zeroed `status` (saves one launch per search).  want_kmax=False: status[0] (largest neighbour count) is not maintained
-        (callers that allocate a fixed number of columns do not need it; see D3F_NB_NO_KMAX)."""
+        (callers that allocate a fixed number of columns do not need it; see D3F_NB_NO_KMAX).  nn_hint (first_only): the distance
+        within which the caller expects the nearest support -- a speed hint only, see include/d3feat_amd.h."""
         lib = _lib.load()
         queries = _req(queries, torch.float32, "queries", 2).contiguous()
         dev = queries.device
@@ -299,7 +300,8 @@ class NeighborGrid:
             rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
                                               ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),
                                               int(pad_value), int(cap),
-                                              1 if first_only else 0, (1 if reset_status else 0) | (0 if want_kmax else 2),
+                                              1 if first_only else 0, float(nn_hint),
+                                              (1 if reset_status else 0) | (0 if want_kmax else 2),
                                               status.data_ptr(),
                                               _stream(dev))
         _lib.check(rc, "neighbor_grid_search")
@@ -743,7 +745,7 @@ def detect_head(x, neighbors, stack_lengths_dev, include_zero_dev, stack_group=0
     B = stack_lengths_dev.numel()
     desc = torch.empty((N, Cc), dtype=torch.float32, device=dev)
     score = torch.empty((N, 1), dtype=torch.float32, device=dev)
-    scratch = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((2 * B + 2 + (N + 3) // 4,), dtype=torch.int32, device=dev)
     with _timed("detect_head", dict(N=N, K=nb.shape[1], C=Cc), dev):
         rc = lib.d3f_detect_head(x.data_ptr(), N, ldx, Cc, nb.data_ptr(), ldi, nb.shape[1],
                                  stack_lengths_dev.data_ptr(),

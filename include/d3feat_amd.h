@@ -136,6 +136,10 @@ int d3f_batch_radius_neighbors(const float* queries, int Nq, const float* suppor
  *       first_only            1: only column 0 (the nearest support, ties by index) is computed -- all that
  *                             closest_pool reads of the upsampling matrices (models/network_blocks.py:81);
  *                             columns 1..width-1 are filled with pad_value
+ *       nn_hint               (first_only) > 0: the caller expects the nearest support within this distance (< radius), e.g.
+ *                             sqrt(3) dl for the upsampling matrices, whose supports are the voxel barycentres of the queries:
+ *                             only the cells that ball touches are visited first; a query whose nearest support is farther
+ *                             is searched again over the full stencil, so the result never depends on the hint.  0: none
  *       reset_status          bit 0: status_dev is zeroed first (one extra launch); clear: the caller zeroed it (a
  *                             captured fragment zeroes the status words of all its ops with one fill).
  *                             bit 1 (D3F_NB_NO_KMAX): status_dev[0] (the largest neighbour count, which only callers that
@@ -151,8 +155,8 @@ int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev
                             void* grid, size_t grid_bytes, void* stream);
 int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
                              const int* q_lens_dev, int B, float radius, int queries_are_supports,
-                             int* out, int ld, int width, int pad_value, int cap, int first_only, int reset_status,
-                             int* status_dev, void* stream);
+                             int* out, int ld, int width, int pad_value, int cap, int first_only, float nn_hint,
+                             int reset_status, int* status_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * KPConv, phase 1: neighbour gather + kernel-point influence + weighted aggregation.
@@ -277,7 +281,7 @@ int d3f_affine_act(const float* x, int ldx, int M, int N, const float* col_scale
  *       fragment's result never depends on its stack mates.  Ignored when include_zero_dev is given.
  *   N is an upper bound: the real point count is sum(lens_dev)
  *   desc f32[N,C] = l2_normalize(x, eps 1e-10);  score f32[N]
- *   scratch_dev: >= 2*B+2 ints of device scratch.  C <= 128.
+ *   scratch_dev: >= 2*B + 2 + (N + 3) / 4 ints of device scratch (per-cloud maxima, offsets, one flag byte per row).  C <= 128.
  * ------------------------------------------------------------------------------------------- */
 int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int ld_idx, int K,
                     const int* lens_dev, const int* include_zero_dev, int stack_group, int B, float* desc, int ldd,

@@ -156,3 +156,28 @@ def test_capacity_mode_forms_of_the_subsampler_equal_the_oracle():
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, os.path.join(here, "gs_sort_path_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SORT-PATH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("hint_scale", [0.05, 0.3, 0.7, 0.99])
+def test_first_only_hint_never_changes_the_result(device, hint_scale):
+    """d3f_neighbor_grid_search(first_only, nn_hint): the hint restricts the first attempt to the cells a ball of that radius
+    touches; wherever the nearest support is farther than the hint (here: most queries, the hint is wrong on purpose) the full
+    stencil is searched again, so column 0 equals the unhinted search and the full search's first column -- ties by index."""
+    from d3feat_amd import ops
+    rng = np.random.default_rng(11)
+    s = (rng.random((30000, 3)) * np.asarray([2.0, 1.5, 0.4])).astype(np.float32)
+    s[100:140] = s[100]                                   # exact ties: lowest index wins
+    q = (rng.random((20000, 3)) * np.asarray([2.2, 1.6, 0.6]) - 0.1).astype(np.float32)
+    q[:40] = s[100]
+    r = np.float32(0.08)
+    S, Q = torch.from_numpy(s).to(device), torch.from_numpy(q).to(device)
+    sl, ql = [18000, 12000], [11000, 9000]
+    grid = ops.NeighborGrid(S, sl, r)
+    full, _ = grid.search(Q, ql, 96)
+    plain, _ = grid.search(Q, ql, 4, first_only=True)
+    hinted, st = grid.search(Q, ql, 4, first_only=True, nn_hint=float(hint_scale * r))
+    torch.cuda.synchronize()
+    assert st.tolist()[1] == 0
+    assert torch.equal(plain[:, 0], full[:, 0])
+    assert torch.equal(hinted, plain)
+    assert int((plain[:, 0] == 30000).sum()) > 0          # queries without any support inside the radius are padded
