@@ -81,6 +81,14 @@ def parse():
                          "contractions with bf16 operands and fp32 accumulation; use with --batch 8 --slots 2")
     ap.add_argument("--no-marginal", action="store_true", help="skip the marginal-cost measurements (extra engines with one op "
                     "family skipped each)")
+    ap.add_argument("--config3", action="store_true",
+                    help="SURVEY §8d config #3's workload shape instead of config #2's uniform fragments: a pool of 16 fragments per "
+                         "rank whose sizes are drawn from U(15 k, 45 k) points after the 0.03 m subsample (raw points and room edge "
+                         "scaled to keep the sampling density); capacities are those of the largest fragment, so the smaller ones "
+                         "run with capacity slack.  A SEPARATE configuration (never the config #2 headline)")
+    ap.add_argument("--gather-chunk", type=int, default=8,
+                    help="N > 1: fragments per asynchronous shard-exchange chunk (parallel.ShardCollector overlapped mode: the "
+                         "shards cross xGMI while the next fragments are computed); 0 = one all_gather of the whole shard at the end")
     ap.add_argument("--raw-points", type=int, default=300000, help="raw points per synthetic fragment (config #2: 300k)")
     ap.add_argument("--edge", type=float, default=1.68, help="room edge in metres (config #2: 1.68 -> ~30k pts at 0.03 m)")
     return ap.parse_args()
@@ -165,9 +173,18 @@ def main():
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     # synthetic fragments of this rank, raw points resident in HBM before timing starts; the first `pool` are cycled through
     # the timed region, the first `cpu_fragments` form the CPU / parity sample
+    if args.config3:
+        args.pool = max(args.pool, 16)
     nfr = max(args.pool, args.cpu_fragments if do_cpu else 0)
     seeds = [rank * 1000 + i for i in range(nfr)]
-    raws_host = [room_fragment(s, n_raw=args.raw_points, edge=args.edge) for s in seeds]
+    if args.config3:
+        # sizes U(15 k, 45 k) after the subsample: points scale with the surface, so the room edge goes with sqrt(size) and the
+        # raw count with the size (config #2: 300 k raw points, edge 1.68 m -> ~30 k points)
+        targets = np.random.default_rng(1234 + rank).uniform(15000, 45000, nfr)
+        raws_host = [room_fragment(s, n_raw=int(args.raw_points * t / 30000.0), edge=args.edge * float(np.sqrt(t / 30000.0)))
+                     for s, t in zip(seeds, targets)]
+    else:
+        raws_host = [room_fragment(s, n_raw=args.raw_points, edge=args.edge) for s in seeds]
     raws_all = [torch.from_numpy(r).to(device) for r in raws_host]
     raws = raws_all[: args.pool]
 
@@ -203,7 +220,14 @@ def main():
                                 n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
                                 batch=args.batch, bf16=args.bf16)
     # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
-    shard = parallel.ShardCollector(rows_cap=((max(args.steps, 128) if world == 1 else args.steps) + 8) * int(n0_max * 1.02 + 64), width=36, device=device)
+    # (N > 1: overlapped mode -- fixed stride per fragment, chunks of --gather-chunk fragments all-gathered asynchronously
+    # while the next replays run; every rank holds the same number of fragments, so the collective order is the same everywhere)
+    frag_rows = (int(n0_max * args.cap_factor) + 1023) // 1024 * 1024
+    if world > 1 and args.gather_chunk > 0:
+        shard = parallel.ShardCollector(rows_cap=(args.steps + args.gather_chunk) * frag_rows, width=36, device=device,
+                                        chunk_frags=args.gather_chunk, frag_rows=frag_rows)
+    else:
+        shard = parallel.ShardCollector(rows_cap=((max(args.steps, 128) if world == 1 else args.steps) + 8) * int(n0_max * 1.02 + 64), width=36, device=device)
 
     def run(nsteps, engine=engine, collect=None, pool=raws):
         """nsteps fragments through the hot path; every fragment's record block goes to `collect` (ShardCollector)."""
@@ -240,14 +264,14 @@ def main():
     # at least W untimed steps; with the engine, enough of them to replay every slot's graph once
     run(max(args.warmup, (args.slots * args.batch) if engine is not None else 0), collect=shard)
     if world > 1:
-        shard.gather()
+        shard.gather(compact=False)
     shard.reset()
     sync()
     ops.trace_marker(1, device)                  # (named kernel: tools/rocpd_summary.py --timed-region cuts a trace here ...
     sync()
     t0 = time.perf_counter()
     run(args.steps, collect=shard)
-    gathered = shard.gather()
+    gathered = shard.gather(compact=False) if shard.chunk_frags > 0 else shard.gather()
     sync()
     dt = time.perf_counter() - t0
     ops.trace_marker(2, device)                  #  ... and here; outside the clock)
@@ -256,7 +280,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     npts = int(np.mean(shard.frag_rows)) if shard.frag_rows else 0
-    gathered_rows = [int(g[0].shape[0]) for g in gathered]
+    gathered_rows = [int(sum(g[1])) for g in gathered]
     gathered_frags = [len(g[1]) for g in gathered]
     del gathered
     shard.reset()
@@ -350,22 +374,30 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "fragments/sec (30k-pt clouds)" + (" -- configs[4]: bf16 contraction" if args.bf16 else ""),
+            "metric": "fragments/sec (30k-pt clouds)" + (" -- configs[4]: bf16 contraction" if args.bf16 else "") +
+                      (" -- configs[2] shape: fragment sizes U(15k, 45k)" if args.config3 else ""),
             "value": round(world * args.steps / dt, 3), "unit": "fragments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 operands / f32 accumulate in the unary + unfused KPConv contractions; f32 elsewhere (NOT the fp32 "
                       "parity path)" if args.bf16 else "f32"), "data": "synthetic",
-            "config": {"workload": "SURVEY §8d config #2: synthetic 3DMatch room fragment, 300k raw pts -> grid subsample "
-                                   "0.03 m (~%dk pts) -> self-pair -> 5-level pyramid -> full KPFCNN forward (random-init "
-                                   "weights, 14.1M params) -> 32-d descriptors + scores" % round(npts / 1000),
+            "config": {"workload": ("SURVEY §8d config #3 shape (NOT the config #2 headline): synthetic 3DMatch room fragments of "
+                                    "U(15 k, 45 k) points (mean %dk) after the 0.03 m subsample, capacities of the largest" % round(npts / 1000)
+                                    if args.config3 else
+                                    "SURVEY §8d config #2: synthetic 3DMatch room fragment, 300k raw pts -> grid subsample "
+                                    "0.03 m (~%dk pts)" % round(npts / 1000)) +
+                                   " -> self-pair -> 5-level pyramid -> full KPFCNN forward (random-init "
+                                   "weights, 14.1M params) -> 32-d descriptors + scores",
+                       "points_per_cloud_pool": sorted(int(len(x)) for x in subs),
                        "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
                        "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
                        "final_gather": {"ranks": len(gathered_rows), "fragments_per_rank": gathered_frags,
                                         "rows_per_rank": gathered_rows, "bytes_per_rank": [r * 144 for r in gathered_rows],
                                         "what": "every rank's whole shard of [xyz | desc | score] records (144 B/point, the first cloud "
-                                                "of every stacked self-pair: what utils/tester.py:208-229 keeps per fragment), one "
-                                                "padded all_gather inside the timed region"},
+                                                "of every stacked self-pair: what utils/tester.py:208-229 keeps per fragment), inside "
+                                                "the timed region: " + ("asynchronous all_gathers of %d-fragment chunks behind the compute"
+                                                                        % shard.chunk_frags if shard.chunk_frags > 0 else
+                                                                        "one padded all_gather at the end")},
                        "execution": ("eager op-by-op launches" if engine is None else
                                      "HIP-graph replay of %d stacked fragment(s), device-resident sizes, %d replays in flight%s"
                                      % (engine.F, len(engine.slots),

@@ -38,13 +38,30 @@ def shard_fragments(n_items, rank, world_size, sizes=None):
     return sorted(mine)
 
 
+def _host_staged():
+    """backend gloo moves HOST memory: device tensors are staged through the host around every collective.  (The production
+    backend is "nccl" = RCCL, device to device over xGMI; gloo with device tensors is the two-ranks-on-one-GPU test --
+    RCCL refuses two ranks on one device -- and costs a synchronising copy each way.)"""
+    return dist.get_backend() == "gloo"
+
+
+def all_gather_into(out, inp, async_op=False):
+    """dist.all_gather_into_tensor(out, inp) for device or host tensors under either backend; -> work handle or None."""
+    if inp.is_cuda and _host_staged():
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, inp.cpu())
+        out.copy_(h_out)
+        return None
+    return dist.all_gather_into_tensor(out, inp, async_op=async_op)
+
+
 def allreduce_histograms(hists, device=None):
     """Sum int64 histograms [layers, bins] over ranks (no-op for a single process)."""
     rank, ws = world()
     if ws == 1:
         return hists
     t = torch.as_tensor(np.ascontiguousarray(hists), dtype=torch.int64)
-    if device is not None:
+    if device is not None and not _host_staged():
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
@@ -76,39 +93,135 @@ def gather_descriptors(xyz, desc, score):
 class ShardCollector:
     """This rank's results, kept in HBM as they are produced: one f32[rows, width] buffer of [xyz | desc | score] records
     (ops.pack_descriptors) plus the row count of every fragment.  `add` is one contiguous device-to-device copy (plumbing,
-    issued on the current stream); `gather` is the path's only data collective."""
+    issued on the current stream); `gather` is the path's only data collective.
 
-    def __init__(self, rows_cap, width=36, device=None):
+    chunk_frags > 0 (with frag_rows = the row capacity of one fragment's contribution): OVERLAPPED mode.  Fragment k lives at
+    the fixed rows [k * frag_rows, ...), so no size has to be agreed on before data moves: after every `chunk_frags` fragments
+    the finished chunk is all-gathered asynchronously (RCCL runs it on its own stream behind the compute; point-to-point
+    xGMI: 7 peers x one 4.2 MB-per-fragment message), `gather` only waits, sends the last partial chunk and exchanges the row
+    counts.  The end-of-run exchange of a whole shard -- ~10 % of the timed region on 8 GPUs when done at once -- is hidden."""
+
+    def __init__(self, rows_cap, width=36, device=None, chunk_frags=0, frag_rows=0, async_chunks=None):
+        # async_chunks: how many chunks are exchanged WHILE fragments are produced.  Collectives must be issued in the same
+        # order on every rank, so with shards of different lengths (LPT partition) pass min over ranks of n_r // chunk_frags
+        # (every rank can compute it: the partition is deterministic); None = no limit (equal shards: bench.py)
+        self.async_chunks = async_chunks
+        self.chunk_frags, self.frag_rows_cap = int(chunk_frags), int(frag_rows)
+        if self.chunk_frags > 0:
+            assert self.frag_rows_cap > 0
+            nchunks = max(-(-int(rows_cap) // (self.chunk_frags * self.frag_rows_cap)), 1)
+            rows_cap = nchunks * self.chunk_frags * self.frag_rows_cap
         self.buf = torch.empty((int(rows_cap), int(width)), dtype=torch.float32, device=device)
         self.rows = 0
         self.frag_rows = []
+        self._works, self._chunks = [], []
 
     def reset(self):
+        for w in self._works:
+            if w is not None:
+                w.wait()
         self.rows, self.frag_rows = 0, []
+        self._works, self._chunks = [], []
+
+    def _grow(self, need):
+        grown = torch.empty((max(2 * self.buf.shape[0], need), self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
+        grown[: self.rows].copy_(self.buf[: self.rows])
+        self.buf = grown
 
     def add(self, packed):
         n = int(packed.shape[0])
+        if self.chunk_frags > 0:
+            k, R = len(self.frag_rows), self.frag_rows_cap
+            if n > R:
+                raise ValueError("ShardCollector: a fragment of %d rows exceeds the fixed stride %d" % (n, R))
+            if (k + 1) * R > self.buf.shape[0]:
+                for w in self._works:          # the chunks in flight read the old buffer
+                    if w is not None:
+                        w.wait()
+                self.rows = k * R
+                self._grow((k + self.chunk_frags) * R)
+            self.buf[k * R:k * R + n].copy_(packed, non_blocking=True)
+            self.frag_rows.append(n)
+            self.rows = (k + 1) * R
+            if (k + 1) % self.chunk_frags == 0 and (self.async_chunks is None or len(self._works) < self.async_chunks):
+                self._launch_chunk((k + 1) // self.chunk_frags - 1, async_op=True)
+            return
         if self.rows + n > self.buf.shape[0]:
-            grown = torch.empty((max(2 * self.buf.shape[0], self.rows + n), self.buf.shape[1]), dtype=torch.float32,
-                                device=self.buf.device)
-            grown[: self.rows].copy_(self.buf[: self.rows])
-            self.buf = grown
+            self._grow(self.rows + n)
         self.buf[self.rows:self.rows + n].copy_(packed, non_blocking=True)
         self.rows += n
         self.frag_rows.append(n)
 
+    def _launch_chunk(self, c, async_op):
+        ws = world()[1]
+        if ws == 1:
+            return
+        rows = self.chunk_frags * self.frag_rows_cap
+        recv = torch.empty((ws * rows, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
+        self._chunks.append(recv)
+        self._works.append(all_gather_into(recv, self.buf[c * rows:(c + 1) * rows], async_op=async_op))
+
     def records(self):
+        if self.chunk_frags > 0:
+            R = self.frag_rows_cap
+            parts = [self.buf[k * R:k * R + n] for k, n in enumerate(self.frag_rows)]
+            return torch.cat(parts) if parts else self.buf[:0]
         return self.buf[: self.rows]
 
-    def gather(self):
-        """-> list over ranks of (records, frag_rows).  The receive buffer is sized once for the collector's capacity and
-        kept (views of it are returned: valid until the next gather), so a timed gather allocates nothing."""
+    def gather(self, compact=True):
+        """-> list over ranks of (records, frag_rows).  Plain mode: the receive buffer is sized for what the ranks actually hold
+        and kept (views of it are returned: valid until the next gather), so a repeated timed gather allocates nothing.
+        Overlapped mode: waits for the chunks in flight, sends the last partial chunk, exchanges the row counts; compact=False
+        returns each rank's records as a LIST of per-fragment views (no compaction copy)."""
+        if self.chunk_frags > 0:
+            return self._gather_chunked(compact)
+
         def receive(rows_total):
-            need = max(rows_total, world()[1] * self.buf.shape[0])
-            if getattr(self, "_recv", None) is None or self._recv.shape[0] < need:
-                self._recv = torch.empty((need, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
+            if getattr(self, "_recv", None) is None or self._recv.shape[0] < rows_total:
+                self._recv = torch.empty((rows_total, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
             return self._recv[:rows_total]
         return gather_shard(self.records(), self.frag_rows, backing=self.buf, receive=receive)
+
+    def _gather_chunked(self, compact):
+        rank, ws = world()
+        C, R = self.chunk_frags, self.frag_rows_cap
+        if ws == 1:
+            parts = [self.buf[k * R:k * R + n] for k, n in enumerate(self.frag_rows)]
+            return [((torch.cat(parts) if parts else self.buf[:0]) if compact else parts, list(self.frag_rows))]
+        dev = self.buf.device
+        nf = torch.tensor([len(self.frag_rows)], dtype=torch.int64, device=dev)
+        nfs = torch.empty((ws,), dtype=torch.int64, device=dev)
+        all_gather_into(nfs, nf)
+        nfs = [int(v) for v in nfs.tolist()]
+        fmax = max(max(nfs), 1)
+        # ranks hold different numbers of fragments (LPT shards): every rank takes part in ceil(fmax / C) chunk collectives
+        nch = -(-fmax // C)
+        if nch * C * R > self.buf.shape[0]:
+            for w in self._works:
+                if w is not None:
+                    w.wait()
+            self.rows = len(self.frag_rows) * R
+            self._grow(nch * C * R)
+        for c in range(len(self._works), nch):
+            self._launch_chunk(c, async_op=False)
+        for w in self._works:
+            if w is not None:
+                w.wait()
+        fr = torch.zeros((fmax,), dtype=torch.int64, device=dev)
+        if self.frag_rows:
+            fr[: len(self.frag_rows)] = torch.tensor(self.frag_rows, dtype=torch.int64).to(dev)
+        frs = torch.empty((ws * fmax,), dtype=torch.int64, device=dev)
+        all_gather_into(frs, fr)
+        frs = frs.view(ws, fmax).tolist()
+        out = []
+        for r in range(ws):
+            parts = []
+            for k in range(nfs[r]):
+                ch = self._chunks[k // C].view(ws, C * R, -1)[r]
+                parts.append(ch[(k % C) * R:(k % C) * R + int(frs[r][k])])
+            rows = [int(v) for v in frs[r][: nfs[r]]]
+            out.append(((torch.cat(parts) if parts else self.buf[:0]) if compact else parts, rows))
+        return out
 
 
 def gather_shard(records, frag_rows, backing=None, receive=None):
@@ -126,14 +239,14 @@ def gather_shard(records, frag_rows, backing=None, receive=None):
     W = records.shape[1]
     meta = torch.tensor([records.shape[0], len(frag_rows)], dtype=torch.int64, device=dev)
     metas = torch.empty((ws * 2,), dtype=torch.int64, device=dev)        # concatenated along dim 0 (gloo chunks it that way)
-    dist.all_gather_into_tensor(metas, meta)
+    all_gather_into(metas, meta)
     metas = [[int(v) for v in m] for m in metas.view(ws, 2).tolist()]
     rmax, fmax = max(m[0] for m in metas), max(max(m[1] for m in metas), 1)
     fr = torch.zeros((fmax,), dtype=torch.int64, device=dev)
     if frag_rows:
         fr[: len(frag_rows)] = torch.tensor(list(frag_rows), dtype=torch.int64).to(dev)
     frs = torch.empty((ws * fmax,), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(frs, fr)
+    all_gather_into(frs, fr)
     frs = frs.view(ws, fmax).tolist()
     if rmax == records.shape[0] and records.is_contiguous():
         payload = records
@@ -143,6 +256,6 @@ def gather_shard(records, frag_rows, backing=None, receive=None):
         payload = torch.zeros((rmax, W), dtype=torch.float32, device=dev)
         payload[: records.shape[0]] = records
     out = receive(ws * rmax) if receive is not None else torch.empty((ws * rmax, W), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out, payload)
+    all_gather_into(out, payload)
     out = out.view(ws, rmax, W)
     return [(out[r, : m[0]], [int(v) for v in f[: m[1]]]) for r, (m, f) in enumerate(zip(metas, frs))]

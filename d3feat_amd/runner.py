@@ -38,13 +38,13 @@ def _gather_index_lists(mine, n_items, device):
     t = torch.full((n_items,), -1, dtype=torch.int64, device=device)
     if mine:
         t[: len(mine)] = torch.tensor(list(mine), dtype=torch.int64, device=device)
-    out = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(out, t)
-    return [[int(v) for v in o.tolist() if v >= 0] for o in out]
+    out = torch.empty((ws * n_items,), dtype=torch.int64, device=device)
+    parallel.all_gather_into(out, t)
+    return [[int(v) for v in o if v >= 0] for o in out.view(ws, n_items).tolist()]
 
 
 def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibrate, device, out_root=None, gather=True,
-                save=None, log=None, keep="first"):
+                save=None, log=None, keep="first", overlap_chunk=0):
     """fragment_ids: list of id strings ('<scene>/cloud_bin_<k>.ply'); sizes: raw point count per fragment (all ranks pass the
     same lists); load(i) -> float32 [n,3] raw cloud of fragment i (called by the owner only).
     make_engine(config, weights, limits, raw_cap, n0_cap_hint) -> engine with .F, .slots, submit(slot, [raw...]),
@@ -53,11 +53,16 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
     keep: what a fragment contributes to the shard that is gathered -- "first": the first cloud's records, which is what
     utils/tester.py:208-229 keeps of a stacked self-pair; "pair": the whole stacked block (KITTI pairs).  `save` always
     receives the whole block.
+    overlap_chunk > 0: the shards are exchanged while they are produced, `overlap_chunk` fragments per asynchronous collective
+    (parallel.ShardCollector overlapped mode; fixed stride = the engine's row capacity of one contribution).
     -> dict(limits, mine, order (rank 0..W-1 -> fragment indices), shards (list over ranks of (records, frag_rows)) | None)."""
     assert keep in ("first", "pair")
     rank, world = parallel.world()
     n = len(fragment_ids)
     mine = parallel.shard_fragments(n, rank, world, sizes=sizes)
+    # chunks every rank can exchange while it still produces: the shortest shard decides (same collective order everywhere)
+    async_chunks = (min(len(parallel.shard_fragments(n, r, world, sizes=sizes)) for r in range(world)) // overlap_chunk
+                    if overlap_chunk > 0 else 0)
     raws = {i: load(i) for i in mine}
     # ---- calibration: local histograms, summed over ranks
     hists = calibrate([raws[i] for i in mine])
@@ -74,8 +79,15 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
         nonlocal collector
         for i, rec in zip(pending[sl], engine.fetch(sl, packed=True)):
             if collector is None:
-                collector = parallel.ShardCollector(rows_cap=max(int(rec.shape[0]) * max(len(mine), 1), 1), width=rec.shape[1],
-                                                    device=rec.device)
+                if overlap_chunk > 0 and gather:
+                    # fixed stride = the engine's row capacity of one contribution: the SAME number on every rank (the chunk
+                    # collectives have one size); a fragment beyond it (eager fallback of an oversize cloud) cannot be kept
+                    cap_rows = int(getattr(engine, "n0_cap", rec.shape[0] // 2)) * (1 if keep == "first" else 2)
+                    collector = parallel.ShardCollector(rows_cap=cap_rows * max(len(mine), 1), width=rec.shape[1], device=rec.device,
+                                                        chunk_frags=overlap_chunk, frag_rows=cap_rows, async_chunks=async_chunks)
+                else:
+                    collector = parallel.ShardCollector(rows_cap=max(int(rec.shape[0]) * max(len(mine), 1), 1), width=rec.shape[1],
+                                                        device=rec.device)
             collector.add(rec[: rec.shape[0] // 2] if keep == "first" else rec)
             produced.append(i)
             if save is not None:
@@ -99,8 +111,10 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
     order = _gather_index_lists(mine, max(n, 1), device)
     shards = None
     if gather:
-        if collector is None:
-            collector = parallel.ShardCollector(rows_cap=1, width=36, device=device)
+        if collector is None:     # a rank without fragments still takes part in every collective
+            collector = (parallel.ShardCollector(rows_cap=1, width=36, device=device, chunk_frags=overlap_chunk, async_chunks=0,
+                                                 frag_rows=int(getattr(engine, "n0_cap", 1)) * (1 if keep == "first" else 2))
+                         if overlap_chunk > 0 else parallel.ShardCollector(rows_cap=1, width=36, device=device))
         shards = collector.gather()
     return dict(limits=limits, mine=list(mine), order=order, shards=shards, fallbacks=getattr(engine, "fallbacks", 0))
 

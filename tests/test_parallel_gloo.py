@@ -86,6 +86,29 @@ def _worker(rank, world, port, out_dir):
                 gi = torch.Generator().manual_seed(1000 * r + i)
                 assert torch.equal(rec[o:o + n], torch.rand(n, 36, generator=gi))
                 o += n
+        # ---- the same in OVERLAPPED mode: fixed stride per fragment, chunks of 2 fragments exchanged while the fragments are added
+        # (1 early chunk on both ranks: the shorter shard -- 3 fragments -- decides), buffer deliberately too small (grows), both
+        # result forms (compacted / per-fragment views), and a second run after reset()
+        col = parallel.ShardCollector(rows_cap=100, width=36, chunk_frags=2, frag_rows=80, async_chunks=3 // 2)
+        for rep in range(2):
+            for i in range(nfr):
+                gi = torch.Generator().manual_seed(1000 * rank + i)
+                col.add(torch.rand(50 + 7 * i + rank, 36, generator=gi))
+            assert len(col._works) == 1
+            for compact in ((True, False) if rep == 0 else (False,)):
+                shards = col.gather(compact=compact)
+                for r, (rec, fr) in enumerate(shards):
+                    assert fr == [50 + 7 * i + r for i in range(3 + r)]
+                    parts = rec if not compact else None
+                    o = 0
+                    for i, n in enumerate(fr):
+                        gi = torch.Generator().manual_seed(1000 * r + i)
+                        want = torch.rand(n, 36, generator=gi)
+                        assert torch.equal(parts[i] if parts is not None else rec[o:o + n], want)
+                        o += n
+            col.reset()
+        with pytest.raises(ValueError):
+            col.add(torch.rand(81, 36))
         open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     finally:
         dist.barrier()

@@ -65,7 +65,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap_chunk=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -80,7 +80,7 @@ def _worker(rank, world, port, out_dir):
             return _Engine()
         saved = []
         res = runner.run_sharded(IDS, SIZES, _load, None, None, make_engine, _hist, torch.device("cpu"),
-                                 save=lambda fid, rec: saved.append(fid))
+                                 save=lambda fid, rec: saved.append(fid), overlap_chunk=overlap_chunk)
         want_limits = runner.limits_from_histograms(_hist([_load(i) for i in range(N_FRAG)]))
         assert np.array_equal(res["limits"], want_limits) and np.array_equal(seen_limits["limits"], want_limits)
         # ownership: a partition of the fragment list, the same on every rank
@@ -107,9 +107,12 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(180)
-def test_sharded_runner_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("overlap_chunk", [0, 2, 3])
+def test_sharded_runner_two_ranks_gloo(tmp_path, overlap_chunk):
+    """overlap_chunk > 0: the shards are exchanged in asynchronous chunks of that many fragments while they are produced (shards
+    of 5 and 4 fragments: the shorter one decides how many chunks go early, the rest follows in gather)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap_chunk), nprocs=world, join=True)
     owned = [open(tmp_path / ("ok_%d" % r)).read().split(",") for r in range(world)]
     assert sorted(int(i) for o in owned for i in o if i) == list(range(N_FRAG))
     for i in range(N_FRAG):

@@ -34,14 +34,24 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--overlap-chunk", type=int, default=0,
+                    help="exchange the shards in asynchronous chunks of this many fragments while they are produced (0: one "
+                         "all_gather at the end)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo: collectives through host memory -- with --one-device, several ranks share GPU 0 (RCCL refuses "
+                         "two ranks on one device): the way to run runner + engine + gather with > 1 rank on a 1-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="every rank computes on cuda:0")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if a.backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     from d3feat_amd import runner
     from d3feat_amd.models.variables import build_variables
     from d3feat_amd.utils.config import Config, threedmatch_config
@@ -73,13 +83,14 @@ def main():
             return read_ply_xyz(os.path.join(a.fragments, ids[i]))
     t0 = time.perf_counter()
     res = runner.run_sharded(ids, sizes, load, cfg, W, runner.gpu_engine_factory(a.slots, a.batch), runner.gpu_calibrate(cfg), dev,
-                             gather=not a.no_gather, save=runner.save_records_3dmatch(a.out))
+                             gather=not a.no_gather, save=runner.save_records_3dmatch(a.out), overlap_chunk=a.overlap_chunk)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"fragments": len(ids), "world": world, "seconds": round(dt, 3), "limits": [int(x) for x in res["limits"]],
                           "fragments_per_rank": [len(o) for o in res["order"]], "fallbacks": res["fallbacks"],
-                          "gathered_rows": [int(s[0].shape[0]) for s in res["shards"]] if res["shards"] else None}))
+                          "gathered_rows": [int(s[0].shape[0]) for s in res["shards"]] if res["shards"] else None,
+                          "gathered_checksum": [round(float(s[0].double().sum().item()), 3) for s in res["shards"]] if res["shards"] else None}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
