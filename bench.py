@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--bf16", action="store_true",
                     help="BASELINE configs[4] (a SEPARATE configuration, never the fp32 headline): unary / unfused KPConv "
                          "contractions with bf16 operands and fp32 accumulation; use with --batch 8 --slots 2")
+    ap.add_argument("--bf16-features", action="store_true",
+                    help="BASELINE configs[4] in full: bf16 contraction AND the activations between the layers stored as bfloat16 "
+                         "(implies --bf16; still a separate configuration)")
     ap.add_argument("--no-marginal", action="store_true", help="skip the marginal-cost measurements (extra engines with one op "
                     "family skipped each)")
     ap.add_argument("--config3", action="store_true",
@@ -97,9 +100,10 @@ def parse():
 class Step:
     """The hot path for one fragment, op by op (instrumented pass, --eager)."""
 
-    def __init__(self, cfg, model, limits, device, bf16=False):
+    def __init__(self, cfg, model, limits, device, bf16=False, bf16_features=False):
         from d3feat_amd.datasets.common import FragmentDataset
         self.cfg, self.model, self.device, self.bf16 = cfg, model, device, bool(bf16)
+        self.bf16_features = bool(bf16_features)
         self.ds = FragmentDataset([], fast=True)
         self.ds.neighborhood_limits = limits
         self.ds.stack_group = 2
@@ -115,7 +119,7 @@ class Step:
         pts = torch.cat([x for s in subs for x in (s, s)], 0)                                # self-pairs (device copies)
         lens = ops.as_lens([int(s.shape[0]) for s in subs for _ in (0, 1)], self.device)
         flat = self.map(pts, None, None, None, lens, ("a", "a"), pts)
-        with ops.bf16_contraction(self.bf16):
+        with ops.bf16_contraction(self.bf16, features=self.bf16_features):
             desc, score = self.model.run(flat)
         return ops.pack_descriptors(pts, desc, score)
 
@@ -141,6 +145,8 @@ def source_hash():
 
 def main():
     args = parse()
+    if args.bf16_features:
+        args.bf16 = True
     if args.batch <= 0:
         args.batch = (8 if args.steps >= 256 else 4) if args.steps >= 64 else max(1, min(8, -(-args.steps // max(args.slots, 1))))
     import torch
@@ -199,7 +205,7 @@ def main():
     limits = np.sum(cumsum < (0.8 * cumsum[hist_n - 1, :]), axis=0).astype(np.int32)
 
     model = KernelPointFCNN(None, cfg, weights=W, device=device)
-    step = Step(cfg, model, limits, device, bf16=args.bf16)          # eager op-by-op path (instrumented pass, --eager)
+    step = Step(cfg, model, limits, device, bf16=args.bf16, bf16_features=args.bf16_features)          # eager op-by-op path (instrumented pass, --eager)
     if args.ablate:
         install_ablation(args.ablate.split(","))     # after the calibration (which reads its results back)
 
@@ -218,7 +224,7 @@ def main():
         n0_cap = (int(n0_max * args.cap_factor) + 1023) // 1024 * 1024
         engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, level_ratio=args.level_ratio, slots=args.slots, device=device,
                                 n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
-                                batch=args.batch, bf16=args.bf16)
+                                batch=args.batch, bf16=args.bf16, bf16_features=args.bf16_features)
     # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
     # (N > 1: overlapped mode -- fixed stride per fragment, chunks of --gather-chunk fragments all-gathered asynchronously
     # while the next replays run; every rank holds the same number of fragments, so the collective order is the same everywhere)
@@ -374,12 +380,15 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "fragments/sec (30k-pt clouds)" + (" -- configs[4]: bf16 contraction" if args.bf16 else "") +
+            "metric": "fragments/sec (30k-pt clouds)" + ((" -- configs[4]: bf16 features + bf16 contraction" if args.bf16_features
+                                                         else " -- configs[4]: bf16 contraction") if args.bf16 else "") +
                       (" -- configs[2] shape: fragment sizes U(15k, 45k)" if args.config3 else ""),
             "value": round(world * args.steps / dt, 3), "unit": "fragments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16 operands / f32 accumulate in the unary + unfused KPConv contractions; f32 elsewhere (NOT the fp32 "
+            "dtype": (("bf16 feature storage between the layers, bf16 operands / f32 accumulate in the unary + unfused KPConv "
+                       "contractions, f32 arithmetic inside the gather kernels (NOT the fp32 parity path)") if args.bf16_features else
+                      "bf16 operands / f32 accumulate in the unary + unfused KPConv contractions; f32 elsewhere (NOT the fp32 "
                       "parity path)" if args.bf16 else "f32"), "data": "synthetic",
             "config": {"workload": ("SURVEY §8d config #3 shape (NOT the config #2 headline): synthetic 3DMatch room fragments of "
                                     "U(15 k, 45 k) points (mean %dk) after the 0.03 m subsample, capacities of the largest" % round(npts / 1000)

@@ -33,22 +33,22 @@ SIGNATURES = {
     "d3f_neighbor_grid_order_offset": (_sz, [_i, _i]),
     "d3f_neighbor_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp]),
     "d3f_neighbor_grid_search": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "d3f_row_positive": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "d3f_row_positive": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp,
-                                  _vp, _vp]),
+                                  _vp, _i, _vp]),
     "d3f_kpconv_fused_c1": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
-                                 _f, _vp, _i, _vp, _vp, _vp, _vp]),
+                                 _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "d3f_kpconv_fused32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp,
-                                _i, _vp, _vp, _vp, _vp]),
+                                _i, _vp, _vp, _vp, _i, _vp]),
     "d3f_kpconv_fused_supported": (_i, [_i, _i, _i, _i, _i]),
     "d3f_kpconv_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "d3f_kpconv_fused": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
-                              _f, _vp, _i, _vp, _vp, _vp, _vp]),
+                              _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),
     "d3f_gemm_upsample_cat_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _sz,
                                        _vp, _vp, _i, _vp]),
-    "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_ind_max_pool": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
     "d3f_pack_descriptors": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
@@ -61,7 +61,7 @@ SIGNATURES = {
     "d3f_neighbor_grid_score": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "d3f_gemm_pack_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "d3f_gemm_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
-                           _vp, _vp, _i, _vp]),
+                           _vp, _vp, _i, _i, _i, _vp]),
     "d3f_decode_xyz_records": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "d3f_detect_head": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
 }

@@ -626,15 +626,27 @@ gemm_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict
     }
 }
 
+// res_bf16 / c_bf16: the residual operand / the output hold bfloat16 values (bf16 feature storage, d3f_gemm_bf16)
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E,
-                          const int* __restrict__ M_dev) {
+                          const int* __restrict__ M_dev, int res_bf16 = 0, int c_bf16 = 0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)d3f_dyn(M, M_dev) * N) return;
     const int m = (int)(i / N), n = (int)(i % N);
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += slab[((size_t)s * M + m) * N + n];
-    C[(size_t)m * ldc + n] = gemm_epilogue(v, m, n, E);
+    if (res_bf16 && E.residual) {
+        const float r = d3f_bf16_f32(((const unsigned short*)E.residual)[(size_t)m * E.ldr + n]);
+        GemmEpi E2 = E;
+        E2.residual = nullptr;
+        E2.leaky = 0;
+        v = gemm_epilogue(v, m, n, E2) + r;
+        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+    } else {
+        v = gemm_epilogue(v, m, n, E);
+    }
+    if (c_bf16) ((unsigned short*)C)[(size_t)m * ldc + n] = (unsigned short)d3f_bf16_rne(v);
+    else C[(size_t)m * ldc + n] = v;
 }
 
 // Tile selection.  Large tiles (each wave owns 2x2 / 2x1 MFMA tiles: half the LDS traffic per flop, 4 independent
@@ -864,6 +876,7 @@ extern "C" int d3f_gemm_pack_bf16(const float* B, int ldb, int K, int N, void* W
     return D3F_OK;
 }
 
+template <bool ABF, bool CBF>   // ABF: A / skip / residual hold bfloat16 (bf16 feature storage); CBF: C is written as bfloat16
 __global__ void __launch_bounds__(256)
 gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wt, int Kp, float* __restrict__ C,
                  int ldc, int M, int N, int K, int tiles_per_split, float* __restrict__ slab, GemmEpi E,
@@ -903,20 +916,32 @@ gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __r
         }
     }
     const int brow = n0 + (tid >> 2);
-    float4 ra[2];
+    float4 ra[2];      // fp32 activations: four values per slot, rounded while staging
+    uint2 rh[2];       // bf16 activations: the same four values, already in storage format
     uint4 rb;
+    const unsigned short* Ah = (const unsigned short*)A;
+    const unsigned short* A2h = (const unsigned short*)G.A2;
     auto load_tile = [&](int t) {
         const int k0 = t * GB_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + i * 256;
             const int gm = m0 + (e >> 3), k = k0 + ((e & 7) << 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M && k < K) {                 // (K, K1 and the leading dimensions are multiples of 4: checked by the launcher)
-                if (G.A2 && k >= G.K1) v = *(const float4*)(G.A2 + (size_t)gm * G.lda2 + (k - G.K1));
-                else if (srow[i] >= 0) v = *(const float4*)(A + (size_t)srow[i] * lda + k);
+            if (ABF) {
+                uint2 v = make_uint2(0u, 0u);
+                if (gm < M && k < K) {
+                    if (G.A2 && k >= G.K1) v = *(const uint2*)(A2h + (size_t)gm * G.lda2 + (k - G.K1));
+                    else if (srow[i] >= 0) v = *(const uint2*)(Ah + (size_t)srow[i] * lda + k);
+                }
+                rh[i] = v;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gm < M && k < K) {             // (K, K1 and the leading dimensions are multiples of 4: checked by the launcher)
+                    if (G.A2 && k >= G.K1) v = *(const float4*)(G.A2 + (size_t)gm * G.lda2 + (k - G.K1));
+                    else if (srow[i] >= 0) v = *(const float4*)(A + (size_t)srow[i] * lda + k);
+                }
+                ra[i] = v;
             }
-            ra[i] = v;
         }
         rb = (brow < N) ? *(const uint4*)(Wt + (size_t)brow * Kp + k0 + ((tid & 3) << 3)) : make_uint4(0u, 0u, 0u, 0u);
     };
@@ -924,7 +949,7 @@ gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __r
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + i * 256;
-            uint2 p = make_uint2(gb_pack2(ra[i].x, ra[i].y), gb_pack2(ra[i].z, ra[i].w));
+            const uint2 p = ABF ? rh[i] : make_uint2(gb_pack2(ra[i].x, ra[i].y), gb_pack2(ra[i].z, ra[i].w));
             *(uint2*)&As[buf][(e >> 3) * GB_LS + ((e & 7) << 2)] = p;
         }
         *(uint4*)&Bs[buf][(tid >> 2) * GB_LS + ((tid & 3) << 3)] = rb;
@@ -963,27 +988,34 @@ gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __r
         float v = acc[r];
         if (E.row_scale) v *= E.row_scale[gm];
         v = v * cs + ch;
-        if (E.residual) v += E.residual[(size_t)gm * E.ldr + gn];
+        if (E.residual)
+            v += ABF ? d3f_bf16_f32(((const unsigned short*)E.residual)[(size_t)gm * E.ldr + gn]) : E.residual[(size_t)gm * E.ldr + gn];
         if (E.leaky) v = v > 0.f ? v : v * E.alpha;
-        C[(size_t)gm * ldc + gn] = v;
+        if (CBF) ((unsigned short*)C)[(size_t)gm * ldc + gn] = (unsigned short)d3f_bf16_rne(v);
+        else C[(size_t)gm * ldc + gn] = v;
     }
 }
 
 // A f32[M,K] (lda) or the composite [ x'[idx[m,0]] | skip[m] ] (idx != NULL / skip != NULL, as d3f_gemm_upsample_cat_f32);
 // Wt = d3f_gemm_pack_bf16(W [K,N]).  K, K1 = C1, lda, lds multiples of 4 and 16-byte aligned bases (else D3F_ERR_ARG: use the
 // fp32 entry points).  workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint).
-extern "C" int d3f_gemm_bf16(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds,
-                             int C2, const void* Wt, float* C, int ldc, int M, int N, const float* row_scale,
-                             const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
+extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int* idx, int ld_idx, const void* skip_, int lds,
+                             int C2, const void* Wt, void* C_, int ldc, int M, int N, const float* row_scale,
+                             const float* col_scale, const float* col_shift, const void* residual_, int ldr, int leaky,
                              float alpha, void* workspace, size_t workspace_bytes, const int* M_dev, const int* N1_dev,
-                             int M_hint, void* stream_) {
+                             int M_hint, int a_bf16, int c_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* A = (const float*)A_;
+    const float* skip = (const float*)skip_;
+    const float* residual = (const float*)residual_;
+    float* C = (float*)C_;
     const int K = C1 + C2;
     if (M < 0 || N < 1 || N1 < 0 || C1 < 4 || C2 < 0 || (K % 4) || (C1 % 4) || lda < C1 || (lda % 4) || ldc < N ||
         (C2 > 0 && (lds < C2 || (lds % 4))) || (residual && ldr < N) || (idx && ld_idx < 1) || (!idx && N1 < M))
         return D3F_ERR_ARG;
     if (M == 0) return D3F_OK;
-    if (!A || !Wt || !C || (C2 > 0 && !skip) || (((uintptr_t)A | (uintptr_t)skip | (uintptr_t)Wt) & 15)) return D3F_ERR_ARG;
+    if (!A || !Wt || !C || (C2 > 0 && !skip) || ((uintptr_t)Wt & 15) || (((uintptr_t)A | (uintptr_t)skip) & (a_bf16 ? 7 : 15)))
+        return D3F_ERR_ARG;
     const int Kp = (K + GB_BK - 1) / GB_BK * GB_BK;
     int bm, bn, S, tps;
     gemm_plan(M, N > 32 ? N : 64, K, M_hint, bm, bn, S, tps);   // (tile is 64 x 64 here; the plan only decides the K split)
@@ -1000,9 +1032,12 @@ extern "C" int d3f_gemm_bf16(const float* A, int N1, int lda, int C1, const int*
     GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
     GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
     dim3 grid(d3f_cdiv(N, 64), S, d3f_cdiv(M, 64));
-    gemm_bf16_kernel<<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wt, Kp, C, ldc, M, N, K, tps, slab, E, M_dev, G);
+#define D3F_GB(ABF_, CBF_) gemm_bf16_kernel<ABF_, CBF_><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wt, Kp, C, ldc, M, N, K, tps, slab, E, M_dev, G)
+    if (a_bf16) { if (c_bf16) D3F_GB(true, true); else D3F_GB(true, false); }
+    else { if (c_bf16) D3F_GB(false, true); else D3F_GB(false, false); }
+#undef D3F_GB
     if (S > 1)
-        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
+        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev, a_bf16, c_bf16);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

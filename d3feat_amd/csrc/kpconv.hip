@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) kp_rowpos_kernel(const float* __restrict_
 
 // 16-byte loads, LPR lanes per row (64 / LPR rows per wavefront): for the narrow rows of the fine levels the one-row-per-
 // wavefront form spends its time in the 64-lane fp64 butterfly, not in the loads.  Same fp64 sum, another (equally exact) order.
-template <int LPR>
-__global__ void __launch_bounds__(256) kp_rowpos_vec_kernel(const float* __restrict__ f, int Ns, const int* __restrict__ Ns_dev,
+template <int LPR, class FT = float>   // FT: feature storage type (float, or unsigned short = bf16: common.h D3fFeat)
+__global__ void __launch_bounds__(256) kp_rowpos_vec_kernel(const FT* __restrict__ f, int Ns, const int* __restrict__ Ns_dev,
                                                             int ldf, int Cin, unsigned char* __restrict__ pos) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long row = t / LPR;
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) kp_rowpos_vec_kernel(const float* __restr
     double s = 0.0;
     if (in) {
         for (int c = 4 * l; c < Cin; c += 4 * LPR) {
-            const float4 v = *(const float4*)&f[(size_t)row * ldf + c];
+            const float4 v = D3fFeat<FT>::ld4(&f[(size_t)row * ldf + c]);
             s += (double)v.x; s += (double)v.y; s += (double)v.z; s += (double)v.w;
         }
     }
@@ -158,10 +158,10 @@ __global__ void __launch_bounds__(256) kp_rowpos_vec_kernel(const float* __restr
     if (in && l == 0) pos[row] = s > 0.0 ? 1 : 0;
 }
 
-template <int LQ, bool FAST>  // lanes per query = Cin / 4; FAST: linear / sum / 15 kernel points (kp_influences_t)
+template <int LQ, bool FAST, class FT = float>  // lanes per query = Cin / 4; FAST: linear / sum / 15 kernel points (kp_influences_t)
 __global__ void __launch_bounds__(256)
 kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
-                int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                 KpParams P, float* __restrict__ wf, float* __restrict__ inv_cnt, const int* __restrict__ Nq_dev,
                 const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
     constexpr int TQ = 256 / LQ;  // queries per workgroup
@@ -221,7 +221,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                fv[u] = ids[u] >= 0 ? *(const float4*)&f[(size_t)ids[u] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = ids[u] >= 0 ? D3fFeat<FT>::ld4(&f[(size_t)ids[u] * ldf + 4 * cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -360,10 +360,11 @@ kpconv_c1_fused_kernel(const float* __restrict__ q, int Nq, const float* __restr
 // an LDS copy of the 16 x 16 sums with lanes = output channels.
 #define C1_SC 64                    // neighbours staged per pass (4 per loader lane)
 #define C1_QS (C1_SC * 4 + 4)      // floats per query in LDS; +4 de-phases the four queries of a wavefront (b128 broadcasts)
+template <class OT = float>   // OT: output feature storage type (the input feature is the constant-1 column, fp32)
 __global__ void __launch_bounds__(256)
 kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                     int ld_idx, int K, const float* __restrict__ f, int ldf, KpParams P, const float* __restrict__ W,
-                    int Cout, KpEpi E, float* __restrict__ out, int ldo, const int* __restrict__ Nq_dev,
+                    int Cout, KpEpi E, OT* __restrict__ out, int ldo, const int* __restrict__ Nq_dev,
                     const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
@@ -452,7 +453,7 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             v = v * (1.0f / fmaxf(sacc[qq][15], 1.0f)) * cs + ch;
             if (E.residual) v += E.residual[(size_t)gq * E.ldr + o];
             if (E.leaky) v = v > 0.f ? v : v * E.alpha;
-            out[(size_t)gq * ldo + o] = v;
+            D3fFeat<OT>::st1(&out[(size_t)gq * ldo + o], v);
         }
     }
 }
@@ -461,9 +462,10 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
                                    const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
                                    int aggregation, const float* W, int Cout, const float* col_scale,
                                    const float* col_shift, const float* residual, int ldr, int leaky, float alpha,
-                                   float* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
-                                   void* stream_) {
+                                   void* out_, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                                   int out_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    float* out = (float*)out_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 1 || num_kp < 1 || num_kp > KP_MAXP - 1 || influence < 0 ||
         influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || Cout < 1 || ldo < Cout ||
         (residual && ldr < Cout))
@@ -475,8 +477,13 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
     P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
     P.aggregation = aggregation;
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
+    if (out_bf16 && !(aggregation == 0 && num_kp <= 15)) return D3F_ERR_ARG;    // bf16 feature storage: the shipped configuration
     if (aggregation == 0 && num_kp <= 15) {
-        kpconv_c1_kp_kernel<<<d3f_cdiv(Nq, 16), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E, out, ldo,
+        if (out_bf16)
+            kpconv_c1_kp_kernel<unsigned short><<<d3f_cdiv(Nq, 16), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E,
+                                                                                      (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
+        else
+        kpconv_c1_kp_kernel<float><<<d3f_cdiv(Nq, 16), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, P, W, Cout, E, out, ldo,
                                                                   Nq_dev, Ns_dev, q_order);
     } else {   // 'closest' needs the arg-min over the kernel points of every neighbour: lanes = neighbours
         const long long waves = d3f_cdiv(Nq, C1_QPW);
@@ -506,10 +513,10 @@ typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
 
 // contraction + epilogue of the Cin = Cout = 32 kernels: the 60 register accumulators of every (query, channel group) thread
 // go through the LDS tile in two passes and are contracted with K_values on the matrix cores (see the header comment)
-template <class TileWriter>   // write_tile(wft, p0, np): this thread's weighted features of kernel points p0 .. p0+np-1 -> LDS tile
+template <class TileWriter, class FT>   // write_tile(wft, p0, np): this thread's weighted features of kernel points p0 .. p0+np-1 -> LDS tile
 __device__ __forceinline__ void kf32_contract_epilogue(TileWriter write_tile, int tid, float* kf_smem, const int* lcnt,
                                                        const int* lq, const KpParams& P, const float* __restrict__ W,
-                                                       const KpEpi& E, float* __restrict__ out, int ldo) {
+                                                       const KpEpi& E, FT* __restrict__ out, int ldo) {
     float* wft = kf_smem;
     // ---- contraction on the matrix cores: out[32 x 32] = wf[32 x 480] @ W[480 x 32], in two passes of 8 / 7 kernel points:
     //      this thread's weighted features -> LDS tile wft[ql][(p - p0)*32 + 4*cl + j] (k index = p*Cin + c, as K_values),
@@ -564,15 +571,15 @@ __device__ __forceinline__ void kf32_contract_epilogue(TileWriter write_tile, in
         if (E.col_shift) v += E.col_shift[o];
         if (E.residual) v += E.residual[(size_t)gq * E.ldr + o];
         if (E.leaky) v = v > 0.f ? v : v * E.alpha;
-        out[(size_t)gq * ldo + o] = v;
+        D3fFeat<FT>::st1(&out[(size_t)gq * ldo + o], v);
     }
 }
 
-template <bool FAST, int PF = 8>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
+template <bool FAST, int PF = 8, class FT = float>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
 __global__ void __launch_bounds__(256, PF == 4 ? 4 : 3)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
-                      int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
-                      KpParams P, const float* __restrict__ W, KpEpi E, float* __restrict__ out, int ldo,
+                      int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                      KpParams P, const float* __restrict__ W, KpEpi E, FT* __restrict__ out, int ldo,
                       const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
@@ -629,7 +636,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = lidx[ql * KF_LQ + k1 + u];
-                fv[u] = ids[u] >= 0 ? *(const float4*)&f[(size_t)ids[u] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = ids[u] >= 0 ? D3fFeat<FT>::ld4(&f[(size_t)ids[u] * ldf + 4 * cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -661,11 +668,14 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
 }
 
 extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                                  const float* f, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                                  const void* f_, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
                                   float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
-                                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out,
-                                  int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream_) {
+                                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* out_,
+                                  int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16,
+                                  void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* f = (const float*)f_;
+    float* out = (float*)out_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 32 || (ldf % 4) || num_kp < 1 || num_kp > KP_MAXP - 1 ||
         influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || ldo < 32 ||
         (residual && ldr < 32))
@@ -688,7 +698,14 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 #define D3F_KF(FAST_, PF_)                                                                                                   \
     kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
                                                                                  out, ldo, Nq_dev, Ns_dev, q_order)
-    if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
+    if (feat_bf16) {      // bf16 feature storage (in and out); the shipped configuration only; no residual operand
+        if (!kp_fast_config(num_kp, influence, aggregation) || residual) return D3F_ERR_ARG;
+        static std::atomic<unsigned long long> lds_done_h{0};
+        const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, 8, unsigned short>};
+        if (d3f_opt_in_lds(lds_done_h, fnh, (int)lds) != D3F_OK) return D3F_ERR_HIP;
+        kpconv_fused32_kernel<true, 8, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
+            q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
+    } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
     else if (pf4) D3F_KF(true, 4);
     else D3F_KF(true, 8);
 #undef D3F_KF
@@ -722,11 +739,11 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 // Registers: 60 accumulators + the gather prefetch decide the occupancy.  512-thread workgroups (Cin = 128) are two waves
 // per SIMD each: at more than 128 registers only ONE workgroup fits a CU and its gather and matrix phases cannot overlap with
 // anybody's, so that variant prefetches four rows instead of eight and is held to 128 registers (two workgroups per CU).
-template <int LQ, int PF = (LQ == 32 ? 4 : 8)>   // lanes per query = Cin / 4 (16 or 32); Cout == Cin; waves = LQ / 4 = Cout / 16
+template <int LQ, int PF = (LQ == 32 ? 4 : 8), class FT = float>   // lanes per query = Cin / 4 (16 or 32); Cout == Cin; waves = LQ / 4 = Cout / 16
 __global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)
 kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
-                    int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
-                    KpParams P, const float* __restrict__ Wp, KpEpi E, float* __restrict__ out, int ldo,
+                    int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                    KpParams P, const float* __restrict__ Wp, KpEpi E, FT* __restrict__ out, int ldo,
                     const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
     constexpr int CIN = 4 * LQ, COUT = CIN;
     constexpr int KC = LQ;                  // neighbours per chunk (one (query, neighbour) pair per thread)
@@ -783,7 +800,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                fv[u] = ids[u] >= 0 ? *(const float4*)&f[(size_t)ids[u] * ldf + 4 * cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = ids[u] >= 0 ? D3fFeat<FT>::ld4(&f[(size_t)ids[u] * ldf + 4 * cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -875,7 +892,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
         v = v * cs + ch;
         if (E.residual) v += E.residual[(size_t)gq * E.ldr + n];
         if (E.leaky) v = v > 0.f ? v : v * E.alpha;
-        out[(size_t)gq * ldo + n] = v;
+        D3fFeat<FT>::st1(&out[(size_t)gq * ldo + n], v);
     }
 }
 
@@ -907,12 +924,15 @@ extern "C" int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int inf
 }
 
 extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                                const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                                const void* f_, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
                                 float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,
                                 const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
-                                float alpha, float* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
-                                void* stream_) {
+                                float alpha, void* out_, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                                int feat_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* f = (const float*)f_;
+    float* out = (float*)out_;
+    if (feat_bf16 && residual) return D3F_ERR_ARG;
     if (!d3f_kpconv_fused_supported(Cin, Cout, num_kp, influence, aggregation)) return D3F_ERR_ARG;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < Cin || (ldf % 4) || num_kp < 1 || num_kp > KP_MAXP - 1 ||
         influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f) || ldo < Cout ||
@@ -933,7 +953,16 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
     // tuning knob (read once): D3F_KG_PF4=1 runs the Cin = 64 variant with the shallow gather prefetch (128 registers, four
     // workgroups per CU instead of three)
     static const int pf4 = [] { const char* e = getenv("D3F_KG_PF4"); return e ? atoi(e) : 0; }();
-    if (Cin == 64) { if (pf4) D3F_KG(16, 4); else D3F_KG(16, 8); }
+    if (feat_bf16) {
+        const unsigned short* fh = (const unsigned short*)f_;
+        unsigned short* oh = (unsigned short*)out_;
+        if (Cin == 64)
+            kpconv_fused_kernel<16, 8, unsigned short><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+                                                                                         W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
+        else
+            kpconv_fused_kernel<32, 4, unsigned short><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+                                                                                         W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
+    } else if (Cin == 64) { if (pf4) D3F_KG(16, 4); else D3F_KG(16, 8); }
     else D3F_KG(32, 4);
 #undef D3F_KG
     D3F_LAUNCH_CHECK();
@@ -941,12 +970,26 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------
-extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev,
-                                void* stream_) {
+extern "C" int d3f_row_positive(const void* f_, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev,
+                                int feat_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* f = (const float*)f_;
     if (Ns < 0 || Cin < 1 || ldf < Cin) return D3F_ERR_ARG;
     if (Ns == 0) return D3F_OK;
     if (!f || !row_pos) return D3F_ERR_ARG;
+    if (feat_bf16) {
+        if (Cin % 4 || ldf % 4 || ((uintptr_t)f_ & 7)) return D3F_ERR_ARG;
+        const unsigned short* fh = (const unsigned short*)f_;
+        const int q4 = Cin / 4;
+#define D3F_ROWPOS_H(LPR_) kp_rowpos_vec_kernel<LPR_, unsigned short><<<d3f_cdiv((long long)Ns * LPR_, 256), 256, 0, stream>>>(fh, Ns, Ns_dev, ldf, Cin, row_pos)
+        if (q4 <= 8) D3F_ROWPOS_H(8);
+        else if (q4 <= 16) D3F_ROWPOS_H(16);
+        else if (q4 <= 32) D3F_ROWPOS_H(32);
+        else D3F_ROWPOS_H(64);
+#undef D3F_ROWPOS_H
+        D3F_LAUNCH_CHECK();
+        return D3F_OK;
+    }
     if (Cin % 4 == 0 && ldf % 4 == 0 && ((uintptr_t)f & 15) == 0) {
         const int q4 = Cin / 4;
 #define D3F_ROWPOS(LPR_) kp_rowpos_vec_kernel<LPR_><<<d3f_cdiv((long long)Ns * LPR_, 256), 256, 0, stream>>>(f, Ns, Ns_dev, ldf, Cin, row_pos)
@@ -964,10 +1007,11 @@ extern "C" int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsign
 }
 
 extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                                    const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host,
+                                    const void* f_, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host,
                                     int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
-                                    const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream_) {
+                                    const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* f = (const float*)f_;
     if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || Cin < 1 || ldf < Cin || num_kp < 1 || num_kp > KP_MAXP - 1 ||
         influence < 0 || influence > 2 || aggregation < 0 || aggregation > 1 || !(KP_extent > 0.f))
         return D3F_ERR_ARG;
@@ -979,6 +1023,18 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
     P.aggregation = aggregation;
     const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0);
     const bool fast = kp_fast_config(num_kp, influence, aggregation);
+    if (feat_bf16) {     // bf16 feature rows in, fp32 weighted features out; the deep layers of the shipped configuration
+        const unsigned short* fh = (const unsigned short*)f_;
+        if (!fast || (ldf % 4) || ((uintptr_t)f_ & 7) || ((uintptr_t)wf & 15) || !(Cin == 256 || Cin == 512)) return D3F_ERR_ARG;
+        if (Cin == 256)
+            kpconv_agg_vec4<64, true, unsigned short><<<d3f_cdiv(Nq, 4), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P, wf,
+                                                                                         inv_cnt, Nq_dev, Ns_dev, q_order);
+        else
+            kpconv_agg_vec4<128, true, unsigned short><<<d3f_cdiv(Nq, 2), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P, wf,
+                                                                                          inv_cnt, Nq_dev, Ns_dev, q_order);
+        D3F_LAUNCH_CHECK();
+        return D3F_OK;
+    }
 #define D3F_AGG(LQ_)                                                                                                        \
     do {                                                                                                                    \
         if (fast) kpconv_agg_vec4<LQ_, true><<<d3f_cdiv(Nq, 256 / LQ_), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, \

@@ -21,7 +21,8 @@ __global__ void __launch_bounds__(256) colmin_init_kernel(unsigned* __restrict__
     if (c == C) cm[C] = 0u;       // the flag
 }
 
-__global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x, int N1, const int* __restrict__ N1_dev,
+template <class FT>   // feature storage type (float / unsigned short = bf16, common.h D3fFeat)
+__global__ void __launch_bounds__(256) colmin_kernel(const FT* __restrict__ x, int N1, const int* __restrict__ N1_dev,
                                                      int ldx, int C, unsigned* __restrict__ cm) {
     if (cm[C] == 0u) return;      // no row needs the shadow row
     N1 = d3f_dyn(N1, N1_dev);
@@ -29,14 +30,15 @@ __global__ void __launch_bounds__(256) colmin_kernel(const float* __restrict__ x
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     unsigned m = 0xFFFFFFFFu;
-    for (int r = blockIdx.y; r < N1; r += gridDim.y) m = min(m, d3f_f2ord(x[(size_t)r * ldx + c]));
+    for (int r = blockIdx.y; r < N1; r += gridDim.y) m = min(m, d3f_f2ord(D3fFeat<FT>::ld1(&x[(size_t)r * ldx + c])));
     atomicMin(&cm[c], m);
 }
 
 // rows without a valid neighbour (or K == 0) take the shadow row
+template <class FT>
 __global__ void __launch_bounds__(256) maxpool_patch_kernel(const unsigned* __restrict__ cm, int C, int N1,
                                                             const int* __restrict__ idx, int N2, int ld_idx, int K,
-                                                            float* __restrict__ out, int ldo, const int* __restrict__ N1_dev,
+                                                            FT* __restrict__ out, int ldo, const int* __restrict__ N1_dev,
                                                             const int* __restrict__ N2_dev) {
     if (cm[C] == 0u) return;
     N1 = d3f_dyn(N1, N1_dev);
@@ -51,14 +53,14 @@ __global__ void __launch_bounds__(256) maxpool_patch_kernel(const unsigned* __re
             any = any || (id >= 0 && id < N1);
         }
         if (__any(any)) continue;
-        for (int c = lane; c < C; c += 64) out[(size_t)n * ldo + c] = d3f_ord2f(cm[c]);
+        for (int c = lane; c < C; c += 64) D3fFeat<FT>::st1(&out[(size_t)n * ldo + c], d3f_ord2f(cm[c]));
     }
 }
 
-template <int VEC>  // channels per thread (4: 16-byte loads; 1: generic)
-__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, int N1, int ldx, int C,
+template <int VEC, class FT = float>  // channels per thread (4: 16-byte loads; 1: generic)
+__global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
-                                                      unsigned* __restrict__ flag, float* __restrict__ out, int ldo,
+                                                      unsigned* __restrict__ flag, FT* __restrict__ out, int ldo,
                                                       const int* __restrict__ N1_dev, const int* __restrict__ N2_dev,
                                                       const int* __restrict__ row_order) {
     N1 = d3f_dyn(N1, N1_dev);
@@ -86,11 +88,11 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
             nvalid += ok ? 1 : 0;
             if (ok) {
                 if (VEC == 4) {
-                    const float4 f = *(const float4*)&x[(size_t)id[j] * ldx + c];
+                    const float4 f = D3fFeat<FT>::ld4(&x[(size_t)id[j] * ldx + c]);
                     val[j][0] = f.x; val[j][1 % VEC] = f.y; val[j][2 % VEC] = f.z; val[j][3 % VEC] = f.w;
                 } else {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) val[j][v] = x[(size_t)id[j] * ldx + c + v];
+                    for (int v = 0; v < VEC; ++v) val[j][v] = D3fFeat<FT>::ld1(&x[(size_t)id[j] * ldx + c + v]);
                 }
             } else {
 #pragma unroll
@@ -104,18 +106,37 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
     }
     if (nvalid == 0 && c == 0) atomicOr(flag, 1u);   // this row is the shadow row: patched after the column minima exist
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) out[(size_t)n * ldo + c + v] = m[v];
+    for (int v = 0; v < VEC; ++v) D3fFeat<FT>::st1(&out[(size_t)n * ldo + c + v], m[v]);   // (a maximum of bf16 values is a bf16 value)
 }
 
-extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
-                                float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev,
-                                const int* row_order, void* stream_) {
+extern "C" int d3f_ind_max_pool(const void* x_, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
+                                void* out_, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev,
+                                const int* row_order, int feat_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const float* x = (const float*)x_;
+    float* out = (float*)out_;
     if (N1 < 0 || N2 < 0 || C < 1 || ldx < C || ldo < C || K < 0 || ld_idx < K) return D3F_ERR_ARG;
     if (N2 == 0) return D3F_OK;
     if (!x || !idx || !out || !col_min_dev) return D3F_ERR_ARG;
     unsigned* cm = (unsigned*)col_min_dev;
     colmin_init_kernel<<<d3f_cdiv(C + 1, 256), 256, 0, stream>>>(cm, C);
+    if (feat_bf16) {
+        if (C % 4 || ldx % 4 || ((uintptr_t)x_ & 7)) return D3F_ERR_ARG;
+        const unsigned short* xh = (const unsigned short*)x_;
+        unsigned short* oh = (unsigned short*)out_;
+        maxpool_kernel<4, unsigned short><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(xh, N1, ldx, C, idx, N2, ld_idx, K,
+                                                                                                     cm + C, oh, ldo, N1_dev, N2_dev, row_order);
+        if (N1 > 0) {
+            int rows = d3f_cdiv(N1, 32);
+            if (rows > 256) rows = 256;
+            colmin_kernel<unsigned short><<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(xh, N1, N1_dev, ldx, C, cm);
+        }
+        int pbh = d3f_cdiv(N2, 4);
+        if (pbh > 256) pbh = 256;
+        maxpool_patch_kernel<unsigned short><<<pbh, 256, 0, stream>>>(cm, C, N1, idx, N2, ld_idx, K, oh, ldo, N1_dev, N2_dev);
+        D3F_LAUNCH_CHECK();
+        return D3F_OK;
+    }
     if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
         maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
                                                                                       cm + C, out, ldo, N1_dev, N2_dev,
@@ -126,11 +147,11 @@ extern "C" int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const in
     if (N1 > 0) {
         int rows = d3f_cdiv(N1, 32);
         if (rows > 256) rows = 256;
-        colmin_kernel<<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, N1_dev, ldx, C, cm);
+        colmin_kernel<float><<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, N1_dev, ldx, C, cm);
     }
     int pb = d3f_cdiv(N2, 4);
     if (pb > 256) pb = 256;
-    maxpool_patch_kernel<<<pb, 256, 0, stream>>>(cm, C, N1, idx, N2, ld_idx, K, out, ldo, N1_dev, N2_dev);
+    maxpool_patch_kernel<float><<<pb, 256, 0, stream>>>(cm, C, N1, idx, N2, ld_idx, K, out, ldo, N1_dev, N2_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

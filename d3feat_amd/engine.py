@@ -52,7 +52,7 @@ class _Slot:
 class FragmentEngine:
     def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
                  device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None, two_clouds=False, batch=1,
-                 bf16=False):
+                 bf16=False, bf16_features=False):
         """raw_cap / n0_cap: raw points / voxels per FRAGMENT that a slot can take (a fragment beyond them is recomputed by
         the eager path).
         batch: fragments per graph replay.  The per-fragment cost of this path is dominated by the ~270 dependent launches
@@ -67,7 +67,9 @@ class FragmentEngine:
         two_clouds=True: every fragment is a pair of DIFFERENT clouds (the KITTI test generator, datasets/KITTI.py:94-106):
         submit(slot, (raw_a, raw_b)); raw_cap / n0_cap then bound the SUM over the two clouds.
         bf16=True: every unary / unfused KPConv contraction runs with bf16 operands and fp32 accumulation (ops.bf16_contraction;
-        BASELINE configs[4]) -- NOT the parity path: results differ from fp32 by the operand rounding."""
+        BASELINE configs[4]) -- NOT the parity path: results differ from fp32 by the operand rounding.
+        bf16_features=True (implies bf16): the activations between the layers are additionally STORED as bfloat16 -- "bf16
+        features with MFMA contraction"; arithmetic inside every kernel stays fp32."""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.device = config, device
@@ -76,7 +78,8 @@ class FragmentEngine:
         self.mirror = bool(mirror_self_pair)
         self.two = bool(two_clouds)
         self.F = int(batch)
-        self.bf16 = bool(bf16)
+        self.bf16 = bool(bf16) or bool(bf16_features)
+        self.bf16_features = bool(bf16_features)
         if self.two and self.mirror:
             raise ValueError("mirror_self_pair and two_clouds exclude each other")
         if self.F < 1 or 2 * self.F * (2 if self.two else 1) > _lib.MAX_BATCH:
@@ -117,7 +120,7 @@ class FragmentEngine:
         else:
             pts, lens = ops.stack_self_pair(sub, sub_l)        # [c_1; c_1; c_2; c_2; ...]
         flat = sl.map(pts, None, None, None, lens, ("a", "a"), pts)
-        with ops.bf16_contraction(self.bf16):
+        with ops.bf16_contraction(self.bf16, features=self.bf16_features):
             desc, score = self.model.run(flat)
         # the pyramid itself stays readable after a replay (parity checks, calibration): static buffers of the graph
         sl.flat, sl.level_lengths = flat, sl.ds.level_lengths
@@ -289,7 +292,7 @@ class FragmentEngine:
             pts = torch.cat([sub, sub], 0)
             lens = ops.as_lens([n, n], self.device)
         flat = self._eager_map(pts, None, None, None, lens, ("a", "a"), pts)
-        with ops.bf16_contraction(self.bf16):
+        with ops.bf16_contraction(self.bf16, features=self.bf16_features):
             desc, score = self.model.run(flat)
         return pts, desc, score
 

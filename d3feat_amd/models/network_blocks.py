@@ -116,7 +116,8 @@ def _check_inference(training):
 def last_unary_block(layer_ind, inputs, features, radius, fdim, config, training):
     """:194-205: 1x1 convolution to 32 channels, no batch norm / activation."""
     w = weight_variable([int(features.shape[1]), 32])
-    return conv_ops.unary_convolution(features, w)
+    with ops.f32_output():      # descriptors and scores are computed from fp32 values whatever the feature storage
+        return conv_ops.unary_convolution(features, w)
 
 
 def unary_block(layer_ind, inputs, features, radius, fdim, config, training):

@@ -356,19 +356,58 @@ BF16_CONTRACTION = False
 _BF16_PACKED = {}
 
 
+BF16_FEATURES = False     # bf16 feature STORAGE (needs BF16_CONTRACTION): activations live in HBM as torch.bfloat16
+F32_OUTPUT = False        # inside bf16 feature storage: the next contractions write float32 (the descriptor head's input)
+
+
 class bf16_contraction:
-    def __init__(self, on=True):
-        self.on = bool(on)
+    """BASELINE configs[4].  on: every unary / unfused KPConv contraction multiplies bf16 operands (fp32 accumulate).
+    features=True additionally STORES the activations between the layers as bfloat16 (KPConv gathers, max pooling, the
+    decoder gather and every contraction then move half the bytes; arithmetic inside the kernels stays fp32)."""
+
+    def __init__(self, on=True, features=False):
+        self.on, self.features = bool(on), bool(on) and bool(features)
 
     def __enter__(self):
-        global BF16_CONTRACTION
+        global BF16_CONTRACTION, BF16_FEATURES
         self.prev, BF16_CONTRACTION = BF16_CONTRACTION, self.on
+        self.prevf, BF16_FEATURES = BF16_FEATURES, self.features
         return self
 
     def __exit__(self, *exc):
-        global BF16_CONTRACTION
-        BF16_CONTRACTION = self.prev
+        global BF16_CONTRACTION, BF16_FEATURES
+        BF16_CONTRACTION, BF16_FEATURES = self.prev, self.prevf
         return False
+
+
+class f32_output:
+    """Contractions inside this context write float32 even under bf16 feature storage (last_unary: descriptors / scores are
+    computed from fp32 values)."""
+
+    def __enter__(self):
+        global F32_OUTPUT
+        self.prev, F32_OUTPUT = F32_OUTPUT, True
+        return self
+
+    def __exit__(self, *exc):
+        global F32_OUTPUT
+        F32_OUTPUT = self.prev
+        return False
+
+
+def _feat(t, name, ndim=None):
+    """A feature tensor: float32, or bfloat16 under bf16 feature storage."""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16:
+        return _req(t, torch.bfloat16, name, ndim)
+    return _req(t, torch.float32, name, ndim)
+
+
+def _h(t):
+    return 1 if (t is not None and t.dtype == torch.bfloat16) else 0
+
+
+def _out_dtype():
+    return torch.bfloat16 if (BF16_FEATURES and not F32_OUTPUT) else torch.float32
 
 
 def packed_bf16_weights(W):
@@ -394,7 +433,7 @@ def _bf16_ok(*operands):
     for t, ld, cols in operands:
         if t is None:
             continue
-        if cols % 4 or ld % 4 or t.data_ptr() % 16:
+        if cols % 4 or ld % 4 or t.data_ptr() % (8 if t.dtype == torch.bfloat16 else 16):
             return False
     return True
 
@@ -403,7 +442,10 @@ def _gemm_bf16(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, M, N, row_sca
                alpha, m_dev, n1_dev, hint, dev):
     lib = _lib.load()
     Wp = packed_bf16_weights(W)
-    ws = workspace(lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint), dev)
+    # (the bf16 launcher plans its K split for a 64-column tile even when N <= 32: ask for the same plan's slab)
+    ws = workspace(lib.d3f_gemm_workspace_bytes(M, max(N, 64), C1 + C2, hint), dev)
+    if out.data_ptr() % 16 or (residual is not None and (residual.data_ptr() % 8 or ldr % 4)):
+        raise ValueError("gemm (bf16): output / residual must be 16 / 8-byte aligned with a leading dimension of 4 k")
     with _timed("gemm_bf16", dict(M=M, N=N, K=C1 + C2), dev):
         rc = lib.d3f_gemm_bf16(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
                                skip.data_ptr() if skip is not None else None, lds, C2, Wp.data_ptr(), out.data_ptr(), N, M, N,
@@ -411,14 +453,14 @@ def _gemm_bf16(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, M, N, row_sca
                                col_scale.data_ptr() if col_scale is not None else None,
                                col_shift.data_ptr() if col_shift is not None else None,
                                residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0, float(alpha),
-                               ws.data_ptr(), ws.numel(), m_dev, n1_dev, hint, _stream(dev))
+                               ws.data_ptr(), ws.numel(), m_dev, n1_dev, hint, _h(A), _h(out), _stream(dev))
     _lib.check(rc, "gemm_bf16")
 
 
 def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, leaky=False, alpha=0.2, out=None):
     """out = act((A @ Bm) * row_scale[:,None] * col_scale + col_shift + residual) on the matrix cores."""
     lib = _lib.load()
-    A, lda = _rows(_req(A, torch.float32, "A"), "A")
+    A, lda = _rows(_feat(A, "A"), "A")
     Bm, ldb = _rows(_req(Bm, torch.float32, "B"), "B")
     M, K = A.shape
     if Bm.shape[0] != K:
@@ -426,11 +468,13 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
     N = Bm.shape[1]
     dev = A.device
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        out = torch.empty((M, N), dtype=_out_dtype() if BF16_CONTRACTION else torch.float32, device=dev)
     out, ldc = _rows(out, "out")
     ldr = 0
     if residual is not None:
-        residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
+        residual, ldr = _rows(_feat(residual, "residual"), "residual")
+    if (_h(A) or _h(out) or _h(residual)) and not (BF16_CONTRACTION and (residual is None or _h(residual) == _h(A))):
+        raise TypeError("gemm: bfloat16 feature tensors need ops.bf16_contraction(features=True)")
     for v, n, name in ((row_scale, M, "row_scale"), (col_scale, N, "col_scale"), (col_shift, N, "col_shift")):
         if v is not None:
             _req(v, torch.float32, name)
@@ -441,6 +485,8 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
         _gemm_bf16(A, M, lda, K, None, 0, None, 0, 0, Bm, out, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky, alpha,
                    _nd(A), None, hint, dev)
         return _tag(out, A)
+    if _h(A) or _h(out):
+        raise TypeError("gemm: bfloat16 operands that the bf16 contraction cannot address (K %d, lda %d)" % (K, lda))
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, K, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=K), dev):
@@ -472,25 +518,27 @@ class UpsampleCat:
 def gemm_upsample_cat(u, W, col_scale=None, col_shift=None, leaky=False, alpha=0.2):
     """out = act(([ x'[inds[:,0]] | skip ] @ W) * col_scale + col_shift) without building the concatenation."""
     lib = _lib.load()
-    x, ldx = _rows(_req(u.x, torch.float32, "x"), "x")
+    x, ldx = _rows(_feat(u.x, "x"), "x")
     inds, ldi = _rows(_req(u.inds, torch.int32, "inds"), "inds")
     W, ldb = _rows(_req(W, torch.float32, "W"), "W")
     C1, C2, lds, skip = x.shape[1], 0, 0, None
     if u.skip is not None:
-        skip, lds = _rows(_req(u.skip, torch.float32, "skip"), "skip")
+        skip, lds = _rows(_feat(u.skip, "skip"), "skip")
         C2 = skip.shape[1]
     M, N = inds.shape[0], W.shape[1]
     if W.shape[0] != C1 + C2:
         raise ValueError("gemm_upsample_cat: W has %d rows, operands %d + %d columns" % (W.shape[0], C1, C2))
-    if C2 and (C1 % 4 or lds % 4 or skip.data_ptr() % 16):
+    if C2 and (C1 % 4 or lds % 4 or skip.data_ptr() % 16) and not _h(x):
         return gemm(u.materialize(), W, col_scale=col_scale, col_shift=col_shift, leaky=leaky, alpha=alpha)
     dev = x.device
-    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    out = torch.empty((M, N), dtype=_out_dtype() if BF16_CONTRACTION else torch.float32, device=dev)
     hint = int(getattr(inds, "n_hint", 0) or 0)
     if BF16_CONTRACTION and W.is_contiguous() and _bf16_ok((x, ldx, C1), (skip, lds, C2)):
         _gemm_bf16(x, x.shape[0], ldx, C1, inds, ldi, skip, lds, C2, W, out, M, N, None, col_scale, col_shift, None, 0, leaky, alpha,
                    _nd(inds), _nd(x), hint, dev)
         return _tag(out, inds)
+    if _h(x) or _h(out):
+        raise TypeError("gemm_upsample_cat: bfloat16 operands that the bf16 contraction cannot address")
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
@@ -506,21 +554,23 @@ def gemm_upsample_cat(u, W, col_scale=None, col_shift=None, leaky=False, alpha=0
 def gemm_cat2(A1, A2, W, col_scale=None, col_shift=None, leaky=False, alpha=0.2):
     """out = act(([A1 | A2] @ W) * col_scale + col_shift) without building the concatenation (same rows in A1 and A2)."""
     lib = _lib.load()
-    A1, ld1 = _rows(_req(A1, torch.float32, "A1"), "A1")
-    A2, ld2 = _rows(_req(A2, torch.float32, "A2"), "A2")
+    A1, ld1 = _rows(_feat(A1, "A1"), "A1")
+    A2, ld2 = _rows(_feat(A2, "A2"), "A2")
     W, ldb = _rows(_req(W, torch.float32, "W"), "W")
     M, C1, C2, N = A1.shape[0], A1.shape[1], A2.shape[1], W.shape[1]
     if A2.shape[0] != M or W.shape[0] != C1 + C2:
         raise ValueError("gemm_cat2: operands %s | %s, W %s" % (tuple(A1.shape), tuple(A2.shape), tuple(W.shape)))
-    if C1 % 4 or ld2 % 4 or A2.data_ptr() % 16:
+    if (C1 % 4 or ld2 % 4 or A2.data_ptr() % 16) and not _h(A1):
         return gemm(torch.cat([A1, A2], 1), W, col_scale=col_scale, col_shift=col_shift, leaky=leaky, alpha=alpha)
     dev = A1.device
-    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    out = torch.empty((M, N), dtype=_out_dtype() if BF16_CONTRACTION else torch.float32, device=dev)
     hint = int(getattr(A1, "n_hint", 0) or 0)
     if BF16_CONTRACTION and W.is_contiguous() and _bf16_ok((A1, ld1, C1), (A2, ld2, C2)):
         _gemm_bf16(A1, M, ld1, C1, None, 0, A2, ld2, C2, W, out, M, N, None, col_scale, col_shift, None, 0, leaky, alpha,
                    _nd(A1), _nd(A1), hint, dev)
         return _tag(out, A1)
+    if _h(A1) or _h(A2) or _h(out):
+        raise TypeError("gemm_cat2: bfloat16 operands that the bf16 contraction cannot address")
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
@@ -540,7 +590,7 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
     q = _req(query_points, torch.float32, "query_points", 2).contiguous()
     s = _req(support_points, torch.float32, "support_points", 2).contiguous()
     idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
-    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    f, ldf = _rows(_feat(features, "features"), "features")
     if KP_influence not in _INFLUENCE:
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation_mode not in _AGGREGATION:
@@ -559,12 +609,12 @@ def kpconv_aggregate(query_points, support_points, neighbors_indices, features, 
     nq_dev, ns_dev = _nd(query_points), _nd(support_points)
     if ns_dev is None:
         ns_dev = _nd(features)
-    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, Cin, row_pos.data_ptr(), ns_dev, st), "row_positive")
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, Cin, row_pos.data_ptr(), ns_dev, _h(f), st), "row_positive")
     with _timed("kpconv_aggregate", dict(Nq=Nq, Ns=Ns, K=K, Cin=Cin), dev):
         rc = lib.d3f_kpconv_aggregate(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
                                       Cin, row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent),
                                       _INFLUENCE[KP_influence], _AGGREGATION[aggregation_mode], wf.data_ptr(),
-                                      inv_cnt.data_ptr(), nq_dev, ns_dev, _order(query_points), st)
+                                      inv_cnt.data_ptr(), nq_dev, ns_dev, _order(query_points), _h(f), st)
     _lib.check(rc, "kpconv_aggregate")
     return _tag(wf, query_points), _tag(inv_cnt, query_points)
 
@@ -577,7 +627,7 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     q = _req(query_points, torch.float32, "query_points", 2).contiguous()
     s = _req(support_points, torch.float32, "support_points", 2).contiguous()
     idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
-    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    f, ldf = _rows(_feat(features, "features"), "features")
     kp = _kp_host(K_points)
     num_kp, cin, cout = K_values.shape
     if cin != 32 or cout != 32 or f.shape[1] != 32:
@@ -585,7 +635,7 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
     Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
     dev = q.device
-    out = torch.empty((Nq, cout), dtype=torch.float32, device=dev)
+    out = torch.empty((Nq, cout), dtype=f.dtype, device=dev)
     row_pos = torch.empty((max(Ns, 1),), dtype=torch.uint8, device=dev)
     ldr = 0
     if residual is not None:
@@ -594,7 +644,7 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     nq_dev, ns_dev = _nd(query_points), _nd(support_points)
     if ns_dev is None:
         ns_dev = _nd(features)
-    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, 32, row_pos.data_ptr(), ns_dev, st), "row_positive")
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, 32, row_pos.data_ptr(), ns_dev, _h(f), st), "row_positive")
     with _timed("kpconv_fused32", dict(Nq=Nq, Ns=Ns, K=K, Cin=32, Cout=32), dev):
         rc = lib.d3f_kpconv_fused32(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
                                     row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
@@ -602,7 +652,7 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
                                     col_scale.data_ptr() if col_scale is not None else None,
                                     col_shift.data_ptr() if col_shift is not None else None,
                                     residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
-                                    float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), st)
+                                    float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), _h(f), st)
     _lib.check(rc, "kpconv_fused32")
     return _tag(out, query_points)
 
@@ -636,7 +686,7 @@ def kpconv_fused(query_points, support_points, neighbors_indices, features, K_po
     q = _req(query_points, torch.float32, "query_points", 2).contiguous()
     s = _req(support_points, torch.float32, "support_points", 2).contiguous()
     idx, ld_idx = _rows(_req(neighbors_indices, torch.int32, "neighbors_indices"), "neighbors_indices")
-    f, ldf = _rows(_req(features, torch.float32, "features"), "features")
+    f, ldf = _rows(_feat(features, "features"), "features")
     kp = _kp_host(K_points)
     num_kp, cin, cout = K_values.shape
     if f.shape[1] != cin:
@@ -644,7 +694,7 @@ def kpconv_fused(query_points, support_points, neighbors_indices, features, K_po
     Wp = packed_kpconv_weights(K_values)
     Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
     dev = q.device
-    out = torch.empty((Nq, cout), dtype=torch.float32, device=dev)
+    out = torch.empty((Nq, cout), dtype=f.dtype, device=dev)
     row_pos = torch.empty((max(Ns, 1),), dtype=torch.uint8, device=dev)
     ldr = 0
     if residual is not None:
@@ -653,7 +703,7 @@ def kpconv_fused(query_points, support_points, neighbors_indices, features, K_po
     nq_dev, ns_dev = _nd(query_points), _nd(support_points)
     if ns_dev is None:
         ns_dev = _nd(features)
-    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, cin, row_pos.data_ptr(), ns_dev, st), "row_positive")
+    _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, cin, row_pos.data_ptr(), ns_dev, _h(f), st), "row_positive")
     with _timed("kpconv_fused", dict(Nq=Nq, Ns=Ns, K=K, Cin=cin, Cout=cout), dev):
         rc = lib.d3f_kpconv_fused(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf, cin,
                                   row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
@@ -661,7 +711,7 @@ def kpconv_fused(query_points, support_points, neighbors_indices, features, K_po
                                   col_scale.data_ptr() if col_scale is not None else None,
                                   col_shift.data_ptr() if col_shift is not None else None,
                                   residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
-                                  float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), st)
+                                  float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), _h(f), st)
     _lib.check(rc, "kpconv_fused")
     return _tag(out, query_points)
 
@@ -682,7 +732,7 @@ def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K
     W = _req(K_values, torch.float32, "K_values").reshape(num_kp, cout).contiguous()
     Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
     dev = q.device
-    out = torch.empty((Nq, cout), dtype=torch.float32, device=dev)
+    out = torch.empty((Nq, cout), dtype=torch.bfloat16 if BF16_FEATURES else torch.float32, device=dev)
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(_req(residual, torch.float32, "residual"), "residual")
@@ -694,22 +744,22 @@ def kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K
                                      col_shift.data_ptr() if col_shift is not None else None,
                                      residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
                                      float(alpha), out.data_ptr(), cout, _nd(query_points), _nd(support_points),
-                                     _order(query_points), _stream(dev))
+                                     _order(query_points), _h(out), _stream(dev))
     _lib.check(rc, "kpconv_fused_c1")
     return _tag(out, query_points)
 
 
 def ind_max_pool(x, inds):
     lib = _lib.load()
-    x, ldx = _rows(_req(x, torch.float32, "x"), "x")
+    x, ldx = _rows(_feat(x, "x"), "x")
     inds, ldi = _rows(_req(inds, torch.int32, "inds"), "inds")
     dev = x.device
-    out = torch.empty((inds.shape[0], x.shape[1]), dtype=torch.float32, device=dev)
+    out = torch.empty((inds.shape[0], x.shape[1]), dtype=x.dtype, device=dev)
     colmin = torch.empty((x.shape[1] + 4,), dtype=torch.float32, device=dev)    # column minima (lazy) + flag word
     with _timed("ind_max_pool", dict(N1=x.shape[0], N2=inds.shape[0], K=inds.shape[1], C=x.shape[1]), dev):
         rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
                                   inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _order(inds),
-                                  _stream(dev))
+                                  _h(x), _stream(dev))
     _lib.check(rc, "ind_max_pool")
     return _tag(out, inds)
 

@@ -172,11 +172,16 @@ int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const 
  * ------------------------------------------------------------------------------------------- */
 /* row_pos[s] = (sum_c f[s,c] > 0): the per-support test behind the neighbour count (:250-251), evaluated once
  * per support row.  row_pos u8[Ns]. */
-int d3f_row_positive(const float* f, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev, void* stream);
+/* feat_bf16 (here and in the KPConv / pooling / contraction entry points below): 0 = feature tensors are f32 (the parity path);
+ * 1 = BASELINE configs[4] "bf16 features": every feature tensor named f / x / out / residual holds bfloat16 values (2 bytes per
+ * element, leading dimensions in elements, 8-byte aligned rows); all arithmetic stays fp32, values are rounded to nearest even
+ * when stored.  Only the shipped configuration (linear influence, 'sum', <= 15 kernel points) has the bf16 forms. */
+int d3f_row_positive(const void* f, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev, int feat_bf16,
+                     void* stream);
 int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                         const float* f, int ldf, int Cin, const unsigned char* row_pos, const float* kp_host,
+                         const void* f, int ldf, int Cin, const unsigned char* row_pos, const float* kp_host,
                          int num_kp, float KP_extent, int influence, int aggregation, float* wf, float* inv_cnt,
-                         const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
+                         const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16, void* stream);
 
 /* Whole KPConv_ops (kernels/convolution_ops.py:161-255) + the fused inference epilogue for Cin = 1 -- the input
  * layer of every shipped model (`simple` block on the all-ones features, models/network_blocks.py:222-244):
@@ -185,8 +190,8 @@ int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int Ns, const i
 int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                         const float* f, int ldf, const float* kp_host, int num_kp, float KP_extent, int influence,
                         int aggregation, const float* W, int Cout, const float* col_scale, const float* col_shift,
-                        const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
-                        const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
+                        const float* residual, int ldr, int leaky, float alpha, void* out, int ldo,
+                        const int* Nq_dev, const int* Ns_dev, const int* q_order, int out_bf16, void* stream);
 
 /* Whole KPConv_ops + inference epilogue for Cin = Cout = 32 (the level-0 convolutions of the shipped architecture) in one
  * launch: gather + influences + aggregation as d3f_kpconv_aggregate, then the 32 x (num_kp*32) tile of weighted features is
@@ -194,10 +199,10 @@ int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int Ns, const in
  *   W f32[num_kp*32, 32] (= K_values reshaped, contiguous);  out f32[Nq, 32] (ldo);  row_pos from d3f_row_positive(f)
  *   out = act( (wf @ W) / max(count, 1) * col_scale + col_shift + residual ) */
 int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                       const float* f, int ldf, const unsigned char* row_pos, const float* kp_host, int num_kp,
+                       const void* f, int ldf, const unsigned char* row_pos, const float* kp_host, int num_kp,
                        float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
-                       const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out, int ldo,
-                       const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
+                       const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* out, int ldo,
+                       const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16, void* stream);
 
 /* Whole KPConv_ops + epilogue in one kernel for Cin == Cout in {64, 128} (levels 1 and 2 of the shipped architecture), the
  * [Nq, 15*Cin] weighted-feature tensor of kernels/convolution_ops.py:237-240 staying in LDS (tiles of 16 queries, passes of
@@ -209,11 +214,11 @@ int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int
 int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int influence, int aggregation);
 int d3f_kpconv_pack_weights(const float* W, int K, int N, float* W_packed, void* stream);
 int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                     const float* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                     const void* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
                      float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,
                      const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
-                     float alpha, float* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
-                     void* stream);
+                     float alpha, void* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                     int feat_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, fmaf-chain numerics).
@@ -255,9 +260,9 @@ int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1, const int
  *   col_min_dev: 4-byte words [C + 4], scratch of d3f_ind_max_pool (column minima, computed only when a row has no valid
  *   neighbour and therefore takes the shadow row, and the flag saying so).
  * ------------------------------------------------------------------------------------------- */
-int d3f_ind_max_pool(const float* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
-                     float* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev, const int* row_order,
-                     void* stream);
+int d3f_ind_max_pool(const void* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
+                     void* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev, const int* row_order,
+                     int feat_bf16, void* stream);
 int d3f_closest_pool_cat(const float* x, int N1, int ldx, int C1, const int* idx, int N2, int ld_idx,
                          const float* skip, int lds, int C2, float* out, int ldo, const int* N1_dev, const int* N2_dev,
                          void* stream);
@@ -302,10 +307,12 @@ int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, co
  * W_packed: d3f_gemm_pack_bf16(W f32[K,N]) -> bf16 [N][Kp], Kp = K rounded up to 32 (2 * N * Kp bytes).
  * C1, C2, lda, lds multiples of 4, 16-byte aligned bases.  workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint). */
 int d3f_gemm_pack_bf16(const float* W, int ldb, int K, int N, void* W_packed, void* stream);
-int d3f_gemm_bf16(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
-                  const void* W_packed, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
-                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
-                  size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream);
+/* a_bf16: A, skip and residual hold bfloat16 values (bf16 feature storage, see d3f_row_positive); c_bf16: C is written as bfloat16.
+ * Both 0: the operands are f32 in HBM and only rounded on their way into the multiply (the round-2 form of configs[4]). */
+int d3f_gemm_bf16(const void* A, int N1, int lda, int C1, const int* idx, int ld_idx, const void* skip, int lds, int C2,
+                  const void* W_packed, void* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
+                  const float* col_shift, const void* residual, int ldr, int leaky, float alpha, void* workspace,
+                  size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, int a_bf16, int c_bf16, void* stream);
 
 /* Stage-0 ingestion: float32 xyz [n,3] out of raw file records already on the device -- a binary PLY
  * vertex element (demo_registration.py:23, datasets/ThreeDMatch.py:348; float or double coordinates at byte offsets

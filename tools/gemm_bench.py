@@ -31,7 +31,17 @@ if EXTRA:
     SHAPES = EXTRA
 
 
+BF16 = os.environ.get("D3F_GEMM_BENCH_BF16", "0") == "1"     # the bf16-operand contraction (configs[4]) instead of fp32
+
+
 def time_one(A, B, reps=20):
+    if BF16:
+        with ops.bf16_contraction():
+            return _time_one(A, B, reps)
+    return _time_one(A, B, reps)
+
+
+def _time_one(A, B, reps=20):
     reps = REPS or reps
     for _ in range(1 if REPS else 3):
         ops.gemm(A, B, leaky=True)
