@@ -643,7 +643,10 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                        and k.startswith("kpconv_fused_kernel<%d," % (int(m.group(1)) // 4))]
             nl = sum(e["launches"] for e in ent)
             if nl:
-                r["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl)
+                # the counter run's launches held F_pmc fragments each, this pass's hold Fp: traffic scales with the rows
+                f_pmc = int(traffic.get("__fragments_per_launch__", Fp) or Fp)
+                r["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl * Fp / f_pmc)
+                r["traffic_fragments_per_launch_of_counter_run"] = f_pmc
                 r["traffic_source"] = traffic_src
                 r["traffic_stale"] = traffic_stale
         return r

@@ -124,7 +124,7 @@ def test_row_positive_sign_is_order_independent(device):
     lib = _lib.load()
     ft = torch.from_numpy(f).to(device)
     pos = torch.empty((len(f),), dtype=torch.uint8, device=device)
-    _lib.check(lib.d3f_row_positive(ft.data_ptr(), len(f), C, C, pos.data_ptr(), None, ops._stream(device)), "row_positive")
+    _lib.check(lib.d3f_row_positive(ft.data_ptr(), len(f), C, C, pos.data_ptr(), None, 0, ops._stream(device)), "row_positive")
     assert np.array_equal(pos.cpu().numpy().astype(bool), exact)
 
 

@@ -33,12 +33,12 @@ benchlean)
   timeout 600 python bench.py $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err; cut -c1-160 $OUT/bench_lean.json;;
 prof)
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps 64 --warmup 8 $LEAN > $OUT/prof_bench.json 2> $OUT/prof.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $REPO/bench.py --steps ${PROF_STEPS:-64} --warmup 8 ${PROF_FLAGS:-} $LEAN > $OUT/prof_bench.json 2> $OUT/prof.err
   cd $REPO
   DB=$(ls $OUT/prof/*/*_results.db 2>/dev/null | head -1)
   if [ -n "$DB" ]; then
     python tools/rocpd_summary.py $DB > $OUT/kernel_stats.csv
-    python tools/rocpd_summary.py --timed-region --fragments 64 $DB > $OUT/kernel_stats_timed_region.csv
+    python tools/rocpd_summary.py --timed-region --fragments ${PROF_STEPS:-64} $DB > $OUT/kernel_stats_timed_region.csv
     head -32 $OUT/kernel_stats_timed_region.csv | cut -c1-150
     python tools/timeline_summary.py $DB > $OUT/timeline.json 2>/dev/null
   fi
@@ -57,8 +57,8 @@ prof1)   # ONE replay in flight: kernel durations without the other streams' ker
   rm -rf $OUT/prof1/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
 pmc)
   cd /tmp
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_fetch.err
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 16 --warmup 1 $LEAN > /dev/null 2> $OUT/pmc_write.err
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN > /dev/null 2> $OUT/pmc_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN > /dev/null 2> $OUT/pmc_write.err
   cd $REPO
   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json 2> $OUT/pmc_summary.err
   head -c 600 $OUT/hbm_traffic.json

@@ -52,6 +52,9 @@ def main(dirs):
         h.update(os.path.basename(fn).encode())
         h.update(open(fn, "rb").read())
     out["__source_hash__"] = h.hexdigest()[:16]
+    # fragments per replay of the counter run (tools/gpu_visit.sh pmc: --batch 4): per-launch traffic scales with it, bench.py
+    # rescales to the fragments per launch of its own instrumented pass
+    out["__fragments_per_launch__"] = int(os.environ.get("D3F_PMC_FRAGMENTS_PER_LAUNCH", "4"))
     json.dump(out, sys.stdout, indent=1)
     print()
 
