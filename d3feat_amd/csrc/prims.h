@@ -138,7 +138,8 @@ static inline int d3f_bbox_launch_t(const float* pts, const int* offs, int B, in
                                     hipStream_t stream) {
     // about one workgroup per CU over all elements: every workgroup ends with a ticket on ONE counter, and same-address
     // atomics serialise at ~12 ns each, so thousands of (mostly idle) workgroups cost more than the boxes themselves
-    int chunks = d3f_cdiv(N > 0 ? N : 1, 256 * 8);
+    // (N is the whole stack: an element holds about N / B points; eight points per thread)
+    int chunks = d3f_cdiv(d3f_cdiv(N > 0 ? N : 1, B), 256 * 8);
     const int per_elem = 512 / B > 1 ? 512 / B : 1;
     if (chunks > per_elem) chunks = per_elem;
     bbox_kernel<Epi><<<dim3(chunks, B), 256, 0, stream>>>(pts, offs, B, bbox, counter, epi);
