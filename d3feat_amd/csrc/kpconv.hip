@@ -739,14 +739,15 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 // Registers: 60 accumulators + the gather prefetch decide the occupancy.  512-thread workgroups (Cin = 128) are two waves
 // per SIMD each: at more than 128 registers only ONE workgroup fits a CU and its gather and matrix phases cannot overlap with
 // anybody's, so that variant prefetches four rows instead of eight and is held to 128 registers (two workgroups per CU).
-template <int LQ, int PF = (LQ == 32 ? 4 : 8), class FT = float>   // lanes per query = Cin / 4 (16 or 32); Cout == Cin; waves = LQ / 4 = Cout / 16
+template <int LQ, int PF = (LQ >= 32 ? 4 : 8), class FT = float>   // lanes per query = Cin / 4 (16, 32 or 64); Cout == Cin; waves = LQ / 4 = Cout / 16
 __global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)
 kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                     int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                     KpParams P, const float* __restrict__ Wp, KpEpi E, FT* __restrict__ out, int ldo,
                     const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
     constexpr int CIN = 4 * LQ, COUT = CIN;
-    constexpr int KC = LQ;                  // neighbours per chunk (one (query, neighbour) pair per thread)
+    constexpr int KC = LQ < 32 ? LQ : 32;   // neighbours per chunk (one (query, neighbour) pair per thread; Cin = 256: the first
+                                            // 32 of a query's 64 lanes -- a wider chunk would not fit the tile region)
     constexpr int WS = KC * 16 + 4;         // phase-A stride per query (floats)
     constexpr int HP = KG_KT / CIN;         // kernel points per contraction pass
     static_assert(KG_TQ * WS <= KG_TQ * KG_TS, "the influence region must fit the tile region");
@@ -776,7 +777,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
         {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
             const int k = k0 + cl;
             int id = Ns;
-            if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
+            if (cl < KC && qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
             bool positive = false;
             if (id >= 0 && id < Ns) {
@@ -788,8 +789,10 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
                 for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
             }
             kp_count_positive<LQ>(positive, ql, cl, lcnt);
-            lidx[ql * KC + cl] = id;
-            kp_store_w(&lw[ql * WS + cl * 16], cl, w);
+            if (cl < KC) {
+                lidx[ql * KC + cl] = id;
+                kp_store_w(&lw[ql * WS + cl * 16], cl, w);
+            }
         }
         __syncthreads();
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3); PF feature rows requested before any is consumed ----
@@ -919,8 +922,12 @@ extern "C" int d3f_kpconv_pack_weights(const float* W, int K, int N, float* Wp, 
 
 // the fused kernel exists for the configuration of the shipped models only (kp_influences_t<true>); anything else takes the
 // two-kernel form (d3f_kpconv_aggregate + d3f_gemm_f32)
+// 1: the one-kernel form exists AND is the faster choice; 2: it exists (d3f_kpconv_fused accepts the shape) but the two-kernel
+// form (aggregation + contraction) measured the same or better end to end -- Cin = 256: 1024-thread workgroups, 1471 / 1452 against
+// 1457 / 1472 fragments/s, 1325 against 1351 on the 20-fragment job (profiles/r03_experiments.txt x7); 0: not available.
 extern "C" int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int influence, int aggregation) {
-    return (Cin == Cout && (Cin == 64 || Cin == 128) && kp_fast_config(num_kp, influence, aggregation)) ? 1 : 0;
+    if (!(Cin == Cout && kp_fast_config(num_kp, influence, aggregation))) return 0;
+    return (Cin == 64 || Cin == 128) ? 1 : (Cin == 256 ? 2 : 0);
 }
 
 extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
@@ -959,10 +966,14 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
         if (Cin == 64)
             kpconv_fused_kernel<16, 8, unsigned short><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
+        else if (Cin == 256)
+            kpconv_fused_kernel<64, 4, unsigned short><<<blocks, KG_TQ * 64, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+                                                                                         W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
         else
             kpconv_fused_kernel<32, 4, unsigned short><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
     } else if (Cin == 64) { if (pf4) D3F_KG(16, 4); else D3F_KG(16, 8); }
+    else if (Cin == 256) D3F_KG(64, 4);
     else D3F_KG(32, 4);
 #undef D3F_KG
     D3F_LAUNCH_CHECK();

@@ -657,9 +657,12 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     return _tag(out, query_points)
 
 
-def kpconv_fused_supported(cin, cout, num_kp, KP_influence, aggregation_mode):
-    return bool(_lib.load().d3f_kpconv_fused_supported(int(cin), int(cout), int(num_kp), _INFLUENCE.get(KP_influence, -1),
-                                                       _AGGREGATION.get(aggregation_mode, -1)))
+def kpconv_fused_supported(cin, cout, num_kp, KP_influence, aggregation_mode, available=False):
+    """Should KPConv_ops use the one-kernel form for this shape?  available=True: does the form exist at all (Cin = 256 exists
+    but measured no faster than aggregation + contraction: see d3f_kpconv_fused_supported)."""
+    r = _lib.load().d3f_kpconv_fused_supported(int(cin), int(cout), int(num_kp), _INFLUENCE.get(KP_influence, -1),
+                                               _AGGREGATION.get(aggregation_mode, -1))
+    return r >= 1 if available else r == 1
 
 
 def packed_kpconv_weights(K_values):

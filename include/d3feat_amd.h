@@ -204,10 +204,11 @@ int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int
                        const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* out, int ldo,
                        const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16, void* stream);
 
-/* Whole KPConv_ops + epilogue in one kernel for Cin == Cout in {64, 128} (levels 1 and 2 of the shipped architecture), the
+/* Whole KPConv_ops + epilogue in one kernel for Cin == Cout in {64, 128, 256} (levels 1 to 3 of the shipped architecture), the
  * [Nq, 15*Cin] weighted-feature tensor of kernels/convolution_ops.py:237-240 staying in LDS (tiles of 16 queries, passes of
  * 512 k-values, v_mfma_f32_16x16x4_f32).  Only the configuration of the shipped models (linear influence, 'sum'
- * aggregation, 15 kernel points): d3f_kpconv_fused_supported() says whether a call qualifies; otherwise use
+ * aggregation, 15 kernel points): d3f_kpconv_fused_supported() says whether a call qualifies (1: use it; 2: the form
+ * exists -- Cin = 256 -- but aggregation + contraction measured no slower; 0: not available); otherwise use
  * d3f_kpconv_aggregate + d3f_gemm_f32.  W_packed: K_values [15*Cin, Cout] reordered once by d3f_kpconv_pack_weights
  * (Wp[blk][g][n][j] = W[16*blk + 4*g + j][n]: the MFMA B-operand order, one 16-byte load per lane and k-block).
  * Arguments otherwise as d3f_kpconv_fused32. */

@@ -323,3 +323,27 @@ def test_gemm_upsample_cat_equals_materialised(device, C1, C2, N):
     ref = ref * cs.cpu().numpy() + ch.cpu().numpy()
     ref = np.where(ref > 0, ref, 0.2 * ref)
     _close(got.cpu().numpy(), ref, 2e-5, relative=True)
+
+
+def test_kpconv_fused_256_equals_the_two_kernel_form(device):
+    """The one-kernel KPConv exists for Cin = Cout = 256 too (1024-thread workgroups); KPConv_ops does not choose it (it measured
+    no faster than aggregation + contraction), so it is exercised directly: same result as the two-kernel form to fp32 summation
+    order, on real neighbour lists."""
+    from d3feat_amd import ops
+    from conftest import surface_cloud
+    rng = np.random.default_rng(256)
+    s0 = surface_cloud(256, n_raw=12000)
+    pts = torch.from_numpy(s0).to(device)
+    lens = [len(s0)]
+    nb = ops.batch_radius_neighbors(pts, pts, lens, lens, 0.075, 40)[0]
+    f = torch.from_numpy(rng.standard_normal((len(s0), 256)).astype(np.float32)).to(device)
+    W = torch.from_numpy((rng.standard_normal((15, 256, 256)) / 60).astype(np.float32)).to(device)
+    kp = (rng.standard_normal((15, 3)) * 0.02).astype(np.float32)
+    kp[0] = 0
+    assert ops.kpconv_fused_supported(256, 256, 15, "linear", "sum", available=True)
+    assert not ops.kpconv_fused_supported(256, 256, 15, "linear", "sum")
+    got = ops.kpconv_fused(pts, pts, nb, f, kp, W, 0.03, leaky=True)
+    wf, inv = ops.kpconv_aggregate(pts, pts, nb, f, kp, 0.03)
+    want = ops.gemm(wf, W.reshape(15 * 256, 256), row_scale=inv, leaky=True)
+    torch.cuda.synchronize()
+    assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
