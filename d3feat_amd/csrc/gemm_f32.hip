@@ -8,12 +8,13 @@
 //
 // v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, 64 cycles per SIMD, exact fp32 products and sums) -- the 1e-4 parity bar
 // is an fp32 bar, so the contraction stays in fp32 on the MFMA pipe (157 TF peak).
-// Three kernels, one launcher (gemm_run):
+// Two kernels, one launcher (gemm_run):
 //   gemm_fast_kernel    the production tile kernel for float4-addressable operands (every shape of the network): 256-thread
 //                       workgroup = 4 wavefronts x (TM x TN) 32x32 accumulator tiles, BK = 32, double-buffered LDS, k-permuted
 //                       fragments read with ds_read_b128, transposed accumulators -> 16-byte stores, straight-line staging;
-//                       workgroup tile 64x64 (default), 128x32 (Cout <= 32), 128x64 / 128x128 (large problems, D3F_GEMM_FORCE);
-//   gemm_stream_kernel  opt-in (D3F_GEMM_STREAM) for many rows x shallow K: B slab resident in LDS, A global -> registers;
+//                       workgroup tile 64x64 (default) or 128x32 (Cout <= 32).  Measured and removed again: 128x64 / 128x128 register
+//                       tiles (slower on every shape of the network: tails), a streaming form for many rows x shallow K (B slab
+//                       resident in LDS, A global -> registers: equal end to end), a second prefetch register set (round 3);
 //   gemm_f32_kernel     generic fallback (odd K / N / leading dimensions, unaligned bases): scalar tail handling.
 // Skinny problems (few output tiles, long K: the deep KPConv layers) are split along K into slabs that a second kernel
 // reduces in a fixed order (deterministic).
@@ -452,180 +453,6 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Streaming variant for the wide, shallow layers (many rows, K <= 256: the unary / shortcut / decoder contractions of the
-// two finest levels, which are bound by the HBM traffic of A and C, not by the multiply).
-//  * the B column slab [K x 32*NT] is staged ONCE per workgroup, transposed ([n][k], row stride K + 4), and stays in LDS;
-//  * every wavefront then walks 32-row groups on its own -- no barrier after the prologue.  A goes global -> registers
-//    directly: the MFMA A fragment is one value per lane and k-step and the contraction may visit k in any order, so lane
-//    (row r, half h) loads the float4 pairs A[r][16j + 8h .. +7] and feeds element t to k-step (j, t), where the B fragment
-//    (two ds_read_b128 per eight k-steps) reads the same k from its transposed row;
-//  * rows are clamped instead of predicated (a row past M only feeds output rows that are never stored), so the loads are
-//    straight-line code; the next 64-column chunk (of this or the next row group) is in flight while the current one is
-//    multiplied, and the B fragments of the next 16 columns are fetched before the current MFMAs issue.
-// Against the tile kernel: B is read once per ~14 row groups instead of once per 2, A never passes through LDS, and the
-// real row count only enters through the loop bound, so a capacity-sized launch costs nothing.
-// ------------------------------------------------------------------------------------------------
-#define GS_KC 64                       // k columns per register chunk (8 float4 per lane)
-
-template <int NT, bool GATHER>
-__global__ void __launch_bounds__(256)
-gemm_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                   int M, int N, int K, GemmEpi E, const int* __restrict__ M_dev, GemmGather G) {
-    constexpr int NTILE = 32 * NT;
-    extern __shared__ __attribute__((aligned(16))) float gs_bt[];     // [NTILE][SK], then col_scale | col_shift [2][NTILE]
-    const int SK = K + 4;
-    float* lcs = gs_bt + NTILE * SK;
-    M = d3f_dyn(M, M_dev);
-    const int groups = (M + 31) >> 5;
-    if ((int)(blockIdx.x * 4) >= groups) return;    // whole workgroup idle (capacity-sized grid)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * NTILE;
-    {   // 16-row units of (k, float4 column): a 32-lane store group covers 16 consecutive k of two neighbouring float4
-        // columns, which land on 32 different banks (SK = 4 mod 32 for K a multiple of 32)
-        const int units = (K >> 4) * (NTILE / 4);
-        for (int u = tid >> 4; u < units; u += 16) {
-            const int k = 16 * (u / (NTILE / 4)) + (tid & 15), n4 = (u % (NTILE / 4)) << 2;
-            const float4 v = *(const float4*)&B[(size_t)k * ldb + n0 + n4];
-            float* d = &gs_bt[n4 * SK + k];
-            d[0] = v.x; d[SK] = v.y; d[2 * SK] = v.z; d[3 * SK] = v.w;
-        }
-    }
-    if (tid < NTILE) {
-        lcs[tid] = E.col_scale ? E.col_scale[n0 + tid] : 1.f;
-        lcs[NTILE + tid] = E.col_shift ? E.col_shift[n0 + tid] : 0.f;
-    }
-    __syncthreads();
-    int g = blockIdx.x * 4 + wave;
-    if (g >= groups) return;
-    const int gstride = gridDim.x * 4;
-    const int n1 = d3f_dyn(G.N1, G.N1_dev);
-    const int nchunk = (K + GS_KC - 1) / GS_KC;
-    const int kend1 = G.A2 ? G.K1 : K;              // columns [0, kend1) from A, the rest from the second operand
-
-    // source rows of tile row r of a group: clamped into range (rows >= M are never stored); a shadow gather index reads
-    // as a zero row
-    auto sources = [&](int grp, const float*& pa, const float*& pa2, bool& zero) {
-        int gm = grp * 32 + r;
-        gm = gm < M ? gm : M - 1;
-        int sr = gm;
-        zero = false;
-        if (GATHER) {
-            sr = G.gidx[(size_t)gm * G.ld_gidx];
-            zero = sr < 0 || sr >= n1;
-            sr = zero ? 0 : sr;
-        }
-        pa = A + (size_t)sr * lda + 8 * h;
-        pa2 = G.A2 ? G.A2 + (size_t)gm * G.lda2 + 8 * h - kend1 : pa;
-    };
-    // straight-line: a column block past K is clamped back into the row (loaded, never multiplied), so that no branch --
-    // and with it no conservative s_waitcnt -- separates these loads from the multiply they overlap with
-    auto load_chunk = [&](float4 (&dst)[8], int c, const float* pa, const float* pa2, bool zero) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = min(c * GS_KC + 16 * j, K - 16);      // wave-uniform
-            const bool second = k >= kend1;
-            const float* p = (second ? pa2 : pa) + k;
-            float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
-            if (GATHER) {
-                const bool z = zero && !second;
-                v0.x = z ? 0.f : v0.x; v0.y = z ? 0.f : v0.y; v0.z = z ? 0.f : v0.z; v0.w = z ? 0.f : v0.w;
-                v1.x = z ? 0.f : v1.x; v1.y = z ? 0.f : v1.y; v1.z = z ? 0.f : v1.z; v1.w = z ? 0.f : v1.w;
-            }
-            dst[2 * j] = v0;
-            dst[2 * j + 1] = v1;
-        }
-    };
-
-    const float* bt = gs_bt + r * SK + 8 * h;       // this lane's column of tile 0, its half of every 16-k block
-
-    float4 cur[8], nxt[8];
-    const float *pa, *pa2;
-    bool zero;
-    sources(g, pa, pa2, zero);
-    load_chunk(cur, 0, pa, pa2, zero);
-    for (;;) {
-        const int gn = g + gstride;
-        const float *pan, *pa2n;
-        bool zeron;
-        sources(gn < groups ? gn : g, pan, pa2n, zeron);
-        f32x16 acc[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            {   // next chunk of this group, else the first chunk of the next group (or a harmless re-load at the very end)
-                const bool same = c + 1 < nchunk;
-                load_chunk(nxt, same ? c + 1 : 0, same ? pa : pan, same ? pa2 : pa2n, same ? zero : zeron);
-            }
-            float4 fb[2][NT][2];
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                fb[0][u][0] = *(const float4*)&bt[u * 32 * SK + c * GS_KC];
-                fb[0][u][1] = *(const float4*)&bt[u * 32 * SK + c * GS_KC + 4];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (c * GS_KC + 16 * j < K) {
-                    if (j < 3 && c * GS_KC + 16 * (j + 1) < K) {
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) {
-                            fb[(j + 1) & 1][u][0] = *(const float4*)&bt[u * 32 * SK + c * GS_KC + 16 * (j + 1)];
-                            fb[(j + 1) & 1][u][1] = *(const float4*)&bt[u * 32 * SK + c * GS_KC + 16 * (j + 1) + 4];
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const float4 av = cur[2 * j + (t >> 2)];
-                        const float a = (t & 3) == 0 ? av.x : (t & 3) == 1 ? av.y : (t & 3) == 2 ? av.z : av.w;
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) {
-                            const float4 bv = fb[j & 1][u][t >> 2];
-                            const float b = (t & 3) == 0 ? bv.x : (t & 3) == 1 ? bv.y : (t & 3) == 2 ? bv.z : bv.w;
-                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[u], 0, 0, 0);   // transposed tile
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
-        }
-        // transposed accumulators: lane = output row r of the group, register quad q = columns 8q + 4h .. +3 of a 32-column
-        // tile: 16-byte stores; the per-column terms come from LDS, every value is finished before the first store (see
-        // gemm_fast_kernel)
-        {
-            const int gm = g * 32 + r;
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                float4 o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 c4 = *(const float4*)&lcs[u * 32 + 8 * q + 4 * h];
-                    const float4 h4 = *(const float4*)&lcs[NTILE + u * 32 + 8 * q + 4 * h];
-                    float v[4] = {acc[u][4 * q] * c4.x + h4.x, acc[u][4 * q + 1] * c4.y + h4.y,
-                                  acc[u][4 * q + 2] * c4.z + h4.z, acc[u][4 * q + 3] * c4.w + h4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (E.leaky && !(v[e] > 0.f)) ? v[e] * E.alpha : v[e];
-                        asm volatile("" : "+v"(v[e]));
-                    }
-                    o[q] = make_float4(v[0], v[1], v[2], v[3]);
-                }
-                float* dst = C + (size_t)(gm < M ? gm : 0) * ldc + n0 + u * 32 + 4 * h;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (gm < M) *(float4*)&dst[8 * q] = o[q];
-            }
-        }
-        if (gn >= groups) break;
-        g = gn;
-        pa = pan; pa2 = pa2n; zero = zeron;
-    }
-}
-
 // res_bf16 / c_bf16: the residual operand / the output hold bfloat16 values (bf16 feature storage, d3f_gemm_bf16)
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E,
@@ -655,9 +482,9 @@ static void gemm_plan(int M, int N, int K, int M_hint, int& bm, int& bn, int& S,
     // capacity mode: M is only an upper bound; split K for the row count the caller EXPECTS (skinny deep layers would
     // otherwise be planned as if they filled the chip and run their whole K loop in a handful of workgroups)
     if (M_hint > 0 && M_hint < M) M = M_hint;
-    // Measured on MI355X over the network's 37 shapes (tools/gemm_bench.py sweep): these GEMMs are small (<= 3 GFLOP) and
-    // latency / bandwidth bound, so the 64x64 tile -- 33 KB of LDS, 4 workgroups resident per CU -- beats the register-
-    // tiled 128x128 / 128x64 variants everywhere; the larger tiles stay available through D3F_GEMM_FORCE for big problems.
+    // Measured on MI355X over the network's 37 shapes (round 1 / 2 sweeps): these GEMMs are small (<= 7 GFLOP) and latency /
+    // bandwidth bound, so the 64x64 tile -- 37 KB of LDS, 4 workgroups resident per CU -- beat the register-tiled 128x128 /
+    // 128x64 variants everywhere.
     auto blocks_of = [&](int m, int n) { return (long long)d3f_cdiv(M, m) * d3f_cdiv(N, n); };
     if (N <= 32) { bm = 128; bn = 32; }
     else { bm = 64; bn = 64; }
@@ -673,16 +500,6 @@ static void gemm_plan(int M, int N, int K, int M_hint, int& bm, int& bn, int& S,
         S = (int)(want < maxs ? want : maxs);
         if (S > 64) S = 64;
         if (S < 1) S = 1;
-    }
-    // tuning knob (tools/gemm_bench.py): D3F_GEMM_FORCE="bm,bn,S" overrides the choice; unset in production
-    static const char* const force = getenv("D3F_GEMM_FORCE");   // read once per process
-    if (const char* f = force) {
-        int fbm = 0, fbn = 0, fs = 0;
-        if (sscanf(f, "%d,%d,%d", &fbm, &fbn, &fs) == 3 && N > 32 &&
-            ((fbm == 128 && fbn == 128) || (fbm == 128 && fbn == 64) || (fbm == 64 && fbn == 64))) {
-            bm = fbm; bn = fbn;
-            S = fs < 1 ? 1 : (fs > nt ? nt : fs);
-        }
     }
     tps = d3f_cdiv(nt, S);
     S = d3f_cdiv(nt, tps);
@@ -731,50 +548,8 @@ extern "C" int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1
     return gemm_run(x, ldx, W, ldb, C, ldc, M, N, C1 + C2, E, G, workspace, workspace_bytes, M_dev, M_hint, (hipStream_t)stream_);
 }
 
-// The streaming kernel takes the shapes it was written for: shallow K (whole B slab in LDS), many rows, 16-byte aligned
-// float4-addressable operands.  D3F_GEMM_STREAM=0 disables it, D3F_GEMM_STREAM_BLOCKS sets the persistent grid (tuning knobs).
-static int gemm_stream_blocks() {
-    static int v = [] { const char* e = getenv("D3F_GEMM_STREAM_BLOCKS"); int b = e ? atoi(e) : 0; return b > 0 ? b : 512; }();
-    return v;
-}
-static bool gemm_stream_ok(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const GemmGather& G,
-                           int M_hint) {
-    // D3F_GEMM_STREAM: 1 = where it was measured ahead of the tile kernel in isolation (tools/gemm_bench.py, MI355X: the
-    // finest level's contractions, >= 64 k rows, K <= 128: up to 30 % on 235 k x 32 x 128), 2 = wherever it can run (tests),
-    // default 0: end to end, with four replays in flight, the two kernels measured the same (1134 vs 1116 fragments/s), so
-    // production keeps the single tile kernel.
-    static int on = [] { const char* e = getenv("D3F_GEMM_STREAM"); return e ? atoi(e) : 0; }();
-    if (!on) return false;
-    const int mexp = (M_hint > 0 && M_hint < M) ? M_hint : M;
-    if (K < 16 || K > 256 || K % 16 != 0 || N % 32 != 0) return false;
-    if (on == 1 ? (mexp < 65536 || K > 128) : (mexp < 256)) return false;
-    if (lda % 4 != 0 || ldb % 4 != 0 || (((uintptr_t)A | (uintptr_t)B) & 15) != 0) return false;
-    if ((size_t)64 * (K + 6) * sizeof(float) > 73728) return false;
-    if (G.A2 && (G.K1 % 16 != 0 || G.lda2 % 4 != 0 || ((uintptr_t)G.A2 & 15) != 0)) return false;
-    return true;
-}
-
 static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, GemmEpi E,
                     GemmGather G, void* workspace, size_t workspace_bytes, const int* M_dev, int M_hint, hipStream_t stream) {
-    if (!E.residual && !E.row_scale && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && gemm_stream_ok(A, lda, B, ldb, M, N, K, G, M_hint)) {
-        // column slab per workgroup: as wide as 72 KB of LDS allows (two workgroups per CU)
-        int nt = N % 64 == 0 ? 2 : 1;     // (four column tiles per wave would leave one wave per SIMD: nothing overlaps)
-        const size_t lds = (size_t)(32 * nt) * (K + 4 + 2) * sizeof(float);
-        int bx = d3f_cdiv(d3f_cdiv(M, 32), 4);
-        const int bx_max = gemm_stream_blocks();
-        if (bx > bx_max) bx = bx_max;
-        dim3 grid(bx, N / (32 * nt));
-        static std::atomic<unsigned long long> lds_done{0};   // slabs above 64 KB need the opt-in (per device)
-        const void* const fns[4] = {(const void*)gemm_stream_kernel<2, false>, (const void*)gemm_stream_kernel<1, false>,
-                                    (const void*)gemm_stream_kernel<2, true>, (const void*)gemm_stream_kernel<1, true>};
-        if (d3f_opt_in_lds(lds_done, fns, 73728) != D3F_OK) return D3F_ERR_HIP;
-#define D3F_STREAM(NT_, GA_) gemm_stream_kernel<NT_, GA_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, E, M_dev, G)
-        if (G.gidx) { if (nt == 2) D3F_STREAM(2, true); else D3F_STREAM(1, true); }
-        else { if (nt == 2) D3F_STREAM(2, false); else D3F_STREAM(1, false); }
-#undef D3F_STREAM
-        D3F_LAUNCH_CHECK();
-        return D3F_OK;
-    }
     int bm, bn, S, tps;
     gemm_plan(M, N, K > 0 ? K : 1, M_hint, bm, bn, S, tps);
     float* slab = nullptr;
@@ -788,17 +563,12 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
     if (d3f_cdiv(M, bm) > 65535) return D3F_ERR_ARG;
     dim3 grid(d3f_cdiv(N, bn), S, d3f_cdiv(M, bm));
     // float4-addressable operands (every shape of the network): the straight-line kernel; anything else: the generic one
-    static int fast_on = [] { const char* e = getenv("D3F_GEMM_FAST"); return e ? atoi(e) : 1; }();
-    const bool fast = fast_on && (!E.residual || (E.ldr % 4 == 0 && ((uintptr_t)E.residual & 15) == 0)) && vecA && vecB &&
+    const bool fast = (!E.residual || (E.ldr % 4 == 0 && ((uintptr_t)E.residual & 15) == 0)) && vecA && vecB &&
                       K % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 &&
                       (((uintptr_t)C | (uintptr_t)E.col_scale | (uintptr_t)E.col_shift) & 15) == 0 &&
                       (!G.A2 || (G.K1 % 4 == 0 && G.lda2 % 4 == 0 && ((uintptr_t)G.A2 & 15) == 0));
     if (fast) {
         const size_t lds = (size_t)2 * (bm + bn) * GF_S * sizeof(float);
-        static std::atomic<unsigned long long> lds_done{0};   // the 128 x 128 tile needs 72 KB (per device)
-        const void* const big[4] = {(const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 0>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 1>,
-                                    (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 2>, (const void*)gemm_fast_kernel<2, 2, 2, 2, 1, 3>};
-        if (bm == 128 && bn == 128 && d3f_opt_in_lds(lds_done, big, 2 * 256 * GF_S * (int)sizeof(float)) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, EPI_)                                                                     \
     gemm_fast_kernel<WM_, WN_, TM_, TN_, NA_, EPI_><<<grid, 256, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, tps, slab, E, \
                                                                                 M_dev, G)
@@ -811,8 +581,6 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
         else D3F_GEMM_E(WM_, WN_, TM_, TN_, NA_, 3);                                                                   \
     } while (0)
         if (bn == 32) D3F_GEMM(4, 1, 1, 1, 1);
-        else if (bm == 128 && bn == 128) D3F_GEMM(2, 2, 2, 2, 1);
-        else if (bm == 128 && bn == 64) D3F_GEMM(2, 2, 2, 1, 1);
         else D3F_GEMM(2, 2, 1, 1, 1);
 #undef D3F_GEMM
 #undef D3F_GEMM_E

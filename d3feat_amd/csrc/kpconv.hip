@@ -690,11 +690,8 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static std::atomic<unsigned long long> lds_done{0};
-    const void* const fns[3] = {(const void*)kpconv_fused32_kernel<true, 8>, (const void*)kpconv_fused32_kernel<true, 4>,
-                                (const void*)kpconv_fused32_kernel<false, 8>};
+    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, 8>, (const void*)kpconv_fused32_kernel<false, 8>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-    // tuning knob (read once): D3F_KF_PF4=1 runs the shallow-prefetch variant (128 registers, four workgroups per CU)
-    static const int pf4 = [] { const char* e = getenv("D3F_KF_PF4"); return e ? atoi(e) : 0; }();
 #define D3F_KF(FAST_, PF_)                                                                                                   \
     kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
                                                                                  out, ldo, Nq_dev, Ns_dev, q_order)
@@ -706,8 +703,7 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
         kpconv_fused32_kernel<true, 8, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
             q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
     } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
-    else if (pf4) D3F_KF(true, 4);
-    else D3F_KF(true, 8);
+    else D3F_KF(true, 8);      // (the shallow-prefetch variant PF = 4 -- 128 registers, four workgroups per CU -- measured slower)
 #undef D3F_KF
     D3F_LAUNCH_CHECK();
     return D3F_OK;
@@ -957,9 +953,6 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
 #define D3F_KG(LQ_, PF_)                                                                                                    \
     kpconv_fused_kernel<LQ_, PF_><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, E, \
                                                                       out, ldo, Nq_dev, Ns_dev, q_order)
-    // tuning knob (read once): D3F_KG_PF4=1 runs the Cin = 64 variant with the shallow gather prefetch (128 registers, four
-    // workgroups per CU instead of three)
-    static const int pf4 = [] { const char* e = getenv("D3F_KG_PF4"); return e ? atoi(e) : 0; }();
     if (feat_bf16) {
         const unsigned short* fh = (const unsigned short*)f_;
         unsigned short* oh = (unsigned short*)out_;
@@ -972,7 +965,7 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
         else
             kpconv_fused_kernel<32, 4, unsigned short><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
-    } else if (Cin == 64) { if (pf4) D3F_KG(16, 4); else D3F_KG(16, 8); }
+    } else if (Cin == 64) D3F_KG(16, 8);
     else if (Cin == 256) D3F_KG(64, 4);
     else D3F_KG(32, 4);
 #undef D3F_KG

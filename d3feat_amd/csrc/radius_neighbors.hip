@@ -486,12 +486,9 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     if (!g.ok) return D3F_ERR_WORKSPACE;
     const float r2 = radius * radius;
     const int* qorder = queries_are_supports ? g.order : nullptr;
-    // lanes per query: 32 (two queries per wavefront) unless the ordering budget is large (rare, dense clouds);
-    // D3F_NB_LPQ=64 restores one wavefront per query (tuning knob)
+    // lanes per query: 32 (two queries per wavefront) unless the ordering budget is large (rare, dense clouds)
     cap = (cap + 3) & ~3;   // LDS segments are read four hits at a time
-    int lpq = cap > 256 ? 64 : 32;
-    static const int lpq_knob = [] { const char* f = getenv("D3F_NB_LPQ"); return f ? atoi(f) : 0; }();   // read once
-    if (lpq_knob == 64 || lpq_knob == 32) lpq = lpq_knob;
+    const int lpq = cap > 256 ? 64 : 32;
     const int qpb = 64 * NB_WAVES_PER_BLOCK / lpq;
     const int blocks = d3f_cdiv(Nq, qpb);
     const size_t lds = first_only ? 0 : (size_t)qpb * cap * 2 * sizeof(float);

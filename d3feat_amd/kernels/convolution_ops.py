@@ -20,12 +20,6 @@ from .. import ops
 from .kernel_points import create_kernel_points
 
 
-import os
-
-# D3F_KPCONV_FUSED=0 sends the Cin = 64 / 128 layers through the two-kernel form (aggregation + contraction) again: a tuning
-# knob for A/B measurements, read once at import.
-FUSED_DEEP = os.environ.get("D3F_KPCONV_FUSED", "1") != "0"
-
 
 def unary_convolution(features, K_values, epilogue=None):
     """features f32[n, Cin] @ K_values f32[Cin, Cout]."""
@@ -66,7 +60,7 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
         # level-0 convolutions: aggregation + contraction + epilogue in one kernel, the 113 MB wf tensor stays in LDS
         return ops.kpconv_fused32(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
                                   KP_influence, aggregation_mode, **(epilogue or {}))
-    if FUSED_DEEP and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and \
+    if features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and \
             ops.kpconv_fused_supported(cin, cout, num_kp, KP_influence, aggregation_mode):
         # levels 1 and 2 (Cin = Cout = 64 / 128): the same, in tiles of 16 queries, the contraction fed from LDS
         return ops.kpconv_fused(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,

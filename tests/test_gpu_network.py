@@ -45,20 +45,6 @@ def test_gemm_epilogues(device, M, K, N):
     _close(got.cpu().numpy(), full, 2e-5, relative=True)
 
 
-def test_gemm_streaming_kernel_everywhere(device):
-    """The shallow-K streaming kernel only takes the finest level's shapes by default; D3F_GEMM_STREAM=2 sends every eligible
-    shape through it (the switch is read once per process, hence the child process): the contraction / decoder tests must
-    pass unchanged."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, D3F_GEMM_STREAM="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "test_gemm_epilogues or test_gemm_upsample_cat or test_gemm_strided"], env=env, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_gemm_strided_views(device):
     from d3feat_amd import ops
     rng = np.random.default_rng(0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of d3f_gemm_f32 on the GEMM shapes of one 30k-point self-pair, HIP-event timed.
-    python tools/gemm_bench.py            # planner's choice
-    python tools/gemm_bench.py sweep      # every tile / split-K candidate per shape (tuning the planner)
+    python tools/gemm_bench.py            # the library's plan per shape (D3F_GEMM_BENCH_BF16=1: the bf16 contraction)
+A/B of kernel variants: build the variant into another .so and point D3FEAT_AMD_LIB at it (tools/gpu_experiments.sh).
 """
 import os
 import sys
@@ -56,7 +56,6 @@ def _time_one(A, B, reps=20):
 
 def main():
     dev = torch.device("cuda", 0)
-    sweep = len(sys.argv) > 1 and sys.argv[1] == "sweep"
     tot_us, tot_fl = 0.0, 0.0
     maxk = int(os.environ.get("D3F_GEMM_BENCH_MAXK", "0"))
     for (M, K, N, cnt) in SHAPES:
@@ -67,21 +66,8 @@ def main():
         A = torch.randn(M, K, device=dev)
         B = torch.randn(K, N, device=dev)
         fl = 2.0 * M * K * N
-        os.environ.pop("D3F_GEMM_FORCE", None)
         us = time_one(A, B)
         line = "M=%6d K=%5d N=%5d  plan %7.1f us %6.1f TF" % (M, K, N, us, fl / us / 1e6)
-        if sweep and N > 32:
-            best = (us, "plan")
-            for bm, bn in ((128, 128), (128, 64), (64, 64)):
-                for S in (1, 2, 4, 8, 16, 32):
-                    if S > max(1, K // 32 // 2):
-                        continue
-                    os.environ["D3F_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, S)
-                    u = time_one(A, B, reps=10)
-                    if u < best[0]:
-                        best = (u, "%dx%d S=%d" % (bm, bn, S))
-            line += "   best %7.1f us (%s)" % best
-            os.environ.pop("D3F_GEMM_FORCE", None)
         print(line, flush=True)
         tot_us += us
         tot_fl += fl
