@@ -629,7 +629,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
         r["ms_per_step"] = round(d["ms"] / nprof, 4)
         r["fragments_per_launch"] = Fp
         # HBM traffic per launch: from the newest committed pair of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
-        # of this same command (tools/gpu_round.sh -> tools/pmc_summary.py, corrections of MI355X_MICROARCH.md §HBM applied
+        # of this same command (tools/gpu_visit.sh pmc -> tools/pmc_summary.py, corrections of MI355X_MICROARCH.md §HBM applied
         # there); launch-weighted mean over the template instantiations of the kernel.  `traffic_stale`: the counter file was
         # collected for different kernel sources than the ones running now.
         if traffic is not None:
