@@ -182,12 +182,12 @@ __device__ __forceinline__ void nb_bitonic64(int lane, unsigned& h0, unsigned& l
 }
 
 template <bool FIRST_ONLY, int LPQ, bool HINT>
-__global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
-nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
-                 const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
-                 const float4* __restrict__ sorted,
-                 const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
-                 int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
+__device__ __forceinline__ void
+nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
+               const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
+               const float4* __restrict__ sorted,
+               const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
+               int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QPB = 64 * NB_WAVES_PER_BLOCK / LPQ;   // queries per workgroup
     const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
@@ -377,6 +377,17 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
         }
     }
     for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
+}
+
+template <bool FIRST_ONLY, int LPQ, bool HINT>
+__global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
+nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
+                 const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
+                 const float4* __restrict__ sorted,
+                 const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
+                 int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
+    nb_search_body<FIRST_ONLY, LPQ, HINT>(q, Nq, qlens, B, el, cell_start, cell_base, sorted, qorder, r2, pad, ns_dev, out, ld, width,
+                                          cap, status, want_kmax, nn_hint);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,26 +122,43 @@ class Dataset:
         cap = getattr(self, '_neighbor_cap', 192)
         grids = {}
 
-        def search(q, s, ql, sl, r, layer, first_only=False, nn_hint=0.0):
+        reqs = []      # searches not issued yet: (q, s, ql, sl, r, width, first_only, nn_hint, sink list, sink index)
+
+        def request(q, s, ql, sl, r, layer, sink, first_only=False, nn_hint=0.0):
+            """Ask for one index matrix; it lands in sink[-1] (a placeholder is appended now).  On the fast path the searches of
+            one grid -- conv_i and pool_i of a level and the level above's up_i: same supports, same radius -- are issued
+            together by flush(), after the level's subsampling (whose launch chain then overlaps with nothing it needs)."""
             lim = int(self.neighborhood_limits[layer])
             if first_only and not exact_shapes:
                 lim = 1     # only the nearest support is computed AND stored: closest_pool reads column 0 (network_blocks.py:81);
                             # a full-width row of padding per point was 39 MB of writes per level-0 launch
+            sink.append(None)
             if exact_shapes:
-                full = tf_batch_neighbors(q, s, ql, sl, r)
-                return full[:, :lim]
-            # conv_i and pool_i of a layer query the same supports with the same radius: one grid serves both
-            key = (s.data_ptr(), float(r))
-            grid = grids.get(key)
-            if grid is None:
-                grid = grids[key] = ops.NeighborGrid(s, sl, r)
-                if getattr(s, 'order', None) is None:
-                    s.order = grid.order   # cell-sorted visiting order of this level's points (ops._order)
-            out, status = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status_all[len(pending)],
-                                      reset_status=False, want_kmax=False, nn_hint=nn_hint)
-            pending.append(status)
-            return out
+                sink[-1] = tf_batch_neighbors(q, s, ql, sl, r)[:, :lim]
+                return
+            reqs.append((q, s, ql, sl, float(r), lim, first_only, nn_hint, sink, len(sink) - 1))
 
+        def flush():
+            groups = {}
+            for rq in reqs:
+                groups.setdefault((rq[1].data_ptr(), rq[4]), []).append(rq)
+            del reqs[:]
+            for key, grp in groups.items():
+                s_, sl_, r_ = grp[0][1], grp[0][3], grp[0][4]
+                grid = grids.get(key)
+                if grid is None:
+                    grid = grids[key] = ops.NeighborGrid(s_, sl_, r_)
+                    if getattr(s_, 'order', None) is None:
+                        s_.order = grid.order   # cell-sorted visiting order of this level's points (ops._order)
+                # one launch per search: issuing the two or three searches of a grid as ONE launch (blockIdx.y = query set) was
+                # measured 5-7 % slower end to end (profiles/r03_experiments.txt x8)
+                for (q, _, ql, _, _, lim, fo, hint, sink, at) in grp:
+                    out, status = grid.search(q, ql, lim, cap=cap, first_only=fo, status=status_all[len(pending)],
+                                              reset_status=False, want_kmax=False, nn_hint=hint)
+                    pending.append(status)
+                    sink[at] = out
+
+        empty_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
         for block_i, block in enumerate(arch):
             if 'global' in block or 'upsample' in block:
                 break
@@ -150,15 +167,8 @@ class Dataset:
                 if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
                     continue
             layer = len(input_points)
-            if layer_blocks:
-                if np.any(['deformable' in blck for blck in layer_blocks[:-1]]):
-                    r = r_normal * config.density_parameter / (config.KP_extent * 2.5)
-                else:
-                    r = r_normal
-                conv_i = search(stacked_points, stacked_points, stacked_lengths, stacked_lengths, r, layer)
-            else:
-                conv_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
-            if 'pool' in block or 'strided' in block:
+            pooled = 'pool' in block or 'strided' in block
+            if pooled:      # the next level's points first: pool_i's queries (the searches of this level go out together)
                 dl = 2 * r_normal / (config.KP_extent * 2.5)
                 if caps is not None:
                     hints = getattr(self, 'hints', None)
@@ -173,29 +183,39 @@ class Dataset:
                     pending.append(status_all[len(pending)])
                 else:
                     pool_p, pool_b = tf_batch_subsampling(stacked_points, stacked_lengths, dl)
+            if layer_blocks:
+                if np.any(['deformable' in blck for blck in layer_blocks[:-1]]):
+                    r = r_normal * config.density_parameter / (config.KP_extent * 2.5)
+                else:
+                    r = r_normal
+                request(stacked_points, stacked_points, stacked_lengths, stacked_lengths, r, layer, input_neighbors)
+            else:
+                input_neighbors.append(empty_i)
+            if pooled:
                 if 'deformable' in block:
                     r = r_normal * config.density_parameter / (config.KP_extent * 2.5)
                 else:
                     r = r_normal
-                pool_i = search(pool_p, stacked_points, pool_b, stacked_lengths, r, layer)
+                request(pool_p, stacked_points, pool_b, stacked_lengths, r, layer, input_pools)
+                flush()      # conv_i, pool_i of this level + up_i of the level above: one grid, one launch
                 # the supports of up_i are the voxel barycentres (edge dl) of the queries themselves: every query has one within
-                # sqrt(3) dl -- a hint for the nearest-only search (8 cells instead of 27), never a constraint
-                up_i = search(stacked_points, pool_p, stacked_lengths, pool_b, 2 * r, layer,
-                              first_only=up_first_column_only, nn_hint=1.75 * dl)
+                # sqrt(3) dl -- a hint for the nearest-only search (8 cells instead of 27), never a constraint.  Its grid (the
+                # next level's points, radius 2 r) is the next level's conv grid: issued with that level's searches
+                request(stacked_points, pool_p, stacked_lengths, pool_b, 2 * r, layer, input_upsamples,
+                        first_only=up_first_column_only, nn_hint=1.75 * dl)
             else:
-                pool_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+                flush()
+                input_pools.append(empty_i)
                 pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
                 pool_b = torch.zeros((0,), dtype=torch.int32, device=dev)
-                up_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+                input_upsamples.append(empty_i)
             input_points += [stacked_points]
-            input_neighbors += [conv_i]
-            input_pools += [pool_i]
-            input_upsamples += [up_i]
             input_batches_len += [stacked_lengths]
             stacked_points = pool_p
             stacked_lengths = pool_b
             r_normal *= 2
             layer_blocks = []
+        flush()
 
         overflow = False
         self.static_status = status_all[:len(pending)] if caps is not None else None
