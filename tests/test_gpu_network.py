@@ -45,6 +45,46 @@ def test_gemm_epilogues(device, M, K, N):
     _close(got.cpu().numpy(), full, 2e-5, relative=True)
 
 
+@pytest.mark.parametrize("M,K,N,real", [(200, 4096, 128, 0), (5000, 1000, 192, 0), (70000, 160, 64, 0), (33, 8, 4, 0),
+                                        (9000, 512, 128, 6100), (300000, 256, 64, 171000), (1580, 7680, 512, 1200)])
+def test_gemm_split_plans_and_capacity_rows(device, M, K, N, real):
+    """Contraction shapes whose K range is split into slabs (few tiles, long K), not split (K <= 512), with a device-resident row
+    count below the capacity (rows past it are never written): results vs fp64, bit-identical from call to call (the slabs are
+    reduced in a fixed order), every epilogue.  (Written for the persistent stream-K schedule of experiment x10 -- parked as
+    tools/ubench/gemm_streamk_pipelined.patch -- and kept: it covers the capacity-mode rows of the production kernel too.)"""
+    from d3feat_amd import ops
+    rng = np.random.default_rng(M + K + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    rs = rng.random(M).astype(np.float32) + 0.5
+    cs = rng.random(N).astype(np.float32) + 0.5
+    ch = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    n = real or M
+    ref = A[:n].astype(np.float64) @ B.astype(np.float64)
+    tA, tB = _t(A, device), _t(B, device)
+    if real:
+        tA.n_dev = torch.tensor([real], dtype=torch.int32, device=device)
+        tA.n_hint = real
+    sentinel = 12345.0
+    outs = []
+    for rep in range(3):
+        out = torch.full((M, N), sentinel, dtype=torch.float32, device=device)
+        ops.gemm(tA, tB, out=out)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    _close(outs[0][:n].cpu().numpy(), ref, 2e-5, relative=True)
+    assert bool((outs[0][n:] == sentinel).all())
+    full = ref * rs[:n, None] * cs + ch + res[:n]
+    full = np.where(full > 0, full, 0.2 * full)
+    for kw in (dict(row_scale=_t(rs, device)), dict(residual=_t(res, device)), dict(row_scale=_t(rs, device), residual=_t(res, device))):
+        want = ref * (rs[:n, None] if "row_scale" in kw else 1.0) * cs + ch + (res[:n] if "residual" in kw else 0.0)
+        want = np.where(want > 0, want, 0.2 * want)
+        got = ops.gemm(tA, tB, col_scale=_t(cs, device), col_shift=_t(ch, device), leaky=True, alpha=0.2, **kw)
+        _close(got[:n].cpu().numpy(), want, 2e-5, relative=True)
+
+
 def test_gemm_strided_views(device):
     from d3feat_amd import ops
     rng = np.random.default_rng(0)
