@@ -415,7 +415,8 @@ def main():
                        "capacities": (None if engine is None else
                                       {"raw_points_per_fragment": engine.raw_cap, "voxels_per_cloud": engine.n0_cap,
                                        "rows_per_level": [int(c) for c in engine.caps]}),
-                       "engine_fallbacks": (engine.fallbacks if engine is not None else None)},
+                       "engine_fallbacks": (engine.fallbacks if engine is not None else None),
+                       "engine_isolated_replays": (engine.isolated if engine is not None else None)},
             "parity": parity, "roofline": roof, "rooflines": roofs, "marginal_cost": marginal, "kpconv_layers_ms": layers,
             "cpu_baseline": cpu,
             "mirror_self_pair": mirror_extra, "pcie_inclusive": pcie,

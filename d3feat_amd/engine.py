@@ -13,7 +13,8 @@ synchronisations the GPU idles a third of the time.  Here instead:
   * `slots` graphs live on separate streams, so consecutive fragments overlap and the small deep-level kernels of one
     fragment fill the CUs the other leaves idle.
 A fragment that does not fit its capacity class (or needs the large neighbour-ordering budget) raises a device-side
-flag; `fetch` then recomputes it through the eager path, so results never depend on the capacities.
+flag; `fetch` then recomputes it through the eager path, so results never depend on the capacities.  When the flagged
+replay held several fragments they are first isolated (one short replay each): only the outliers go eager.
 """
 import warnings
 
@@ -104,7 +105,8 @@ class FragmentEngine:
         # process onto a few hardware queues, so idle extra streams still cost concurrency)
         self.neighbor_cap = 192            # hits a query can order in LDS on the fast path (sticky upgrade, see fetch)
         self.slots = [self._build_slot(streams[i] if streams else None) for i in range(int(slots))]
-        self.fallbacks = 0
+        self.fallbacks = 0             # fragments that took the eager path
+        self.isolated = 0              # flagged multi-fragment replays that were split into single-fragment replays
         self.fragments = 0
         self._hit_overflows = 0
         self._warned = False
@@ -254,6 +256,25 @@ class FragmentEngine:
                             p, d, s = torch.cat([p, p]), torch.cat([d, d]), torch.cat([s, s])
                         outs.append((p, d, s))
                     o += n
+        if outs is None and sl.nfrag > 1:
+            # A flagged replay of several fragments: the flags are per stacked call, not per cloud, so the fragments are
+            # isolated -- each goes through the graph again as a batch of one (stand-ins fill the stack: a fraction of a full
+            # replay's time), and only those that still do not fit take the eager path.  One outlier costs its own eager run
+            # plus nfrag short replays, not nfrag eager runs.
+            srcs, single = sl.raw_src, sl.single
+            self.isolated += 1
+            outs = []
+            for fr in srcs:
+                if (sum(int(x.shape[0]) for x in fr) if self.two else int(fr.shape[0])) > self.raw_cap:
+                    self.fragments += 1
+                    self.fallbacks += 1
+                    o = self.run_eager(fr)
+                    outs.append(ops.pack_descriptors(*o) if packed else o)
+                    continue
+                self.submit(slot, [fr])
+                o = self.fetch(slot, packed)[0]                 # (counts the fragment, and its fallback if it takes one)
+                outs.append(o.clone() if packed else tuple(t.clone() for t in o))   # the slot's buffers are reused at once
+            return outs[0] if single else outs
         self.fragments += sl.nfrag
         if outs is None:
             # capacity exceeded / large ordering budget needed / degenerate cloud: the eager path decides (and raises the

@@ -116,7 +116,8 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
                                                  frag_rows=int(getattr(engine, "n0_cap", 1)) * (1 if keep == "first" else 2))
                          if overlap_chunk > 0 else parallel.ShardCollector(rows_cap=1, width=36, device=device))
         shards = collector.gather()
-    return dict(limits=limits, mine=list(mine), order=order, shards=shards, fallbacks=getattr(engine, "fallbacks", 0))
+    return dict(limits=limits, mine=list(mine), order=order, shards=shards, fallbacks=getattr(engine, "fallbacks", 0),
+                isolated=getattr(engine, "isolated", 0))
 
 
 def save_records_3dmatch(root):

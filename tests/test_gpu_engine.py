@@ -217,3 +217,28 @@ def test_engine_batched_fragments(device, setup, mirror):
     # single-fragment call on a batched engine keeps the single-tuple API
     p, d, s = eng.run(raws[1])
     assert torch.equal(p, refs[1][0])
+
+
+def test_engine_flagged_batch_isolates_the_outlier(device, setup):
+    """A replay of four fragments of which ONE exceeds the per-fragment voxel capacity, and one with more raw points than
+    raw_cap: the flags are per stacked call, so the engine replays the fragments one by one and only the outliers take the
+    eager path -- fallbacks count 1 + 1, not 4 + 4; every result equals the fragment's own eager run."""
+    from d3feat_amd.engine import FragmentEngine
+    cfg, W, limits = setup
+    eng = FragmentEngine(cfg, W, limits, raw_cap=45000, n0_cap=9000, slots=1, device=device, batch=4)
+    sizes = (6000, 40000, 4000, 8000)                        # fragment 1: ~10 k voxels > n0_cap, the others 3-6 k
+    raws = [torch.from_numpy(_frag(90 + i, n)).to(device) for i, n in enumerate(sizes)]
+    refs = [tuple(t.clone() for t in eng.run_eager(r)) for r in raws]
+    assert refs[1][0].shape[0] // 2 > 9000 and max(refs[i][0].shape[0] // 2 for i in (0, 2, 3)) < 9000
+    outs = eng.run(raws)
+    assert eng.isolated == 1 and eng.fallbacks == 1 and eng.fragments == 4
+    for (p, d, s), (rp, rd, rs) in zip(outs, refs):
+        assert torch.equal(p, rp)
+        _close(d, rd, 5e-6)
+        _close(s, rs, 5e-6)
+    big = torch.from_numpy(_frag(95, 50000)).to(device)      # more raw points than raw_cap: never enters a replay
+    outs = eng.run([raws[0], big, raws[2]])
+    assert eng.isolated == 2 and eng.fallbacks == 2 and eng.fragments == 7
+    assert torch.equal(outs[0][0], refs[0][0]) and torch.equal(outs[2][0], refs[2][0])
+    packed = eng.run([raws[3], raws[2]])                     # and the graph is healthy afterwards
+    assert eng.fallbacks == 2 and torch.equal(packed[0][0], refs[3][0])
