@@ -28,6 +28,7 @@
 
 struct KpParams {
     float kp[KP_MAXP * 3];
+    float kx[KP_MAXP], ky[KP_MAXP], kz[KP_MAXP];   // the same points, one array per coordinate: (kx[p], kx[p+1]) is a register pair
     int num_kp;
     float extent;
     float inv_2extent;  // 1 / (2 * extent)
@@ -67,12 +68,28 @@ __device__ __forceinline__ void kp_influences(const KpParams& P, float rx, float
 // KP_influence = linear, convolution_mode = sum, num_kernel_points = 15) as straight-line code: 15 x {3 subtractions,
 // 3 multiply-adds, add, v_sqrt, multiply-subtract, max}, no mode branches, the kernel points read as scalar operands.
 // FAST = false keeps the general function above (other modes / fewer kernel points).
+// These kernels are bound by VALU issue (r03 x14: 597 vector instructions per 8-neighbour chunk and wavefront, 285 of them the
+// aggregation's FMAs), so the influences are computed two kernel points at a time with the packed fp32 forms (v_pk_add / v_pk_mul /
+// v_pk_fma_f32: two IEEE operations per lane and issue slot, the same roundings as the scalar sequence -> bit-identical results).
+typedef float kp_f2 __attribute__((ext_vector_type(2)));
 template <bool FAST>
 __device__ __forceinline__ void kp_influences_t(const KpParams& P, float rx, float ry, float rz, float* w) {
     if (FAST) {
+        const kp_f2 rx2 = {rx, rx}, ry2 = {ry, ry}, rz2 = {rz, rz};
+        const kp_f2 one = {1.0f, 1.0f}, ninv = {-P.inv_2extent, -P.inv_2extent}, tiny = {1e-10f, 1e-10f};
 #pragma unroll
-        for (int p = 0; p < KP_MAXP - 1; ++p) {
-            const float dx = rx - P.kp[3 * p], dy = ry - P.kp[3 * p + 1], dz = rz - P.kp[3 * p + 2];
+        for (int p = 0; p < KP_MAXP - 2; p += 2) {
+            const kp_f2 kx = {P.kx[p], P.kx[p + 1]}, ky = {P.ky[p], P.ky[p + 1]}, kz = {P.kz[p], P.kz[p + 1]};
+            const kp_f2 dx = rx2 - kx, dy = ry2 - ky, dz = rz2 - kz;
+            const kp_f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx)) + tiny;
+            const kp_f2 sq = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+            const kp_f2 v = __builtin_elementwise_fma(sq, ninv, one);      // fma(-sqrt, 1/(2 extent), 1) as the scalar form
+            w[p] = fmaxf(v.x, 0.0f);
+            w[p + 1] = fmaxf(v.y, 0.0f);
+        }
+        {
+            constexpr int p = KP_MAXP - 2;
+            const float dx = rx - P.kx[p], dy = ry - P.ky[p], dz = rz - P.kz[p];
             const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             w[p] = fmaxf(fmaf(-__builtin_amdgcn_sqrtf(d2 + 1e-10f), P.inv_2extent, 1.0f), 0.0f);
         }
@@ -81,8 +98,63 @@ __device__ __forceinline__ void kp_influences_t(const KpParams& P, float rx, flo
         kp_influences(P, rx, ry, rz, w);
     }
 }
+static inline KpParams kp_make_params(const float* kp_host, int num_kp, float KP_extent, int influence, int aggregation) {
+    KpParams P;
+    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
+    for (int p = 0; p < KP_MAXP; ++p) { P.kx[p] = P.kp[3 * p]; P.ky[p] = P.kp[3 * p + 1]; P.kz[p] = P.kp[3 * p + 2]; }
+    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
+    P.aggregation = aggregation;
+    return P;
+}
+// The gather kernels address feature / index rows with one 24-bit multiply (full rate; the 64-bit multiply-adds they replace are
+// quarter rate and were a tenth of the kernels' issue slots): row counts and leading dimensions must stay below 2^24.
+static inline bool kp_fits_u24(int Nq, int Ns, int ld_idx, int ldf) {
+    const int lim = 1 << 24;
+    return Nq < lim && Ns < lim && ld_idx < lim && ldf < lim && (long long)Ns * ldf < (1ll << 31) && (long long)Nq * ld_idx < (1ll << 31);
+}
+// one 16-byte piece (channels c4 .. c4+3) of feature row `id`; a shadow neighbour (id < 0) reads row 0 instead -- its influences are
+// exactly 0, so whatever (finite) values arrive contribute nothing, and the load needs no branch, no select and no zero fill
+template <class FT>
+__device__ __forceinline__ float4 kp_gather4(const FT* __restrict__ f, int id, int ldf, int c4) {
+    const unsigned off = __umul24((unsigned)max(id, 0), (unsigned)ldf) + (unsigned)c4;
+    return D3fFeat<FT>::ld4(f + off);
+}
 static inline bool kp_fast_config(int num_kp, int influence, int aggregation) {
     return num_kp == KP_MAXP - 1 && influence == 1 && aggregation == 0;
+}
+
+// Phase-A operands of one (query, neighbour) pair, fetched AHEAD of their chunk so that no chunk starts with a chain of dependent
+// round trips (index -> support point): the index of chunk j + 1 is requested at the top of chunk j (it depends on nothing), the
+// point and row flag it names at the top of chunk j's phase B (the index has had phase A to arrive) and land under phase B's
+// gathers and FMAs.  A shadow neighbour (index outside [0, Ns)) reads row 0 and is moved to 1e6 -- the reference's own shadow
+// point (kernels/convolution_ops.py:186-188): every influence of the shipped (linear) configuration is exactly 0, no branch.
+struct KpPair {
+    int id;              // neighbour index, -1: shadow
+    float x, y, z;       // support point
+    bool pos;            // row flag of the support (the neighbour-count test)
+};
+__device__ __forceinline__ int kp_pair_index(const int* __restrict__ idrow, bool live, int k, int K, int Ns) {
+    return (live && k < K) ? idrow[k] : Ns;
+}
+__device__ __forceinline__ KpPair kp_pair_fetch(int id, int Ns, const float* __restrict__ s, const unsigned char* __restrict__ rowpos) {
+    KpPair r;
+    const bool ok = id >= 0 && id < Ns;
+    const unsigned row = ok ? (unsigned)id : 0u;
+    const float* sp = s + 3u * row;
+    r.x = sp[0]; r.y = sp[1]; r.z = sp[2];
+    r.pos = rowpos[row] != 0;
+    r.id = ok ? id : -1;
+    return r;
+}
+template <bool FAST>
+__device__ __forceinline__ bool kp_pair_influences(const KpParams& P, const KpPair& pr, float qx, float qy, float qz, float* w) {
+    const bool ok = pr.id >= 0;
+    kp_influences_t<FAST>(P, ok ? pr.x - qx : 1e6f, ok ? pr.y - qy : 1e6f, ok ? pr.z - qz : 1e6f, w);
+    if (!FAST) {        // 'constant' influence is 1 at any distance, 'closest' picks a kernel point anyway: the general modes zero
+#pragma unroll          // a shadow's weights explicitly (in the reference its FEATURE row is the zero row)
+        for (int p = 0; p < KP_MAXP; ++p) w[p] = ok ? w[p] : 0.f;
+    }
+    return ok && pr.pos;
 }
 
 // The 16 influences of one (query, neighbour) pair in LDS: four 16-byte quads at base + 16*slot floats.  Eight adjacent
@@ -187,29 +259,21 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
     for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (qg < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    const int* idrow = idx + (qg < Nq ? __umul24((unsigned)qg, (unsigned)ld_idx) : 0u);   // (rows, leading dimensions < 2^24: kp_fits_u24)
+    KpPair pr = kp_pair_fetch(kp_pair_index(idrow, qg < Nq, cl, K, Ns), Ns, s, rowpos);     // chunk 0's pair
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += KC) {
+        const int id_next = kp_pair_index(idrow, qg < Nq, k0 + KC + cl, K, Ns);              // in flight during phase A
         // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
         {
-            const int k = k0 + cl;
-            int id = Ns;
-            if (qg < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
-            bool positive = false;
-            if (id >= 0 && id < Ns) {
-                const float rx = s[3 * (size_t)id] - qx, ry = s[3 * (size_t)id + 1] - qy, rz = s[3 * (size_t)id + 2] - qz;
-                kp_influences_t<FAST>(P, rx, ry, rz, w);
-                positive = rowpos[id] != 0;
-            } else {
-                id = -1;
-#pragma unroll
-                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
-            }
+            const bool positive = kp_pair_influences<FAST>(P, pr, qx, qy, qz, w);
             kp_count_positive<LQ>(positive, ql, cl, lcnt);
-            lidx[ql * KC + cl] = id;
+            lidx[ql * KC + cl] = pr.id;
             kp_store_w(&lw[ql * WS + cl * 16], cl, w);
         }
         __syncthreads();
+        pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                          // in flight during phase B
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
         const int kend = min(KC, K - k0);
         // feature rows are requested in groups of up to eight before any is consumed: the gathers are independent, so their
@@ -221,11 +285,11 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                fv[u] = ids[u] >= 0 ? D3fFeat<FT>::ld4(&f[(size_t)ids[u] * ldf + 4 * cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = kp_gather4(f, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (ids[u] < 0) continue;   // shadow neighbour: influence 0, feature row 0
+                if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
                 kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
 #pragma unroll
@@ -472,10 +536,7 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
         return D3F_ERR_ARG;
     if (Nq == 0) return D3F_OK;
     if (!q || !s || !idx || !f || !kp_host || !W || !out) return D3F_ERR_ARG;
-    KpParams P;
-    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
-    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
-    P.aggregation = aggregation;
+    const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     if (out_bf16 && !(aggregation == 0 && num_kp <= 15)) return D3F_ERR_ARG;    // bf16 feature storage: the shipped configuration
     if (aggregation == 0 && num_kp <= 15) {
@@ -605,27 +666,20 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (qslot < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    const int* idrow = idx + (qslot < Nq ? __umul24((unsigned)qg, (unsigned)ld_idx) : 0u);   // (rows, leading dimensions < 2^24)
+    KpPair pr = kp_pair_fetch(kp_pair_index(idrow, qslot < Nq, cl, K, Ns), Ns, s, rowpos);  // chunk 0's pair
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += KF_LQ) {
+        const int id_next = kp_pair_index(idrow, qslot < Nq, k0 + KF_LQ + cl, K, Ns);       // in flight during phase A
         {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
-            const int k = k0 + cl;
-            int id = Ns;
-            if (qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
-            bool positive = false;
-            if (id >= 0 && id < Ns) {
-                kp_influences_t<FAST>(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
-                positive = rowpos[id] != 0;
-            } else {
-                id = -1;
-#pragma unroll
-                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
-            }
+            const bool positive = kp_pair_influences<FAST>(P, pr, qx, qy, qz, w);
             kp_count_positive<KF_LQ>(positive, ql, cl, lcnt);
-            lidx[ql * KF_LQ + cl] = id;
+            lidx[ql * KF_LQ + cl] = pr.id;
             kp_store_w(&lw[ql * KF_WS + cl * 16], cl, w);
         }
         __syncthreads();
+        pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                         // in flight during phase B
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
         // all eight feature rows of the chunk are requested before any is consumed: the gathers are independent, so their
         // latencies overlap instead of adding up (the kernel is bound by these round trips, not by the FMAs)
@@ -636,11 +690,11 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = lidx[ql * KF_LQ + k1 + u];
-                fv[u] = ids[u] >= 0 ? D3fFeat<FT>::ld4(&f[(size_t)ids[u] * ldf + 4 * cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = kp_gather4(f, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
+                if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
                 kp_load_w(&lw[ql * KF_WS + (k1 + u) * 16], k1 + u, w);
 #pragma unroll
@@ -682,15 +736,20 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
         return D3F_ERR_ARG;
     if (Nq == 0) return D3F_OK;
     if (!q || !s || !idx || !f || !rowpos || !kp_host || !W || !out || (((uintptr_t)f) & 15)) return D3F_ERR_ARG;
-    KpParams P;
-    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
-    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
-    P.aggregation = aggregation;
+    if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;     // (16.7 M rows per call: use d3f_kpconv_aggregate + d3f_gemm_f32)
+    const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static std::atomic<unsigned long long> lds_done{0};
-    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, 8>, (const void*)kpconv_fused32_kernel<false, 8>};
+    // feature rows requested before any is consumed: 4 -> 126 / 123 registers = four workgroups per CU.  (Round 1 measured the
+    // deeper prefetch faster -- then 4 spilled; since the packed influences and 24-bit addressing of round 3 it fits and wins:
+    // 1542 / 1535 against 1521 / 1529 fragments/s, profiles/r03_experiments.txt x16.)
+#define D3F_KP_PF 4
+#ifndef D3F_KP_PF_H
+#define D3F_KP_PF_H 8          // bf16 feature rows (half the bytes per row)
+#endif
+    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF>, (const void*)kpconv_fused32_kernel<false, 8>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_KF(FAST_, PF_)                                                                                                   \
     kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
@@ -698,12 +757,12 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     if (feat_bf16) {      // bf16 feature storage (in and out); the shipped configuration only; no residual operand
         if (!kp_fast_config(num_kp, influence, aggregation) || residual) return D3F_ERR_ARG;
         static std::atomic<unsigned long long> lds_done_h{0};
-        const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, 8, unsigned short>};
+        const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short>};
         if (d3f_opt_in_lds(lds_done_h, fnh, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-        kpconv_fused32_kernel<true, 8, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
+        kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
             q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
     } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
-    else D3F_KF(true, 8);      // (the shallow-prefetch variant PF = 4 -- 128 registers, four workgroups per CU -- measured slower)
+    else D3F_KF(true, D3F_KP_PF);
 #undef D3F_KF
     D3F_LAUNCH_CHECK();
     return D3F_OK;
@@ -768,29 +827,23 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     for (int p = 0; p < KP_MAXP - 1; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (qslot < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    const int* idrow = idx + (qslot < Nq ? __umul24((unsigned)qg, (unsigned)ld_idx) : 0u);   // (rows, leading dimensions < 2^24)
+    const bool pair_lane = cl < KC && qslot < Nq;
+    KpPair pr = kp_pair_fetch(kp_pair_index(idrow, pair_lane, cl, K, Ns), Ns, s, rowpos);  // chunk 0's pair
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += KC) {
+        const int id_next = kp_pair_index(idrow, pair_lane, k0 + KC + cl, K, Ns);           // in flight during phase A
         {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
-            const int k = k0 + cl;
-            int id = Ns;
-            if (cl < KC && qslot < Nq && k < K) id = idx[(size_t)qg * ld_idx + k];
             float w[KP_MAXP];
-            bool positive = false;
-            if (id >= 0 && id < Ns) {
-                kp_influences_t<true>(P, s[3 * (size_t)id] - qx, s[3 * (size_t)id + 1] - qy, s[3 * (size_t)id + 2] - qz, w);
-                positive = rowpos[id] != 0;
-            } else {
-                id = -1;
-#pragma unroll
-                for (int p = 0; p < KP_MAXP; ++p) w[p] = 0.f;
-            }
+            const bool positive = kp_pair_influences<true>(P, pr, qx, qy, qz, w);
             kp_count_positive<LQ>(positive, ql, cl, lcnt);
             if (cl < KC) {
-                lidx[ql * KC + cl] = id;
+                lidx[ql * KC + cl] = pr.id;
                 kp_store_w(&lw[ql * WS + cl * 16], cl, w);
             }
         }
         __syncthreads();
+        pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                         // in flight during phase B
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3); PF feature rows requested before any is consumed ----
         const int kend = min(KC, K - k0);
         for (int kg = 0; kg < kend; kg += PF) {
@@ -799,11 +852,11 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                fv[u] = ids[u] >= 0 ? D3fFeat<FT>::ld4(&f[(size_t)ids[u] * ldf + 4 * cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = kp_gather4(f, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (ids[u] < 0) continue;   // shadow neighbour (or beyond K): influence 0, feature row 0
+                if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
                 kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
 #pragma unroll
@@ -944,10 +997,8 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
     if (Nq == 0) return D3F_OK;
     if (!q || !s || !idx || !f || !rowpos || !kp_host || !W_packed || !out || (((uintptr_t)f | (uintptr_t)W_packed) & 15))
         return D3F_ERR_ARG;
-    KpParams P;
-    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
-    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
-    P.aggregation = aggregation;
+    if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;     // (16.7 M rows per call: use d3f_kpconv_aggregate + d3f_gemm_f32)
+    const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const int blocks = d3f_cdiv(Nq, KG_TQ);
 #define D3F_KG(LQ_, PF_)                                                                                                    \
@@ -957,7 +1008,7 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
         const unsigned short* fh = (const unsigned short*)f_;
         unsigned short* oh = (unsigned short*)out_;
         if (Cin == 64)
-            kpconv_fused_kernel<16, 8, unsigned short><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+            kpconv_fused_kernel<16, D3F_KP_PF_H, unsigned short><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
         else if (Cin == 256)
             kpconv_fused_kernel<64, 4, unsigned short><<<blocks, KG_TQ * 64, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
@@ -965,7 +1016,7 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
         else
             kpconv_fused_kernel<32, 4, unsigned short><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
-    } else if (Cin == 64) D3F_KG(16, 8);
+    } else if (Cin == 64) D3F_KG(16, D3F_KP_PF);
     else if (Cin == 256) D3F_KG(64, 4);
     else D3F_KG(32, 4);
 #undef D3F_KG
@@ -1021,13 +1072,13 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
         return D3F_ERR_ARG;
     if (Nq == 0) return D3F_OK;
     if (!q || !s || !idx || !f || !rowpos || !kp_host || !wf || !inv_cnt) return D3F_ERR_ARG;
-    KpParams P;
-    for (int i = 0; i < KP_MAXP * 3; ++i) P.kp[i] = i < num_kp * 3 ? kp_host[i] : 0.f;
-    P.num_kp = num_kp; P.extent = KP_extent; P.inv_2extent = 1.0f / (2.0f * KP_extent); P.influence = influence;
-    P.aggregation = aggregation;
-    const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0);
+    const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
+    // (the vector kernels address rows with 24-bit multiplies; larger problems take the one-thread-per-output kernel)
+    const bool vec = (Cin % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)f & 15) == 0) && (((uintptr_t)wf & 15) == 0) &&
+                     kp_fits_u24(Nq, Ns, ld_idx, ldf);
     const bool fast = kp_fast_config(num_kp, influence, aggregation);
-    if (feat_bf16) {     // bf16 feature rows in, fp32 weighted features out; the deep layers of the shipped configuration
+    if (feat_bf16) {
+        if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;     // bf16 feature rows in, fp32 weighted features out; the deep layers of the shipped configuration
         const unsigned short* fh = (const unsigned short*)f_;
         if (!fast || (ldf % 4) || ((uintptr_t)f_ & 7) || ((uintptr_t)wf & 15) || !(Cin == 256 || Cin == 512)) return D3F_ERR_ARG;
         if (Cin == 256)
