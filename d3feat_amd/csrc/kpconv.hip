@@ -106,12 +106,8 @@ static inline KpParams kp_make_params(const float* kp_host, int num_kp, float KP
     P.aggregation = aggregation;
     return P;
 }
-// The gather kernels address feature / index rows with one 24-bit multiply (full rate; the 64-bit multiply-adds they replace are
-// quarter rate and were a tenth of the kernels' issue slots): row counts and leading dimensions must stay below 2^24.
-static inline bool kp_fits_u24(int Nq, int Ns, int ld_idx, int ldf) {
-    const int lim = 1 << 24;
-    return Nq < lim && Ns < lim && ld_idx < lim && ldf < lim && (long long)Ns * ldf < (1ll << 31) && (long long)Nq * ld_idx < (1ll << 31);
-}
+// (row addressing by one 24-bit multiply: common.h, d3f_fits_u24)
+static inline bool kp_fits_u24(int Nq, int Ns, int ld_idx, int ldf) { return d3f_fits_u24(Nq, ld_idx) && d3f_fits_u24(Ns, ldf); }
 // one 16-byte piece (channels c4 .. c4+3) of feature row `id`; a shadow neighbour (id < 0) reads row 0 instead -- its influences are
 // exactly 0, so whatever (finite) values arrive contribute nothing, and the load needs no branch, no select and no zero fill
 template <class FT>

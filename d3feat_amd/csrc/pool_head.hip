@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) maxpool_patch_kernel(const unsigned* __re
     }
 }
 
-template <int VEC, class FT = float>  // channels per thread (4: 16-byte loads; 1: generic)
+// U24: every row count / leading dimension fits the 24-bit addressing of common.h (d3f_fits_u24) -- the launcher decides
+template <int VEC, class FT = float, bool U24 = false>  // channels per thread (4: 16-byte loads; 1: generic)
 __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
                                                       unsigned* __restrict__ flag, FT* __restrict__ out, int ldo,
@@ -70,12 +71,14 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, 
     if (blockIdx.x >= nblk) return;                          // capacity-sized grid
     const long long t = (long long)d3f_xcd_tile(blockIdx.x, nblk) * 256 + threadIdx.x;   // one contiguous run of rows per XCD
     if (t >= (long long)N2 * CV) return;
-    const int slot = (int)(t / CV), c = (int)(t % CV) * VEC;
+    int slot, c;
+    if (U24) { const unsigned tu = (unsigned)t; slot = (int)(tu / (unsigned)CV); c = (int)(tu - (unsigned)slot * (unsigned)CV) * VEC; }
+    else { slot = (int)(t / CV); c = (int)(t % CV) * VEC; }
     const int n = row_order ? row_order[slot] : slot;   // spatially coherent visiting order (see kpconv.hip)
     float m[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) m[v] = -3.402823466e38f;
-    const int* row = idx + (size_t)n * ld_idx;
+    const int* row = U24 ? idx + __umul24((unsigned)n, (unsigned)ld_idx) : idx + (size_t)n * ld_idx;
     int nvalid = 0;
     for (int k0 = 0; k0 < K; k0 += 4) {
         int id[4];
@@ -87,12 +90,13 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, 
             const bool ok = id[j] >= 0 && id[j] < N1;
             nvalid += ok ? 1 : 0;
             if (ok) {
+                const FT* xr = U24 ? x + (__umul24((unsigned)id[j], (unsigned)ldx) + (unsigned)c) : x + ((size_t)id[j] * ldx + c);
                 if (VEC == 4) {
-                    const float4 f = D3fFeat<FT>::ld4(&x[(size_t)id[j] * ldx + c]);
+                    const float4 f = D3fFeat<FT>::ld4(xr);
                     val[j][0] = f.x; val[j][1 % VEC] = f.y; val[j][2 % VEC] = f.z; val[j][3 % VEC] = f.w;
                 } else {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) val[j][v] = D3fFeat<FT>::ld1(&x[(size_t)id[j] * ldx + c + v]);
+                    for (int v = 0; v < VEC; ++v) val[j][v] = D3fFeat<FT>::ld1(xr + v);
                 }
             } else {
 #pragma unroll
@@ -119,13 +123,18 @@ extern "C" int d3f_ind_max_pool(const void* x_, int N1, int ldx, int C, const in
     if (N2 == 0) return D3F_OK;
     if (!x || !idx || !out || !col_min_dev) return D3F_ERR_ARG;
     unsigned* cm = (unsigned*)col_min_dev;
+    const bool u24 = d3f_fits_u24(N1, ldx) && d3f_fits_u24(N2, ld_idx) && (long long)N2 * C < (1ll << 31);
     colmin_init_kernel<<<d3f_cdiv(C + 1, 256), 256, 0, stream>>>(cm, C);
     if (feat_bf16) {
         if (C % 4 || ldx % 4 || ((uintptr_t)x_ & 7)) return D3F_ERR_ARG;
         const unsigned short* xh = (const unsigned short*)x_;
         unsigned short* oh = (unsigned short*)out_;
-        maxpool_kernel<4, unsigned short><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(xh, N1, ldx, C, idx, N2, ld_idx, K,
-                                                                                                     cm + C, oh, ldo, N1_dev, N2_dev, row_order);
+        if (u24)
+            maxpool_kernel<4, unsigned short, true><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(
+                xh, N1, ldx, C, idx, N2, ld_idx, K, cm + C, oh, ldo, N1_dev, N2_dev, row_order);
+        else
+            maxpool_kernel<4, unsigned short><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(
+                xh, N1, ldx, C, idx, N2, ld_idx, K, cm + C, oh, ldo, N1_dev, N2_dev, row_order);
         if (N1 > 0) {
             int rows = d3f_cdiv(N1, 32);
             if (rows > 256) rows = 256;
@@ -137,7 +146,11 @@ extern "C" int d3f_ind_max_pool(const void* x_, int N1, int ldx, int C, const in
         D3F_LAUNCH_CHECK();
         return D3F_OK;
     }
-    if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
+    if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && u24)
+        maxpool_kernel<4, float, true><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
+                                                                                                   cm + C, out, ldo, N1_dev, N2_dev,
+                                                                                                   row_order);
+    else if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
         maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
                                                                                       cm + C, out, ldo, N1_dev, N2_dev,
                                                                                       row_order);
@@ -392,6 +405,7 @@ __global__ void __launch_bounds__(256) head32_rowflag_kernel(const float* __rest
     nz[n] = rs != 0.f ? 1 : 0;
 }
 
+template <bool U24>
 __global__ void __launch_bounds__(256)
 head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict__ idx, int ld_idx, int K,
               const int* __restrict__ offs, int B, const unsigned* __restrict__ mx, const unsigned char* __restrict__ nz,
@@ -409,7 +423,9 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
     const float4 yv = make_float4(xv.x * rden, xv.y * rden, xv.z * rden, xv.w * rden);
     float sq = xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
     sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (accumulated as two register pairs: v_pk_mul / v_pk_add_f32 -- the same multiply and add per element, half the issue slots)
+    typedef float hd_f2 __attribute__((ext_vector_type(2)));
+    hd_f2 sum01 = {0.f, 0.f}, sum23 = {0.f, 0.f};
     int cnt = 0;
     const int hbase = threadIdx.x & 32;
     for (int k0 = 0; k0 < K; k0 += 32) {
@@ -427,16 +443,22 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
                 const int kq = kk + u * 4 + slot;
                 id[u] = __shfl(mine, hbase + min(kq, 31), 64);
                 if (kq >= kn) id[u] = -1;
-                v[u] = *(const float4*)&x[(size_t)max(id[u], 0) * ldx + c4];
-                if (id[u] < 0) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                // a shadow slot reads row 0 (24-bit row addressing: common.h) and is multiplied by 0 instead of 1 / den below
+                const float* xr = U24 ? x + (__umul24((unsigned)max(id[u], 0), (unsigned)ldx) + (unsigned)c4)
+                                      : x + ((size_t)max(id[u], 0) * ldx + c4);
+                v[u] = *(const float4*)xr;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 // neighbours of a point belong to the point's own cloud (the searches are per batch element): same den
-                sum.x += v[u].x * rden; sum.y += v[u].y * rden; sum.z += v[u].z * rden; sum.w += v[u].w * rden;
+                const float r = id[u] < 0 ? 0.f : rden;
+                const hd_f2 r2 = {r, r}, v01 = {v[u].x, v[u].y}, v23 = {v[u].z, v[u].w};
+                sum01 = sum01 + v01 * r2;
+                sum23 = sum23 + v23 * r2;
             }
         }
     }
+    float4 sum = make_float4(sum01.x, sum01.y, sum23.x, sum23.y);
     // combine the four row slots (lanes l, l^8, l^16, l^24 hold the same channels)
     sum.x += __shfl_xor(sum.x, 8, 64); sum.y += __shfl_xor(sum.y, 8, 64); sum.z += __shfl_xor(sum.z, 8, 64); sum.w += __shfl_xor(sum.w, 8, 64);
     sum.x += __shfl_xor(sum.x, 16, 64); sum.y += __shfl_xor(sum.y, 16, 64); sum.z += __shfl_xor(sum.z, 16, 64); sum.w += __shfl_xor(sum.w, 16, 64);
@@ -487,7 +509,10 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
         // one flag byte per row, behind the 2 B + 2 scratch words
         unsigned char* nz = (unsigned char*)(scratch_dev + 2 * B + 2);
         head32_rowflag_kernel<<<d3f_cdiv(N, 256), 256, 0, stream>>>(x, N, ldx, offs, B, mx, nz);
-        head32_kernel<<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
+        if (d3f_fits_u24(N, ldx))
+            head32_kernel<true><<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
+        else
+            head32_kernel<false><<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
     }
     else if (C <= 32) head_kernel<1><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
     else if (C <= 64) head_kernel<2><<<blocks, 256, 0, stream>>>(x, N, ldx, C, idx, ld_idx, K, offs, B, mx, desc, ldd, score, row_order);
