@@ -211,7 +211,10 @@ int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int
  * exists -- Cin = 256 -- but aggregation + contraction measured no slower; 0: not available); otherwise use
  * d3f_kpconv_aggregate + d3f_gemm_f32.  W_packed: K_values [15*Cin, Cout] reordered once by d3f_kpconv_pack_weights
  * (Wp[blk][g][n][j] = W[16*blk + 4*g + j][n]: the MFMA B-operand order, one 16-byte load per lane and k-block).
- * Arguments otherwise as d3f_kpconv_fused32. */
+ * Arguments otherwise as d3f_kpconv_fused32.
+ * Size limit of the one-kernel forms (d3f_kpconv_fused32 / d3f_kpconv_fused): rows are addressed with 24-bit multiplies, so
+ * Nq, Ns, ld_idx, ldf < 2^24 and Nq * ld_idx, Ns * ldf < 2^31, else D3F_ERR_ARG (d3f_kpconv_aggregate + d3f_gemm_f32 have no
+ * such limit: beyond it they take their generic kernel). */
 int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int influence, int aggregation);
 int d3f_kpconv_pack_weights(const float* W, int K, int N, float* W_packed, void* stream);
 int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
