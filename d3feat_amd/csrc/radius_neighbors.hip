@@ -1,4 +1,4 @@
-// Fixed-radius neighbour search on gfx950: uniform cell grid + 32 lanes (half a wavefront) per query.
+// Fixed-radius neighbour search on gfx950: uniform cell grid + 16 / 32 lanes (a quarter / half of a wavefront) per query.
 //
 // Reference: tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:211-332 (batch_nanoflann_neighbors, the active
 // path: KD-tree radiusSearch, rows sorted by d2) and :125-208 (batch_ordered_neighbors: brute force, stable).
@@ -15,7 +15,8 @@
 //           scan -> scatter into a float4 {x,y,z,index-bits} array: one 16-byte load per candidate, x-adjacent cells are
 //           contiguous, so the 27-cell stencil is 9 contiguous runs.  The sorted index array doubles as a spatially
 //           coherent visiting order for every per-point kernel of the level;
-//   search (1 launch): LPQ = 32 lanes per query (two queries per wavefront) walk the 9 runs as one virtual list, two
+//   search (1 launch): LPQ = 32 lanes per query (two queries per wavefront; 16 lanes = four queries per wavefront for launches of
+//           >= 100 k queries, where the rounds of resident wavefronts dominate) walk the 9 runs as one virtual list, four (eight)
 //           candidate loads in flight per lane; hits are compacted into the group's LDS segment with a ballot + popcount
 //           prefix (variable-length lists); the <= cap hits are ordered by rank counting (each lane counts how many hits
 //           precede its own, four per 128-bit LDS read -- keys are unique so ranks are a permutation) and the first `width`
@@ -181,6 +182,44 @@ __device__ __forceinline__ void nb_bitonic64(int lane, unsigned& h0, unsigned& l
 #undef NB_STAGE
 }
 
+// The same 64-key network for a 16-lane group, four keys per lane: element e = 16 * slot + lane.  Partners at distance 1 / 2 via
+// DPP, 4 / 8 via ds_swizzle, 16 / 32 are the lane's own other slots (register compare-exchange, no cross-lane traffic).
+__device__ __forceinline__ void nb_cmpx_own(unsigned& ha, unsigned& la, unsigned& hb, unsigned& lb, bool ascending) {
+    const bool b_less = (hb < ha) || (hb == ha && lb < la);
+    const bool swap = (b_less == ascending);        // ascending: the smaller key ends in a
+    const unsigned th = swap ? hb : ha, tl = swap ? lb : la;
+    hb = swap ? ha : hb; lb = swap ? la : lb;
+    ha = th; la = tl;
+}
+__device__ __forceinline__ void nb_bitonic64x16(int lane, unsigned (&h)[4], unsigned (&l)[4]) {
+    // direction of element e in the merge of size K: ascending iff (e & K) == 0 (K = 64: always)
+#define NB_UP(K_, S_) (((K_) == 64) ? true : ((K_) >= 16 ? ((((S_) * 16) & (K_)) == 0) : ((lane & (K_)) == 0)))
+#define NB_XSTAGE(K_, J_)                                                                        \
+    do {                                                                                         \
+        const bool low_ = (lane & (J_)) == 0;                                                    \
+        nb_cmpx<J_>(h[0], l[0], NB_UP(K_, 0) == low_);                                           \
+        nb_cmpx<J_>(h[1], l[1], NB_UP(K_, 1) == low_);                                           \
+        nb_cmpx<J_>(h[2], l[2], NB_UP(K_, 2) == low_);                                           \
+        nb_cmpx<J_>(h[3], l[3], NB_UP(K_, 3) == low_);                                           \
+    } while (0)
+    NB_XSTAGE(2, 1);
+    NB_XSTAGE(4, 2); NB_XSTAGE(4, 1);
+    NB_XSTAGE(8, 4); NB_XSTAGE(8, 2); NB_XSTAGE(8, 1);
+    NB_XSTAGE(16, 8); NB_XSTAGE(16, 4); NB_XSTAGE(16, 2); NB_XSTAGE(16, 1);
+    // K = 32: distance 16 = slots (0,1) ascending, (2,3) descending
+    nb_cmpx_own(h[0], l[0], h[1], l[1], true);
+    nb_cmpx_own(h[2], l[2], h[3], l[3], false);
+    NB_XSTAGE(32, 8); NB_XSTAGE(32, 4); NB_XSTAGE(32, 2); NB_XSTAGE(32, 1);
+    // K = 64: distance 32 = slots (0,2), (1,3); distance 16 = (0,1), (2,3); all ascending
+    nb_cmpx_own(h[0], l[0], h[2], l[2], true);
+    nb_cmpx_own(h[1], l[1], h[3], l[3], true);
+    nb_cmpx_own(h[0], l[0], h[1], l[1], true);
+    nb_cmpx_own(h[2], l[2], h[3], l[3], true);
+    NB_XSTAGE(64, 8); NB_XSTAGE(64, 4); NB_XSTAGE(64, 2); NB_XSTAGE(64, 1);
+#undef NB_XSTAGE
+#undef NB_UP
+}
+
 template <bool FIRST_ONLY, int LPQ, bool HINT>
 __device__ __forceinline__ void
 nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
@@ -251,19 +290,19 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
         zl = max(zl, (int)floor(((double)qz - h - e.mn[2]) * e.inv_h)); zh = min(zh, (int)floor(((double)qz + h - e.mn[2]) * e.inv_h));
     }
     const int x0 = max(xl, 0), x1 = min(xh, e.dims[0] - 1);
-    // lanes 0..8: run start, lanes 9..17: run end, of the 9 (y,z) rows of the stencil
-    int bound = 0;
-    if (lane < 18) {
-        const int j = lane < 9 ? lane : lane - 9;
+    // lanes 0..8: start and end of the 9 (y,z) rows of the stencil (both fetched by the run's lane: one round trip, and the
+    // 16-lane form of the kernel has no lanes 9..17 to hold the ends)
+    int bound = 0, len_l = 0;
+    if (lane < 9) {
+        const int j = lane;
         const int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
         if (x0 <= x1 && y >= max(yl, 0) && y <= min(yh, e.dims[1] - 1) && z >= max(zl, 0) && z <= min(zh, e.dims[2] - 1)) {
             const int rowbase = e.cbase + e.dims[0] * (y + e.dims[1] * z);
-            bound = d3f_scan_at(cell_start, cell_base, rowbase + (lane < 9 ? x0 : x1 + 1));
+            bound = d3f_scan_at(cell_start, cell_base, rowbase + x0);
+            len_l = d3f_scan_at(cell_start, cell_base, rowbase + x1 + 1) - bound;
         }
     }
-    static_assert(LPQ >= 32, "the 18 run bounds live in one lane group");
-    const int hi_l = __shfl_down(bound, 9, LPQ);
-    const int len_l = (lane < 9) ? hi_l - bound : 0;
+    static_assert(LPQ >= 16, "the 9 runs of the stencil live in one lane group");
     // group-uniform run offsets: off[j] = lo[j] - prefix[j]; prefix kept for the lane -> run test
     int pre[10], off[9];
     pre[0] = 0;
@@ -281,7 +320,7 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
     // four candidate loads in flight per lane (a typical query's ~120 candidates in ONE round trip): the loads of consecutive
     // steps are independent, only the hit compaction is sequential.  Straight-line loads: a lane beyond the list re-reads
     // the list's first candidate (address clamp) instead of branching around the load.
-    constexpr int NLD = 4;
+    constexpr int NLD = LPQ == 16 ? 8 : 4;      // (16 lanes per query: the same ~128 candidates per round trip)
     for (int v0 = 0; v0 < T; v0 += NLD * LPQ) {
         float4 sp[NLD];
         bool in[NLD];
@@ -348,6 +387,21 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
     if (m + lane < m4) { hd2[m + lane] = 3.4e38f; hidx[m + lane] = 0x7fffffff; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (LPQ == 16 && n <= 64 && cap >= 64) {      // group-uniform: the common case goes through the register network
+        unsigned h[4], l4[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            h[sl] = 0xFFFFFFFFu; l4[sl] = 0xFFFFFFFFu;
+            if (lane + 16 * sl < m) { h[sl] = __float_as_uint(hd2[lane + 16 * sl]); l4[sl] = (unsigned)hidx[lane + 16 * sl]; }
+        }
+        nb_bitonic64x16(lane, h, l4);
+        const int mw = min(m, width);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (lane + 16 * sl < mw) row[lane + 16 * sl] = (int)l4[sl];
+        for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
+        return;
+    }
     if (LPQ == 32 && n <= 64 && cap >= 64) {      // group-uniform: the common case goes through the register network
         unsigned h0 = 0xFFFFFFFFu, l0 = 0xFFFFFFFFu, h1 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu;
         if (lane < m) { h0 = __float_as_uint(hd2[lane]); l0 = (unsigned)hidx[lane]; }
@@ -499,7 +553,12 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     const int* qorder = queries_are_supports ? g.order : nullptr;
     // lanes per query: 32 (two queries per wavefront) unless the ordering budget is large (rare, dense clouds)
     cap = (cap + 3) & ~3;   // LDS segments are read four hits at a time
-    const int lpq = cap > 256 ? 64 : 32;
+    // lanes per query.  The kernel runs at full occupancy and costs (rounds of resident wavefronts) x (a chain of ~4 dependent
+    // round trips): 16 lanes per query -- four queries per wavefront, eight candidate loads in flight per lane, four keys per lane
+    // in the ordering network -- halves the rounds of a large launch (level 0 at F = 4: 111 -> 95 us, nearest-only 77 -> 63 us)
+    // but lengthens the chain of a launch that is less than a round anyway (levels 2-4: 17 -> 21-29 us), so it is chosen by size
+    // (profiles/r03_experiments.txt x19); 64 lanes only for the large ordering budget.
+    const int lpq = cap > 256 ? 64 : (Nq >= 100000 ? 16 : 32);
     const int qpb = 64 * NB_WAVES_PER_BLOCK / lpq;
     const int blocks = d3f_cdiv(Nq, qpb);
     const size_t lds = first_only ? 0 : (size_t)qpb * cap * 2 * sizeof(float);
@@ -513,8 +572,8 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     nb_search_kernel<FO_, LPQ_, false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                               \
         queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
         kcap, status_dev, want_kmax, nn_hint)
-    if (first_only) { if (lpq == 64) D3F_NB(true, 64); else D3F_NB(true, 32); }
-    else { if (lpq == 64) D3F_NB(false, 64); else D3F_NB(false, 32); }
+    if (first_only) { if (lpq == 64) D3F_NB(true, 64); else if (lpq == 32) D3F_NB(true, 32); else D3F_NB(true, 16); }
+    else { if (lpq == 64) D3F_NB(false, 64); else if (lpq == 32) D3F_NB(false, 32); else D3F_NB(false, 16); }
 #undef D3F_NB
     D3F_LAUNCH_CHECK();
     return D3F_OK;

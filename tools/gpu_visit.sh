@@ -53,6 +53,7 @@ prof1)   # ONE replay in flight: kernel durations without the other streams' ker
     python tools/rocpd_summary.py --timed-region --fragments 32 $DB > $OUT/kernel_stats_one_replay_in_flight.csv
     head -40 $OUT/kernel_stats_one_replay_in_flight.csv | cut -c1-150
     python tools/gs_timeline.py $DB 2 34
+    [ -n "$PROF1_BYGRID" ] && python tools/kernel_by_grid.py $DB "$PROF1_BYGRID"
   fi
   rm -rf $OUT/prof1/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
 pmc)
