@@ -320,7 +320,8 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
     // four candidate loads in flight per lane (a typical query's ~120 candidates in ONE round trip): the loads of consecutive
     // steps are independent, only the hit compaction is sequential.  Straight-line loads: a lane beyond the list re-reads
     // the list's first candidate (address clamp) instead of branching around the load.
-    constexpr int NLD = LPQ == 16 ? 8 : 4;      // (16 lanes per query: the same ~128 candidates per round trip)
+    constexpr int NLD = (LPQ == 16 && !FIRST_ONLY) ? 8 : 4;   // (16 lanes per query: the same ~128 candidates per round trip;
+                                                               //  the nearest-only scan visits 8 cells, ~35 candidates)
     for (int v0 = 0; v0 < T; v0 += NLD * LPQ) {
         float4 sp[NLD];
         bool in[NLD];
