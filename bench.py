@@ -58,8 +58,9 @@ def parse():
     ap.add_argument("--slots", type=int, default=4, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
     ap.add_argument("--batch", type=int, default=0,
                     help="fragments stacked into one graph replay (FragmentEngine(batch=F)); a step is still ONE fragment.  "
-                         "0 = by job size: 8 from 256 fragments on (1479 against 1445 fragments/s at 4, profiles/r03_experiments.txt x3), "
-                         "4 from 64, or for a job shorter than 64 fragments ceil(steps / slots) (at most 8) so that the "
+                         "0 = by job size: 12 from 384 fragments on (1591 / 1586 against 1558 / 1578 fragments/s at 8 and 1569 / 1570 at 16, "
+                         "profiles/r03_experiments.txt x22), 8 from 64 (96 fragments: 1540 against 1475 at 4), or for a job shorter "
+                         "than 64 fragments ceil(steps / slots) (at most 8) so that the "
                          "whole job is one round of replays, all in flight together, instead of a round plus a lone straggler")
     ap.add_argument("--cap-factor", type=float, default=1.1,
                     help="voxel capacity of a slot = this x the largest fragment of the pool.  Launches are sized by capacity, so slack "
@@ -148,7 +149,7 @@ def main():
     if args.bf16_features:
         args.bf16 = True
     if args.batch <= 0:
-        args.batch = (8 if args.steps >= 256 else 4) if args.steps >= 64 else max(1, min(8, -(-args.steps // max(args.slots, 1))))
+        args.batch = (12 if args.steps >= 384 else 8) if args.steps >= 64 else max(1, min(8, -(-args.steps // max(args.slots, 1))))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
