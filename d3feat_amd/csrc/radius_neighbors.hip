@@ -33,7 +33,7 @@ struct NbElem {
 };
 
 #define NB_WAVES_PER_BLOCK 4
-#define NB_EL_LDS 18      // batch elements whose grid geometry fits the search kernel's LDS copy (256 threads x 4 bytes / 56)
+#define NB_EL_LDS 40      // batch elements whose grid geometry the search kernel copies to LDS (56 bytes each; 16 fragments = 32 clouds)
 
 // one thread per element: choose the cell edge (>= radius*(1+2^-20); doubled until the element's grid fits
 // its share of the cell budget), grid dims and cell base.
@@ -239,7 +239,7 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
     __shared__ NbElem sel[NB_EL_LDS];
     if (B <= NB_EL_LDS) {
         constexpr int W = (int)(sizeof(NbElem) / sizeof(int));
-        if ((int)threadIdx.x < B * W) ((int*)sel)[threadIdx.x] = ((const int*)el)[threadIdx.x];
+        for (int i = threadIdx.x; i < B * W; i += blockDim.x) ((int*)sel)[i] = ((const int*)el)[i];
         __syncthreads();
     }
     int nq_real = 0;
