@@ -742,9 +742,7 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     // deeper prefetch faster -- then 4 spilled; since the packed influences and 24-bit addressing of round 3 it fits and wins:
     // 1542 / 1535 against 1521 / 1529 fragments/s, profiles/r03_experiments.txt x16.)
 #define D3F_KP_PF 4
-#ifndef D3F_KP_PF_H
-#define D3F_KP_PF_H 8          // bf16 feature rows (half the bytes per row)
-#endif
+#define D3F_KP_PF_H 4          // the same for bf16 feature rows (120 registers): 202 -> 178 us and 112 -> 99 us per launch (x24)
     const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF>, (const void*)kpconv_fused32_kernel<false, 8>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_KF(FAST_, PF_)                                                                                                   \
