@@ -88,6 +88,17 @@ def test_host_side_argument_checks_need_no_gpu(lib):
     assert lib.d3f_grid_subsample_workspace_bytes(30000, 2, 0, 0) > 30000 * 4 * 14
     assert lib.d3f_gemm_workspace_bytes(390, 512, 7680, 0) >= 256
     assert lib.d3f_neighbor_grid_bytes(60000, 2) > 60000 * 16
+    # the one-kernel KPConv forms address rows with 24-bit multiplies: row counts / leading dimensions beyond that are refused
+    # before anything is launched (include/d3feat_amd.h; the two-kernel form has no such limit)
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.addressof(buf)
+    kp = (ctypes.c_float * 45)()
+    args = lambda Nq, Ns, ld_idx, ldf: (p, Nq, p, Ns, p, ld_idx, 8, p, ldf, p, ctypes.addressof(kp), 15, 0.05, 1, 0, p, None, None, None, 0, 1, 0.2,
+                                        p, 32, None, None, None, 0, None)
+    assert lib.d3f_kpconv_fused32(*args(100, 1 << 24, 8, 32)) == -3
+    assert lib.d3f_kpconv_fused32(*args(100, 1 << 20, 8, 1 << 12)) == -3        # Ns * ldf >= 2^31
+    assert lib.d3f_kpconv_fused32(*args(1 << 24, 100, 8, 32)) == -3
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
