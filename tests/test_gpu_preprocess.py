@@ -181,3 +181,34 @@ def test_first_only_hint_never_changes_the_result(device, hint_scale):
     assert torch.equal(plain[:, 0], full[:, 0])
     assert torch.equal(hinted, plain)
     assert int((plain[:, 0] == 30000).sum()) > 0          # queries without any support inside the radius are padded
+
+
+def test_large_query_sets_take_the_16_lane_form_and_equal_the_oracle(device, coracle):
+    """Launches of >= 100 k queries run the search kernel with 16 lanes per query (four queries per wavefront, the 64-key ordering
+    network with four keys per lane; csrc/radius_neighbors.hip): four surface clouds of ~30 k points, (a) queries = supports (the
+    convolution matrices), (b) another query set of the same size against them (the pooling matrices), both against the oracle
+    row for row; (c) the nearest-only search (upsampling matrices) equals column 0 of the full search, with and without the
+    distance hint; exact ties (duplicated supports) are ordered by index in every form."""
+    from d3feat_amd import ops, tf_custom_ops as tfo
+    from d3feat_amd.utils.synthetic import room_fragment
+    clouds = [coracle.grid_subsampling(room_fragment(700 + i, n_raw=260000 + 15000 * i), 0.03) for i in range(4)]
+    lens = np.asarray([len(c) for c in clouds], np.int32)
+    s = np.concatenate(clouds).astype(np.float32)
+    assert s.shape[0] >= 100000, s.shape
+    s[5000:5040] = s[5000]                                 # exact ties
+    r = np.float32(0.075)
+    want = coracle.batch_neighbors(s, s, lens, lens, r)
+    got = tfo.batch_ordered_neighbors(_t(s, device), _t(s, device), _t(lens, device), _t(lens, device), r).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    rng = np.random.default_rng(5)
+    q = (s + rng.normal(0.0, 0.02, s.shape)).astype(np.float32)
+    want_q = coracle.batch_neighbors(q, s, lens, lens, r)
+    got_q = tfo.batch_ordered_neighbors(_t(q, device), _t(s, device), _t(lens, device), _t(lens, device), r).cpu().numpy()
+    assert got_q.shape == want_q.shape and np.array_equal(got_q, want_q)
+    grid = ops.NeighborGrid(_t(s, device), lens.tolist(), r)
+    full, _ = grid.search(_t(q, device), lens.tolist(), want_q.shape[1])
+    plain, _ = grid.search(_t(q, device), lens.tolist(), 1, first_only=True)
+    hinted, _ = grid.search(_t(q, device), lens.tolist(), 1, first_only=True, nn_hint=float(0.6 * r))
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy(), want_q)
+    assert torch.equal(plain[:, 0], full[:, 0]) and torch.equal(hinted, plain)
