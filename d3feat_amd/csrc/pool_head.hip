@@ -80,13 +80,15 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, 
     for (int v = 0; v < VEC; ++v) m[v] = -3.402823466e38f;
     const int* row = U24 ? idx + __umul24((unsigned)n, (unsigned)ld_idx) : idx + (size_t)n * ld_idx;
     int nvalid = 0;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        int id[4];
-        float val[4][VEC];
+    constexpr int NB = 8;        // neighbour rows requested per batch (the kernel is rounds x dependent round trips at full
+                                 // occupancy with 30 registers: eight loads in flight still fit 8 waves per SIMD)
+    for (int k0 = 0; k0 < K; k0 += NB) {
+        int id[NB];
+        float val[NB][VEC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) id[j] = (k0 + j < K) ? row[k0 + j] : -2;
+        for (int j = 0; j < NB; ++j) id[j] = (k0 + j < K) ? row[k0 + j] : -2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const bool ok = id[j] >= 0 && id[j] < N1;
             nvalid += ok ? 1 : 0;
             if (ok) {
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, 
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], val[j][v]);
     }
