@@ -55,6 +55,24 @@ def all_gather_into(out, inp, async_op=False):
     return dist.all_gather_into_tensor(out, inp, async_op=async_op)
 
 
+def exchange_into(out, inp, dst=None, async_op=False):
+    """The payload exchange of the path.  dst=None: every rank receives every rank's `inp` (all_gather into `out`
+    [ranks * rows, W]).  dst=r: ONLY rank r receives (dist.gather -- under RCCL one point-to-point xGMI transfer per peer into
+    the matching slice of `out`, nothing lands on the other ranks, whose `out` is None): BASELINE.json north_star's "gather of
+    descriptors only at the end".  -> work handle or None."""
+    if dst is None:
+        return all_gather_into(out, inp, async_op=async_op)
+    rank, ws = world()
+    if inp.is_cuda and _host_staged():
+        h_out = torch.empty((ws,) + tuple(inp.shape), dtype=inp.dtype) if rank == dst else None
+        dist.gather(inp.cpu(), list(h_out.unbind(0)) if rank == dst else None, dst=dst)
+        if rank == dst:
+            out.view((ws,) + tuple(inp.shape)).copy_(h_out)
+        return None
+    glist = list(out.view((ws,) + tuple(inp.shape)).unbind(0)) if rank == dst else None
+    return dist.gather(inp, glist, dst=dst, async_op=async_op)
+
+
 def allreduce_histograms(hists, device=None):
     """Sum int64 histograms [layers, bins] over ranks (no-op for a single process)."""
     rank, ws = world()
@@ -95,17 +113,25 @@ class ShardCollector:
     (ops.pack_descriptors) plus the row count of every fragment.  `add` is one contiguous device-to-device copy (plumbing,
     issued on the current stream); `gather` is the path's only data collective.
 
+    dst: who receives the shards.  None = every rank (all_gather: O(ranks) receive memory on every rank); an int = that rank
+    only (the default of bench.py / runner.py: rank 0 -- north_star's "gather of descriptors only at the end"; the other ranks
+    allocate no receive memory and `gather` returns (None, frag_rows) for the shards they did not receive).
+
     chunk_frags > 0 (with frag_rows = the row capacity of one fragment's contribution): OVERLAPPED mode.  Fragment k lives at
     the fixed rows [k * frag_rows, ...), so no size has to be agreed on before data moves: after every `chunk_frags` fragments
-    the finished chunk is all-gathered asynchronously (RCCL runs it on its own stream behind the compute; point-to-point
-    xGMI: 7 peers x one 4.2 MB-per-fragment message), `gather` only waits, sends the last partial chunk and exchanges the row
-    counts.  The end-of-run exchange of a whole shard -- ~10 % of the timed region on 8 GPUs when done at once -- is hidden."""
+    the finished chunk is exchanged asynchronously (RCCL runs it on its own stream behind the compute; point-to-point xGMI:
+    one 4.2 MB-per-fragment message per peer), `gather` only waits, sends the last partial chunk and exchanges the row counts.
+    Chunk c of every rank lands in row block c of ONE receive buffer allocated once (grown by doubling; only on receiving
+    ranks) -- no allocation per chunk.  A fragment larger than the stride (the engine's eager fallback of an oversize cloud
+    returns more rows than its capacity) is kept aside and exchanged by one trailing variable-length collective that every rank
+    enters iff any rank holds such a fragment -- the receivers recognise it by its row count > stride."""
 
-    def __init__(self, rows_cap, width=36, device=None, chunk_frags=0, frag_rows=0, async_chunks=None):
+    def __init__(self, rows_cap, width=36, device=None, chunk_frags=0, frag_rows=0, async_chunks=None, dst=None):
         # async_chunks: how many chunks are exchanged WHILE fragments are produced.  Collectives must be issued in the same
         # order on every rank, so with shards of different lengths (LPT partition) pass min over ranks of n_r // chunk_frags
         # (every rank can compute it: the partition is deterministic); None = no limit (equal shards: bench.py)
         self.async_chunks = async_chunks
+        self.dst = dst
         self.chunk_frags, self.frag_rows_cap = int(chunk_frags), int(frag_rows)
         if self.chunk_frags > 0:
             assert self.frag_rows_cap > 0
@@ -114,33 +140,42 @@ class ShardCollector:
         self.buf = torch.empty((int(rows_cap), int(width)), dtype=torch.float32, device=device)
         self.rows = 0
         self.frag_rows = []
-        self._works, self._chunks = [], []
+        self._works = []
+        self._recv_chunks = None       # [chunk capacity, ranks * chunk rows, W] on receiving ranks
+        self._over = []                # records of the fragments larger than the stride, in order
+
+    def receives(self):
+        return self.dst is None or world()[0] == self.dst
 
     def reset(self):
         for w in self._works:
             if w is not None:
                 w.wait()
         self.rows, self.frag_rows = 0, []
-        self._works, self._chunks = [], []
+        self._works, self._over = [], []
 
     def _grow(self, need):
         grown = torch.empty((max(2 * self.buf.shape[0], need), self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
         grown[: self.rows].copy_(self.buf[: self.rows])
         self.buf = grown
 
+    def _wait_all(self):
+        for w in self._works:
+            if w is not None:
+                w.wait()
+
     def add(self, packed):
         n = int(packed.shape[0])
         if self.chunk_frags > 0:
             k, R = len(self.frag_rows), self.frag_rows_cap
-            if n > R:
-                raise ValueError("ShardCollector: a fragment of %d rows exceeds the fixed stride %d" % (n, R))
             if (k + 1) * R > self.buf.shape[0]:
-                for w in self._works:          # the chunks in flight read the old buffer
-                    if w is not None:
-                        w.wait()
+                self._wait_all()               # the chunks in flight read the old buffer
                 self.rows = k * R
                 self._grow((k + self.chunk_frags) * R)
-            self.buf[k * R:k * R + n].copy_(packed, non_blocking=True)
+            if n > R:
+                self._over.append(packed.clone())      # its slot stays unused; exchanged by the trailing collective
+            else:
+                self.buf[k * R:k * R + n].copy_(packed, non_blocking=True)
             self.frag_rows.append(n)
             self.rows = (k + 1) * R
             if (k + 1) % self.chunk_frags == 0 and (self.async_chunks is None or len(self._works) < self.async_chunks):
@@ -152,26 +187,41 @@ class ShardCollector:
         self.rows += n
         self.frag_rows.append(n)
 
+    def _recv_block(self, c):
+        """Row block c of the receive buffer (receiving ranks only)."""
+        ws = world()[1]
+        rows = self.chunk_frags * self.frag_rows_cap
+        cap = 0 if self._recv_chunks is None else self._recv_chunks.shape[0]
+        if c >= cap:
+            self._wait_all()                   # chunks in flight write the old buffer
+            ncap = max(2 * cap, c + 1, self.buf.shape[0] // rows)
+            grown = torch.empty((ncap, ws * rows, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
+            if cap:
+                grown[:cap].copy_(self._recv_chunks)
+            self._recv_chunks = grown
+        return self._recv_chunks[c]
+
     def _launch_chunk(self, c, async_op):
         ws = world()[1]
         if ws == 1:
             return
         rows = self.chunk_frags * self.frag_rows_cap
-        recv = torch.empty((ws * rows, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
-        self._chunks.append(recv)
-        self._works.append(all_gather_into(recv, self.buf[c * rows:(c + 1) * rows], async_op=async_op))
+        recv = self._recv_block(c) if self.receives() else None
+        self._works.append(exchange_into(recv, self.buf[c * rows:(c + 1) * rows], dst=self.dst, async_op=async_op))
 
     def records(self):
         if self.chunk_frags > 0:
             R = self.frag_rows_cap
-            parts = [self.buf[k * R:k * R + n] for k, n in enumerate(self.frag_rows)]
+            over = iter(self._over)
+            parts = [self.buf[k * R:k * R + n] if n <= R else next(over) for k, n in enumerate(self.frag_rows)]
             return torch.cat(parts) if parts else self.buf[:0]
         return self.buf[: self.rows]
 
     def gather(self, compact=True):
-        """-> list over ranks of (records, frag_rows).  Plain mode: the receive buffer is sized for what the ranks actually hold
-        and kept (views of it are returned: valid until the next gather), so a repeated timed gather allocates nothing.
-        Overlapped mode: waits for the chunks in flight, sends the last partial chunk, exchanges the row counts; compact=False
+        """-> list over ranks of (records, frag_rows); records is None for a shard this rank did not receive (dst mode).
+        Plain mode: the receive buffer is sized for what the ranks actually hold and kept (views of it are returned: valid until
+        the next gather), so a repeated timed gather allocates nothing.  Overlapped mode: waits for the chunks in flight, sends
+        the last partial chunk, exchanges the row counts (and the oversize fragments, if any rank has one); compact=False
         returns each rank's records as a LIST of per-fragment views (no compaction copy)."""
         if self.chunk_frags > 0:
             return self._gather_chunked(compact)
@@ -180,13 +230,14 @@ class ShardCollector:
             if getattr(self, "_recv", None) is None or self._recv.shape[0] < rows_total:
                 self._recv = torch.empty((rows_total, self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
             return self._recv[:rows_total]
-        return gather_shard(self.records(), self.frag_rows, backing=self.buf, receive=receive)
+        return gather_shard(self.records(), self.frag_rows, backing=self.buf, receive=receive, dst=self.dst)
 
     def _gather_chunked(self, compact):
         rank, ws = world()
         C, R = self.chunk_frags, self.frag_rows_cap
         if ws == 1:
-            parts = [self.buf[k * R:k * R + n] for k, n in enumerate(self.frag_rows)]
+            over = iter(self._over)
+            parts = [self.buf[k * R:k * R + n] if n <= R else next(over) for k, n in enumerate(self.frag_rows)]
             return [((torch.cat(parts) if parts else self.buf[:0]) if compact else parts, list(self.frag_rows))]
         dev = self.buf.device
         nf = torch.tensor([len(self.frag_rows)], dtype=torch.int64, device=dev)
@@ -197,41 +248,64 @@ class ShardCollector:
         # ranks hold different numbers of fragments (LPT shards): every rank takes part in ceil(fmax / C) chunk collectives
         nch = -(-fmax // C)
         if nch * C * R > self.buf.shape[0]:
-            for w in self._works:
-                if w is not None:
-                    w.wait()
+            self._wait_all()
             self.rows = len(self.frag_rows) * R
             self._grow(nch * C * R)
         for c in range(len(self._works), nch):
             self._launch_chunk(c, async_op=False)
-        for w in self._works:
-            if w is not None:
-                w.wait()
+        self._wait_all()
         fr = torch.zeros((fmax,), dtype=torch.int64, device=dev)
         if self.frag_rows:
             fr[: len(self.frag_rows)] = torch.tensor(self.frag_rows, dtype=torch.int64).to(dev)
         frs = torch.empty((ws * fmax,), dtype=torch.int64, device=dev)
-        all_gather_into(frs, fr)
+        all_gather_into(frs, fr)                      # the row counts go to every rank (a few bytes): all agree on what follows
         frs = frs.view(ws, fmax).tolist()
+        # ---- trailing exchange of the fragments larger than the stride: entered by every rank iff any rank holds one
+        over_rows = [[int(v) for v in frs[r][: nfs[r]] if v > R] for r in range(ws)]
+        over_recv = None
+        omax = max(sum(o) for o in over_rows)
+        if omax > 0:
+            payload = torch.zeros((omax, self.buf.shape[1]), dtype=torch.float32, device=dev)
+            if self._over:
+                mine = torch.cat(self._over)
+                payload[: mine.shape[0]] = mine
+            over_recv = torch.empty((ws * omax, self.buf.shape[1]), dtype=torch.float32, device=dev) if self.receives() else None
+            exchange_into(over_recv, payload, dst=self.dst)
+            if over_recv is not None:
+                over_recv = over_recv.view(ws, omax, -1)
         out = []
         for r in range(ws):
-            parts = []
-            for k in range(nfs[r]):
-                ch = self._chunks[k // C].view(ws, C * R, -1)[r]
-                parts.append(ch[(k % C) * R:(k % C) * R + int(frs[r][k])])
             rows = [int(v) for v in frs[r][: nfs[r]]]
+            if not self.receives() and r != rank:
+                out.append((None, rows))
+                continue
+            parts, oo = [], 0
+            local_over = iter(self._over)
+            for k, n in enumerate(rows):
+                if n > R:
+                    if r == rank and over_recv is None:
+                        parts.append(next(local_over))
+                    else:
+                        parts.append(over_recv[r, oo:oo + n])
+                    oo += n
+                elif r == rank and not self.receives():
+                    parts.append(self.buf[k * R:k * R + n])
+                else:
+                    ch = self._recv_chunks[k // C].view(ws, C * R, -1)[r]
+                    parts.append(ch[(k % C) * R:(k % C) * R + n])
             out.append(((torch.cat(parts) if parts else self.buf[:0]) if compact else parts, rows))
         return out
 
 
-def gather_shard(records, frag_rows, backing=None, receive=None):
-    """Variable-length all_gather of every rank's WHOLE shard: records f32[rows, W] (rows differ per rank) and the
-    per-fragment row counts.  Sizes first, then ONE payload collective into one [ranks * rows_max, W] tensor
-    (all_gather_into_tensor: RCCL over xGMI on GPUs, gloo on CPU tensors; no per-rank staging copies).  `backing`: the
-    buffer `records` is the head of -- when it holds rows_max rows the payload is sent from it in place (the rows past
-    this rank's count are never read by the receiver), otherwise the records are padded into a fresh buffer.  `receive(rows)`
-    -> contiguous f32[rows, W] to receive into (default: a fresh tensor).
-    -> list over ranks of (records f32[rows_r, W], frag_rows list)."""
+def gather_shard(records, frag_rows, backing=None, receive=None, dst=None):
+    """Variable-length exchange of every rank's WHOLE shard: records f32[rows, W] (rows differ per rank) and the
+    per-fragment row counts.  Sizes first (to every rank: a few bytes), then ONE payload collective into one
+    [ranks * rows_max, W] tensor (dst=None: all_gather_into_tensor on every rank; dst=r: dist.gather, rank r only -- RCCL over
+    xGMI on GPUs, gloo on CPU tensors; no per-rank staging copies).  `backing`: the buffer `records` is the head of -- when it
+    holds rows_max rows the payload is sent from it in place (the rows past this rank's count are never read by the receiver),
+    otherwise the records are padded into a fresh buffer.  `receive(rows)` -> contiguous f32[rows, W] to receive into (default:
+    a fresh tensor).
+    -> list over ranks of (records f32[rows_r, W] | None when not received here, frag_rows list)."""
     rank, ws = world()
     if ws == 1:
         return [(records, list(frag_rows))]
@@ -255,7 +329,12 @@ def gather_shard(records, frag_rows, backing=None, receive=None):
     else:
         payload = torch.zeros((rmax, W), dtype=torch.float32, device=dev)
         payload[: records.shape[0]] = records
-    out = receive(ws * rmax) if receive is not None else torch.empty((ws * rmax, W), dtype=torch.float32, device=dev)
-    all_gather_into(out, payload)
-    out = out.view(ws, rmax, W)
-    return [(out[r, : m[0]], [int(v) for v in f[: m[1]]]) for r, (m, f) in enumerate(zip(metas, frs))]
+    receives = dst is None or rank == dst
+    out = None
+    if receives:
+        out = receive(ws * rmax) if receive is not None else torch.empty((ws * rmax, W), dtype=torch.float32, device=dev)
+    exchange_into(out, payload, dst=dst)
+    if receives:
+        out = out.view(ws, rmax, W)
+    return [((out[r, : m[0]] if receives else (records if r == rank else None)), [int(v) for v in f[: m[1]]])
+            for r, (m, f) in enumerate(zip(metas, frs))]

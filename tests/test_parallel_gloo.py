@@ -107,8 +107,31 @@ def _worker(rank, world, port, out_dir):
                         assert torch.equal(parts[i] if parts is not None else rec[o:o + n], want)
                         o += n
             col.reset()
-        with pytest.raises(ValueError):
-            col.add(torch.rand(81, 36))
+        # ---- rank-0 gather (north_star: "gather of descriptors only at the end"): only rank 0 receives, in both modes; a
+        # fragment LARGER than the fixed stride (the engine's eager fallback of an oversize cloud) survives the overlapped mode
+        # through the trailing variable-length exchange (it used to raise mid-run on one rank and hang the others)
+        def frag(r, i):
+            n = 50 + 7 * i + r + (60 if (r == 1 and i == 2) else 0)       # rank 1's fragment 2: 125 rows > stride 80
+            return torch.rand(n, 36, generator=torch.Generator().manual_seed(1000 * r + i))
+        for dst in (0, None):
+            for mode in ("plain", "overlapped"):
+                col = (parallel.ShardCollector(rows_cap=64, width=36, dst=dst) if mode == "plain" else
+                       parallel.ShardCollector(rows_cap=100, width=36, chunk_frags=2, frag_rows=80, async_chunks=1, dst=dst))
+                for i in range(nfr):
+                    col.add(frag(rank, i))
+                shards = col.gather(compact=False) if mode == "overlapped" else col.gather()
+                assert len(shards) == world
+                for r, (rec, fr) in enumerate(shards):
+                    assert fr == [frag(r, i).shape[0] for i in range(3 + r)]          # the row counts reach every rank
+                    if dst is not None and rank != dst and r != rank:
+                        assert rec is None                                              # ... the payload only the receiver
+                        continue
+                    parts = rec if mode == "overlapped" else list(torch.split(rec, fr))
+                    for i, n in enumerate(fr):
+                        assert torch.equal(parts[i], frag(r, i)), (dst, mode, r, i)
+                if dst == 0 and rank != 0 and mode == "overlapped":
+                    assert col._recv_chunks is None                                     # no receive memory off the root
+                assert torch.equal(col.records(), torch.cat([frag(rank, i) for i in range(nfr)]))
         open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
     finally:
         dist.barrier()
