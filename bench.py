@@ -90,35 +90,56 @@ def parse():
                          "rank whose sizes are drawn from U(15 k, 45 k) points after the 0.03 m subsample (raw points and room edge "
                          "scaled to keep the sampling density); capacities are those of the largest fragment, so the smaller ones "
                          "run with capacity slack.  A SEPARATE configuration (never the config #2 headline)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3] (a SEPARATE configuration): KITTI-like stacks of two DIFFERENT synthetic LiDAR sweeps "
+                         "(~120k raw points each, datasets/KITTI.py:94-106,268-337), dl = 0.3 m, the reference's real trained KITTI tensors "
+                         "(tests/golden/kitti_epoch61_weights.npz) where its dump has them; a step is one stack = 2 frames")
+    ap.add_argument("--demo", action="store_true",
+                    help="BASELINE configs[0] (a SEPARATE configuration): the reference's demo pair (demo_data/cloud_bin_0/1.ply after ITS "
+                         "0.03 m grid subsample = tests/golden/demo_bin{0,1}_sub003.npy), each cloud fed as a self-pair like "
+                         "demo_registration.py:30-95 does; no stage-0 voxelisation inside the step (the script subsamples before the "
+                         "dataset sees the cloud, demo_registration.py:24)")
+    ap.add_argument("--windows", type=int, default=9,
+                    help="the K-step job is timed this many times back to back (each window bracketed by barrier + synchronize); "
+                         "`value` is the MEDIAN window (a 20-fragment window lasts 14 ms: single windows spread 1290..1430 fragments/s "
+                         "across boxes, profiles/r03_experiments.txt x30/x34), all samples, p10 / p90 are in the line")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-fragment latency measurement (F = 1, one slot)")
+    ap.add_argument("--gather-to", default="0", help="N > 1: the rank that receives the shards at the end (default 0: north_star's "
+                    "\"gather of descriptors only at the end\"), or 'all' (all_gather: every rank receives every shard)")
     ap.add_argument("--gather-chunk", type=int, default=8,
                     help="N > 1: fragments per asynchronous shard-exchange chunk (parallel.ShardCollector overlapped mode: the "
                          "shards cross xGMI while the next fragments are computed); 0 = one all_gather of the whole shard at the end")
     ap.add_argument("--raw-points", type=int, default=300000, help="raw points per synthetic fragment (config #2: 300k)")
+    ap.add_argument("--kitti-points", type=int, default=120000, help="raw points per synthetic LiDAR sweep (config #4: 120k)")
     ap.add_argument("--edge", type=float, default=1.68, help="room edge in metres (config #2: 1.68 -> ~30k pts at 0.03 m)")
     return ap.parse_args()
 
 
 class Step:
-    """The hot path for one fragment, op by op (instrumented pass, --eager)."""
+    """The hot path for one stack, op by op (instrumented pass, --eager)."""
 
-    def __init__(self, cfg, model, limits, device, bf16=False, bf16_features=False):
+    def __init__(self, cfg, model, limits, device, bf16=False, bf16_features=False, two=False, stage0=True):
         from d3feat_amd.datasets.common import FragmentDataset
         self.cfg, self.model, self.device, self.bf16 = cfg, model, device, bool(bf16)
         self.bf16_features = bool(bf16_features)
+        self.two, self.stage0 = bool(two), bool(stage0)
         self.ds = FragmentDataset([], fast=True)
         self.ds.neighborhood_limits = limits
         self.ds.stack_group = 2
         self.map = self.ds.get_tf_mapping(cfg)
 
     def __call__(self, raw_dev):
-        """raw_dev: one raw cloud, or a list of F raw clouds stacked [c_1; c_1; c_2; c_2; ...] like FragmentEngine(batch=F)."""
+        """raw_dev: one item, or a list of F items stacked like FragmentEngine(batch=F): [c_1; c_1; c_2; c_2; ...] for self-pairs,
+        [a_1; b_1; a_2; b_2; ...] when an item is a pair of different clouds (two=True)."""
         import torch
         from d3feat_amd import ops
         from d3feat_amd import tf_custom_ops as tfo
-        raws = raw_dev if isinstance(raw_dev, list) else [raw_dev]
-        subs = [tfo.grid_subsampling(r, self.cfg.first_subsampling_dl) for r in raws]       # stage 0
-        pts = torch.cat([x for s in subs for x in (s, s)], 0)                                # self-pairs (device copies)
-        lens = ops.as_lens([int(s.shape[0]) for s in subs for _ in (0, 1)], self.device)
+        items = raw_dev if isinstance(raw_dev, list) else [raw_dev]
+        clouds = [c for it in items for c in (it if self.two else (it,))]
+        subs = [tfo.grid_subsampling(r, self.cfg.first_subsampling_dl) if self.stage0 else r for r in clouds]   # stage 0
+        stack = subs if self.two else [x for s in subs for x in (s, s)]                      # self-pairs (device copies)
+        pts = torch.cat(stack, 0)
+        lens = ops.as_lens([int(s.shape[0]) for s in stack], self.device)
         flat = self.map(pts, None, None, None, lens, ("a", "a"), pts)
         with ops.bf16_contraction(self.bf16, features=self.bf16_features):
             desc, score = self.model.run(flat)
@@ -144,59 +165,146 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def kitti_weights(cfg, seed=11):
+    """The reference's REAL trained KITTI tensors (results_kitti/Log_11011605/kernel_points/epoch61: 34 weight arrays + 10
+    kernel-point sets, committed as tests/golden/kitti_*.npz) over seeded values for what its dump lacks (batch-norm statistics,
+    the deepest block) -- the same weight set tests/test_gpu_real_weights.py uses."""
+    from d3feat_amd.models.variables import build_variables
+    W = build_variables(cfg, seed=seed, randomize_bn=True).values
+    n = 0
+    for fn in ("kitti_epoch61_weights.npz", "kitti_kernel_points.npz"):
+        src = np.load(os.path.join(ROOT, "tests", "golden", fn))
+        for k in src.files:
+            name = k.replace("__", "/")
+            if name not in W or W[name].shape != src[k].shape:
+                raise ValueError("trained tensor %s %s does not fit the KITTI architecture" % (name, src[k].shape))
+            W[name] = np.ascontiguousarray(src[k], np.float32)
+            n += 1
+    return W, n
+
+
+class Workload:
+    """What a "step" is made of, per BASELINE configuration.  items: what one step feeds the engine -- a raw cloud (config #2 /
+    #3), a pair of raw clouds (config #4), an already subsampled cloud (config #1)."""
+
+    def __init__(self, args, rank):
+        from d3feat_amd.models.variables import build_variables
+        from d3feat_amd.utils.config import kitti_config, threedmatch_config
+        from d3feat_amd.utils.synthetic import lidar_sweep, room_fragment
+        self.two, self.stage0, self.frames = False, True, 1
+        self.level_ratio, self.cap_factor = args.level_ratio, args.cap_factor
+        self.weights = "random-init weights (reference initialiser, seed 42), 14.1M params"
+        nfr = max(args.pool, args.cpu_fragments)
+        seeds = [rank * 1000 + i for i in range(nfr)]
+        if args.config4:
+            self.name = "config4"
+            self.cfg = kitti_config()
+            self.W, nreal = kitti_weights(self.cfg)
+            self.weights = "the reference's trained KITTI tensors (epoch61: %d arrays) + seeded batch-norm statistics / deepest block" % nreal
+            self.two, self.frames = True, 2
+            self.level_ratio = max(args.level_ratio, 0.6)       # LiDAR sweeps thin out more slowly than room surfaces (test_gpu_configs)
+            self.items = [(lidar_sweep(s, args.kitti_points), lidar_sweep(s + 100, args.kitti_points)) for s in seeds]
+            self.what = ("SURVEY §8d config #4 (NOT the config #2 headline): KITTI-like stacks of two DIFFERENT synthetic LiDAR "
+                         "sweeps (64 rings, %dk raw pts each) -> grid subsample 0.3 m" % (args.kitti_points // 1000))
+        elif args.demo:
+            self.name = "demo"
+            self.cfg = threedmatch_config()
+            self.W = build_variables(self.cfg, seed=42).values
+            self.stage0 = False
+            g = os.path.join(ROOT, "tests", "golden")
+            self.items = [np.load(os.path.join(g, "demo_bin0_sub003.npy")), np.load(os.path.join(g, "demo_bin1_sub003.npy"))]
+            self.what = ("SURVEY §8d config #1 (NOT the config #2 headline): the reference's demo pair after its own 0.03 m grid "
+                         "subsample (14 007 / 13 530 pts), each cloud")
+        else:
+            self.name = "config3" if args.config3 else "config2"
+            self.cfg = threedmatch_config()
+            self.W = build_variables(self.cfg, seed=42).values
+            if args.config3:
+                # sizes U(15 k, 45 k) after the subsample: points scale with the surface, so the room edge goes with sqrt(size) and
+                # the raw count with the size (config #2: 300 k raw points, edge 1.68 m -> ~30 k points)
+                targets = np.random.default_rng(1234 + rank).uniform(15000, 45000, nfr)
+                self.items = [room_fragment(s, n_raw=int(args.raw_points * t / 30000.0), edge=args.edge * float(np.sqrt(t / 30000.0)))
+                              for s, t in zip(seeds, targets)]
+                self.what = ("SURVEY §8d config #3 shape (NOT the config #2 headline): synthetic 3DMatch room fragments of U(15 k, 45 k) "
+                             "points after the 0.03 m subsample, capacities of the largest")
+            else:
+                self.items = [room_fragment(s, n_raw=args.raw_points, edge=args.edge) for s in seeds]
+                self.what = "SURVEY §8d config #2: synthetic 3DMatch room fragment, 300k raw pts -> grid subsample 0.03 m"
+
+    def clouds(self, item):
+        return list(item) if self.two else [item]
+
+    def to_device(self, item, device):
+        import torch
+        return tuple(torch.from_numpy(c).to(device) for c in item) if self.two else torch.from_numpy(item).to(device)
+
+    def raw_points(self, item):
+        return sum(int(c.shape[0]) for c in self.clouds(item))
+
+    def kept(self, rec):
+        """What a step contributes to the shard: the first cloud's records of a stacked self-pair (utils/tester.py:208-229 keeps
+        in_batches[0]); both clouds of a stack of two different frames."""
+        return rec if self.two else rec[: rec.shape[0] // 2]
+
+
 def main():
     args = parse()
     if args.bf16_features:
         args.bf16 = True
+    from d3feat_amd import launch
+    if launch.needs_launch(args.gpus):
+        # `python bench.py --gpus N` without a launcher around it: start the N ranks (or refuse: fewer than N devices)
+        sys.exit(launch.relaunch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if args.config4 or args.demo:
+        args.pool = max(args.pool if args.config4 else 2, 2)
+        if args.demo:
+            args.pool, args.cpu_fragments = 2, min(args.cpu_fragments, 2)
     if args.batch <= 0:
         args.batch = (12 if args.steps >= 384 else 8) if args.steps >= 64 else max(1, min(8, -(-args.steps // max(args.slots, 1))))
+        if args.config4:
+            args.batch = min(args.batch, 4)          # a stack of two 120k-pt sweeps is four 30k-pt clouds' worth of rows
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0 and world > 1:
-            print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    if not launch.check_world(args.gpus, world):
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d needs GPU %d, this box exposes %d: refusing to run\n"
+                         % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=device)
+        world = dist.get_world_size()            # n_gpus in the line = what RCCL saw
 
     from d3feat_amd import ops, parallel
     from d3feat_amd.datasets.common import FragmentDataset
     from d3feat_amd.models.KPFCNN_model import KernelPointFCNN
-    from d3feat_amd.models.variables import build_variables
-    from d3feat_amd.utils.config import threedmatch_config
-    from d3feat_amd.utils.synthetic import room_fragment
     from d3feat_amd import tf_custom_ops as tfo
 
-    cfg = threedmatch_config()
-    W = build_variables(cfg, seed=42).values
     if args.ablate:
-        args.no_cpu_baseline = args.no_instrument = args.no_mirror_extra = args.no_pcie_extra = True
+        args.no_cpu_baseline = args.no_instrument = args.no_mirror_extra = args.no_pcie_extra = args.no_latency = True
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    # synthetic fragments of this rank, raw points resident in HBM before timing starts; the first `pool` are cycled through
-    # the timed region, the first `cpu_fragments` form the CPU / parity sample
-    if args.config3:
-        args.pool = max(args.pool, 16)
-    nfr = max(args.pool, args.cpu_fragments if do_cpu else 0)
-    seeds = [rank * 1000 + i for i in range(nfr)]
-    if args.config3:
-        # sizes U(15 k, 45 k) after the subsample: points scale with the surface, so the room edge goes with sqrt(size) and the
-        # raw count with the size (config #2: 300 k raw points, edge 1.68 m -> ~30 k points)
-        targets = np.random.default_rng(1234 + rank).uniform(15000, 45000, nfr)
-        raws_host = [room_fragment(s, n_raw=int(args.raw_points * t / 30000.0), edge=args.edge * float(np.sqrt(t / 30000.0)))
-                     for s, t in zip(seeds, targets)]
-    else:
-        raws_host = [room_fragment(s, n_raw=args.raw_points, edge=args.edge) for s in seeds]
-    raws_all = [torch.from_numpy(r).to(device) for r in raws_host]
+    if not do_cpu:
+        args.cpu_fragments = 0
+    wl = Workload(args, rank)
+    cfg, W = wl.cfg, wl.W
+    secondary_ok = wl.name in ("config2", "config3")           # mirror / PCIe / marginal-cost extras: headline workload only
+    # this rank's synthetic items, resident in HBM before timing starts; the first `pool` are cycled through the timed region,
+    # the first `cpu_fragments` form the CPU / parity sample
+    raws_host = wl.items
+    raws_all = [wl.to_device(r, device) for r in raws_host]
     raws = raws_all[: args.pool]
 
-    # neighbourhood limits: calibrated like init_test_input_pipeline on this rank's pool, histograms summed over ranks
-    subs = [tfo.grid_subsampling(r, cfg.first_subsampling_dl).cpu().numpy() for r in raws]
+    # neighbourhood limits: calibrated like init_test_input_pipeline on this rank's pool (every cloud as a self-pair: the
+    # searches are per cloud, so the histogram proportions are those of the real stacks), histograms summed over ranks
+    subs = [(tfo.grid_subsampling(c, cfg.first_subsampling_dl) if wl.stage0 else c).cpu().numpy()
+            for r in raws for c in (r if wl.two else (r,))]
     cal = FragmentDataset(subs)
     hist_n = int(np.ceil(4 / 3 * np.pi * (cfg.density_parameter + 1) ** 3))
     cal.neighborhood_limits = np.full(cfg.num_layers, hist_n, np.int32)
@@ -206,7 +314,7 @@ def main():
     limits = np.sum(cumsum < (0.8 * cumsum[hist_n - 1, :]), axis=0).astype(np.int32)
 
     model = KernelPointFCNN(None, cfg, weights=W, device=device)
-    step = Step(cfg, model, limits, device, bf16=args.bf16, bf16_features=args.bf16_features)          # eager op-by-op path (instrumented pass, --eager)
+    step = Step(cfg, model, limits, device, bf16=args.bf16, bf16_features=args.bf16_features, two=wl.two, stage0=wl.stage0)
     if args.ablate:
         install_ablation(args.ablate.split(","))     # after the calibration (which reads its results back)
 
@@ -217,32 +325,40 @@ def main():
             torch.cuda.synchronize(device)
 
     engine = None
-    n0_max = max(len(x) for x in subs)
-    if not args.eager:
-        # the fragment engine: whole fragment = one replayed HIP graph with device-resident sizes, `slots` in flight
+    per = 2 if wl.two else 1
+    # voxels per ITEM (both clouds of a two-frame stack together: the engine's capacities bound their sum)
+    n0_items = [sum(len(x) for x in subs[i * per:(i + 1) * per]) for i in range(len(raws))]
+    n0_max = max(n0_items)
+
+    def make_engine(batch, slots, streams=None, mirror=False, bf16=args.bf16, bf16_features=args.bf16_features):
         from d3feat_amd.engine import FragmentEngine
-        raw_cap = int(max(r.shape[0] for r in raws_all) * 1.05) + 1024
-        n0_cap = (int(n0_max * args.cap_factor) + 1023) // 1024 * 1024
-        engine = FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, level_ratio=args.level_ratio, slots=args.slots, device=device,
-                                n0_hint=int(np.mean([len(x) for x in subs])), mirror_self_pair=args.mirror,
-                                batch=args.batch, bf16=args.bf16, bf16_features=args.bf16_features)
-    # this rank's shard: every fragment's [xyz | desc | score] records stay in HBM until the final gather
-    # (N > 1: overlapped mode -- fixed stride per fragment, chunks of --gather-chunk fragments all-gathered asynchronously
-    # while the next replays run; every rank holds the same number of fragments, so the collective order is the same everywhere)
-    frag_rows = (int(n0_max * args.cap_factor) + 1023) // 1024 * 1024
+        raw_cap = int(max(wl.raw_points(r) for r in raws_host) * 1.05) + 1024
+        n0_cap = (int(n0_max * wl.cap_factor) + 1023) // 1024 * 1024
+        return FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, level_ratio=wl.level_ratio, slots=slots, device=device,
+                              n0_hint=int(np.mean(n0_items)), mirror_self_pair=mirror, batch=batch, bf16=bf16,
+                              bf16_features=bf16_features, streams=streams, two_clouds=wl.two, stage0=wl.stage0)
+    if not args.eager:
+        # the fragment engine: whole stack = one replayed HIP graph with device-resident sizes, `slots` in flight
+        engine = make_engine(args.batch, args.slots, mirror=args.mirror)
+    # this rank's shard: every step's [xyz | desc | score] records stay in HBM until the final gather
+    # (N > 1: overlapped mode -- fixed stride per step, chunks of --gather-chunk steps exchanged asynchronously while the next
+    # replays run; every rank holds the same number of steps, so the collective order is the same everywhere)
+    dst = None if args.gather_to == "all" else int(args.gather_to)
+    frag_rows = (int(n0_max * wl.cap_factor) + 1023) // 1024 * 1024
     if world > 1 and args.gather_chunk > 0:
         shard = parallel.ShardCollector(rows_cap=(args.steps + args.gather_chunk) * frag_rows, width=36, device=device,
-                                        chunk_frags=args.gather_chunk, frag_rows=frag_rows)
+                                        chunk_frags=args.gather_chunk, frag_rows=frag_rows, dst=dst)
     else:
-        shard = parallel.ShardCollector(rows_cap=((max(args.steps, 128) if world == 1 else args.steps) + 8) * int(n0_max * 1.02 + 64), width=36, device=device)
+        shard = parallel.ShardCollector(rows_cap=((max(args.steps, 128) if world == 1 else args.steps) + 8) * int(n0_max * 1.02 + 64),
+                                        width=36, device=device, dst=dst)
 
     def run(nsteps, engine=engine, collect=None, pool=raws):
-        """nsteps fragments through the hot path; every fragment's record block goes to `collect` (ShardCollector)."""
+        """nsteps steps through the hot path; every step's record block goes to `collect` (ShardCollector)."""
         if engine is None:
             for i in range(nsteps):
                 rec = step(pool[i % len(pool)])
                 if collect is not None:
-                    collect.add(rec[: rec.shape[0] // 2])
+                    collect.add(wl.kept(rec))
             return
         S, F = len(engine.slots), engine.F
         busy = [False] * S
@@ -250,12 +366,10 @@ def main():
         def drain(sl):
             for rec in engine.fetch(sl, packed=True):
                 if collect is not None:
-                    # a fragment's RESULT is the first cloud of its stacked self-pair: the rows utils/tester.py:208-229 keeps
-                    # (in_batches[0]); the second half is the same cloud again
-                    collect.add(rec[: rec.shape[0] // 2])
+                    collect.add(wl.kept(rec))
             busy[sl] = False
         i = k = 0
-        while i < nsteps:                        # replays of up to F fragments each, round-robin over the slots
+        while i < nsteps:                        # replays of up to F steps each, round-robin over the slots
             sl = k % S
             if busy[sl]:
                 drain(sl)
@@ -274,36 +388,71 @@ def main():
         shard.gather(compact=False)
     shard.reset()
     sync()
-    ops.trace_marker(1, device)                  # (named kernel: tools/rocpd_summary.py --timed-region cuts a trace here ...
-    # the driver's job is a 14 ms window: a cyclic-GC pass of the interpreter inside it is a quarter of the measurement
-    # (one 1064 among eight 1387-1431 fragments/s runs, r03 x29 / x30), so the collector runs before the window, not in it
+    # ---- the timed region: R windows of EXACTLY K steps each, every window bracketed by barrier + synchronize, MAX over ranks per
+    # window; `value` is the median window.  (One window of the driver's 20-fragment job lasts 14 ms -- no steady state; single
+    # windows spread 1290..1430 fragments/s across boxes, which hid a whole round of kernel work: r03 x30/x34.)
+    # the interpreter's cyclic GC runs between the windows, not in them (one GC pass is a quarter of a 14 ms window, r03 x29)
     import gc
-    gc.collect()
-    gc.disable()
-    sync()
-    t0 = time.perf_counter()
-    run(args.steps, collect=shard)
-    gathered = shard.gather(compact=False) if shard.chunk_frags > 0 else shard.gather()
-    sync()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    ops.trace_marker(2, device)                  #  ... and here; outside the clock)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    npts = int(np.mean(shard.frag_rows)) if shard.frag_rows else 0
-    gathered_rows = [int(sum(g[1])) for g in gathered]
-    gathered_frags = [len(g[1]) for g in gathered]
-    del gathered
-    shard.reset()
+    windows = []
+    R = max(1, args.windows)
+    for w in range(R):
+        gc.collect()
+        gc.disable()
+        sync()
+        if w == R // 2:
+            ops.trace_marker(1, device)          # (named kernel: tools/rocpd_summary.py --timed-region cuts a trace here ...
+            sync()
+        t0 = time.perf_counter()
+        run(args.steps, collect=shard)
+        gathered = shard.gather(compact=False) if shard.chunk_frags > 0 else shard.gather()
+        sync()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        if w == R // 2:
+            ops.trace_marker(2, device)          #  ... and here: the middle window; outside the clock)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        windows.append(float(tmax.item()))
+        npts = int(np.mean(shard.frag_rows)) if shard.frag_rows else 0
+        gathered_rows = [int(sum(g[1])) for g in gathered]
+        gathered_frags = [len(g[1]) for g in gathered]
+        received = [g[0] is not None for g in gathered]
+        del gathered
+        shard.reset()
+    dt = float(np.median(windows))
 
-    # the secondary measurements below are steady-state figures: never shorter than 128 fragments, whatever --steps the
+    # the secondary measurements below are steady-state figures: never shorter than 128 steps, whatever --steps the
     # headline was asked for
     sec_steps = max(args.steps, 128)
+    # ---- single-step latency: F = 1, one slot, graph path -- the reference's own timing metric is the time of ONE sess.run
+    # ("Avergae Feature Extraction Time", utils/tester.py:195-200,233), not a throughput
+    latency = None
+    if rank == 0 and engine is not None and not args.no_latency:
+        try:
+            eng1 = make_engine(1, 1, streams=[engine.slots[0].stream])
+            for i in range(4):
+                eng1.submit(0, raws[i % len(raws)])
+                eng1.fetch(0, packed=True)
+            lat = []
+            for i in range(48):
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                eng1.submit(0, raws[i % len(raws)])
+                eng1.fetch(0, packed=True)               # waits for the replay's completion event + the status read-back
+                lat.append((time.perf_counter() - t1) * 1e3)
+            latency = {"median": round(float(np.median(lat)), 4), "p10": round(float(np.percentile(lat, 10)), 4),
+                       "p90": round(float(np.percentile(lat, 90)), 4), "n": len(lat), "unit": "ms per step, submit -> results in HBM",
+                       "execution": "HIP-graph replay of ONE stack (F = 1), nothing else in flight",
+                       "engine_fallbacks": eng1.fallbacks,
+                       "what": "the reference's own metric: wall time of one sess.run (utils/tester.py:195-200,233)"}
+            del eng1
+        except Exception as exc:      # a secondary number must never cost the headline line
+            latency = {"error": repr(exc)[:200]}
+
     # ---- secondary number (N = 1): PCIe-inclusive -- raw fragments start in pinned HOST memory, results end there -------
     pcie = None
-    if rank == 0 and world == 1 and engine is not None and not args.no_pcie_extra:
+    if rank == 0 and world == 1 and engine is not None and not args.no_pcie_extra and secondary_ok:
         try:
             hraws = [r.cpu().pin_memory() for r in raws]
             S, F = len(engine.slots), engine.F
@@ -348,10 +497,8 @@ def main():
 
     # ---- secondary number (N = 1): the same fragments with the self-pair computed once and mirrored ---------------------
     mirror_extra = None
-    if rank == 0 and world == 1 and engine is not None and not args.mirror and not args.no_mirror_extra and not args.bf16:
-        from d3feat_amd.engine import FragmentEngine as _FE
-        eng2 = _FE(cfg, W, limits, raw_cap=engine.raw_cap, n0_cap=engine.n0_cap, level_ratio=engine.level_ratio, slots=args.slots, device=device,
-                   n0_hint=engine.n0_hint, mirror_self_pair=True, streams=[sl.stream for sl in engine.slots], batch=args.batch)
+    if rank == 0 and world == 1 and engine is not None and not args.mirror and not args.no_mirror_extra and not args.bf16 and secondary_ok:
+        eng2 = make_engine(args.batch, args.slots, streams=[sl.stream for sl in engine.slots], mirror=True, bf16=False, bf16_features=False)
         run(args.warmup, eng2)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
@@ -376,46 +523,58 @@ def main():
     # the question is what a family costs the THROUGHPUT.  Measured by leaving its library calls out of a second engine
     # (the replay keeps its shape: sizes are device-resident and do not depend on feature values; outputs are garbage).
     marginal = None
-    if rank == 0 and world == 1 and engine is not None and fam_flops and not args.no_marginal and not args.ablate and not args.mirror and not args.bf16:
+    if rank == 0 and world == 1 and engine is not None and fam_flops and not args.no_marginal and not args.ablate and not args.mirror \
+            and not args.bf16 and secondary_ok:
         marginal = marginal_costs(args, cfg, W, limits, engine, run, shard, device, sec_steps, fam_flops)
 
     # ---- CPU baseline + parity at the benchmarked configuration (rank 0, N=1) ---------------------------------------------
     cpu = parity = None
     if do_cpu:
-        cpu, refs = cpu_baseline(cfg, W, limits, raws_host[: max(1, args.cpu_fragments)], one_thread=not args.no_cpu_1thread)
+        cpu, refs = cpu_baseline(wl, limits, raws_host[: max(1, args.cpu_fragments)], one_thread=not args.no_cpu_1thread)
         parity = parity_check(cfg, engine, step, raws_all[: len(refs)], refs, device, BF16_TOL if args.bf16 else PARITY_TOL)
 
     if rank == 0:
+        frames = wl.frames
+        unit_note = ("a step is one stack of two different frames = 2 fragments" if wl.two else "a step is one fragment (computed as the "
+                     "reference's stacked self-pair)")
         res = {
             "metric": "fragments/sec (30k-pt clouds)" + ((" -- configs[4]: bf16 features + bf16 contraction" if args.bf16_features
                                                          else " -- configs[4]: bf16 contraction") if args.bf16 else "") +
-                      (" -- configs[2] shape: fragment sizes U(15k, 45k)" if args.config3 else ""),
-            "value": round(world * args.steps / dt, 3), "unit": "fragments/s",
+                      {"config2": "", "config3": " -- configs[2] shape: fragment sizes U(15k, 45k)",
+                       "config4": " -- configs[3]: KITTI-like frames (~%dk pts at 0.3 m), two different frames per stack" % round(npts / 2000),
+                       "demo": " -- configs[0]: the reference's demo pair"}[wl.name],
+            "value": round(world * args.steps * frames / dt, 3), "unit": "fragments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": (("bf16 feature storage between the layers, bf16 operands / f32 accumulate in the unary + unfused KPConv "
                        "contractions, f32 arithmetic inside the gather kernels (NOT the fp32 parity path)") if args.bf16_features else
                       "bf16 operands / f32 accumulate in the unary + unfused KPConv contractions; f32 elsewhere (NOT the fp32 "
-                      "parity path)" if args.bf16 else "f32"), "data": "synthetic",
-            "config": {"workload": ("SURVEY §8d config #3 shape (NOT the config #2 headline): synthetic 3DMatch room fragments of "
-                                    "U(15 k, 45 k) points (mean %dk) after the 0.03 m subsample, capacities of the largest" % round(npts / 1000)
-                                    if args.config3 else
-                                    "SURVEY §8d config #2: synthetic 3DMatch room fragment, 300k raw pts -> grid subsample "
-                                    "0.03 m (~%dk pts)" % round(npts / 1000)) +
-                                   " -> self-pair -> 5-level pyramid -> full KPFCNN forward (random-init "
-                                   "weights, 14.1M params) -> 32-d descriptors + scores",
+                      "parity path)" if args.bf16 else "f32"), "data": "synthetic" if wl.name != "demo" else "the reference's demo clouds",
+            "timing": {"windows": R, "window_ms": [round(x * 1e3, 3) for x in windows],
+                       "value_per_window": [round(world * args.steps * frames / x, 1) for x in windows],
+                       "p10": round(world * args.steps * frames / float(np.percentile(windows, 90)), 1),
+                       "p90": round(world * args.steps * frames / float(np.percentile(windows, 10)), 1),
+                       "what": "R back-to-back windows of exactly `steps` steps, each bracketed by barrier + synchronize, max over "
+                               "ranks per window; value / ms_per_step = the MEDIAN window"},
+            "latency_ms": latency,
+            "config": {"workload": wl.what + " (~%dk pts per %s)" % (round(npts / 1000), "stack" if wl.two else "cloud") +
+                                   (" -> self-pair" if not wl.two else "") + " -> 5-level pyramid -> full KPFCNN forward (" + wl.weights +
+                                   ") -> 32-d descriptors + scores; " + unit_note,
                        "points_per_cloud_pool": sorted(int(len(x)) for x in subs),
                        "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
-                       "fragments_per_gpu": args.steps, "parallelism": "fragment-dp%d" % world,
-                       "final_gather": {"ranks": len(gathered_rows), "fragments_per_rank": gathered_frags,
+                       "fragments_per_gpu": args.steps * frames, "parallelism": "fragment-dp%d" % world,
+                       "rccl": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
+                       "final_gather": {"ranks": len(gathered_rows), "to": "rank %d" % dst if dst is not None else "every rank",
+                                        "received_on_rank0": received,
+                                        "fragments_per_rank": gathered_frags,
                                         "rows_per_rank": gathered_rows, "bytes_per_rank": [r * 144 for r in gathered_rows],
                                         "what": "every rank's whole shard of [xyz | desc | score] records (144 B/point, the first cloud "
                                                 "of every stacked self-pair: what utils/tester.py:208-229 keeps per fragment), inside "
-                                                "the timed region: " + ("asynchronous all_gathers of %d-fragment chunks behind the compute"
+                                                "the timed region: " + ("asynchronous exchanges of %d-step chunks behind the compute"
                                                                         % shard.chunk_frags if shard.chunk_frags > 0 else
-                                                                        "one padded all_gather at the end")},
+                                                                        "one padded exchange at the end")},
                        "execution": ("eager op-by-op launches" if engine is None else
-                                     "HIP-graph replay of %d stacked fragment(s), device-resident sizes, %d replays in flight%s"
+                                     "HIP-graph replay of %d stacked step(s), device-resident sizes, %d replays in flight%s"
                                      % (engine.F, len(engine.slots),
                                         "; self-pair computed once and mirrored" if args.mirror else "")),
                        "fragments_per_replay": (engine.F if engine is not None else 1),
@@ -716,22 +875,35 @@ def load_traffic():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(cfg, W, limits, raws_host, one_thread=True):
+def cpu_baseline(wl, limits, raws_host, one_thread=True):
     """The same step on the host cores of this box (reported baseline, not the target).  Geometry: the reference's own
     C++ (oracle/_ref) on 1 thread (the reference ops are single-threaded and test_3dmatch.py:55 uses one input thread).
     Network: the torch-CPU restatement of the TF graph on every core, and once on 1 thread.  -> (object, references)."""
     import torch
     from oracle import clib, parity as par
+    cfg, W = wl.cfg, wl.W
     use_ref = clib.ref_available()
     co = clib.COracle()
     rl = clib.RefLib() if use_ref else None
+    gsub = par.geometry_ops(co, rl)[2]
+
+    def reference(item):
+        """One step on the host, stage 0 included in t_geometry where the step has one."""
+        if not wl.two and wl.stage0:
+            return par.fragment_reference(cfg, W, item, limits, co=co, rl=rl)
+        t = time.perf_counter()
+        clouds = [gsub(c, np.float32(cfg.first_subsampling_dl)) for c in item] if wl.two else [item, item]
+        t = time.perf_counter() - t
+        ref = par.fragment_reference(cfg, W, None, limits, co=co, rl=rl, clouds=clouds)
+        ref["t_geometry"] += t
+        return ref
     ncores = os.cpu_count() or 1
     # the torch-CPU graph stops scaling well before a 256-thread box is full (and degrades past it): 64 intra-op threads,
     # the box's core count is reported beside it
     torch.set_num_threads(min(ncores, 64))
     nthreads = torch.get_num_threads()
-    par.fragment_reference(cfg, W, raws_host[0], limits, co=co, rl=rl)     # warm-up (page-in, thread pools)
-    refs = [par.fragment_reference(cfg, W, r, limits, co=co, rl=rl) for r in raws_host]
+    reference(raws_host[0])     # warm-up (page-in, thread pools)
+    refs = [reference(r) for r in raws_host]
     pre = np.asarray([r["t_geometry"] for r in refs])
     net = np.asarray([r["t_network"] for r in refs])
     tot = pre + net
@@ -747,18 +919,18 @@ def cpu_baseline(cfg, W, limits, raws_host, one_thread=True):
         onp.forward(cfg, W, refs[0]["inp"])
         net1 = time.perf_counter() - t
         torch.set_num_threads(nthreads)
-    out = {"value": round(float(len(refs) / tot.sum()), 4), "unit": "fragments/s", "cores": nthreads,
+    out = {"value": round(float(len(refs) * wl.frames / tot.sum()), 4), "unit": "fragments/s", "cores": nthreads,
            "host_cores": ncores,
            # geometry = the reference's own C++ (oracle/_ref) when available; the network half has no runnable reference
            # (TensorFlow 1 is not installable here), it is the torch-CPU restatement -> "port" for the sum
            "kind": "port", "geometry_kind": "reference" if use_ref else "port",
-           "sample": "%d fragment(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
+           "sample": "%d step(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
                      "thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads (box: %d cores): "
                      "%.3f s/fragment" % (len(refs), "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
                                           float(pre.mean()), nthreads, ncores, float(net.mean())),
            "geometry_s": stats(pre), "network_s": stats(net), "fragment_s": stats(tot),
            "network_1thread_s": round(net1, 3) if net1 is not None else None,
-           "value_1thread": round(1.0 / (float(np.median(pre)) + net1), 4) if net1 is not None else None}
+           "value_1thread": round(wl.frames / (float(np.median(pre)) + net1), 4) if net1 is not None else None}
     return out, refs
 
 

@@ -53,7 +53,7 @@ class _Slot:
 class FragmentEngine:
     def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
                  device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None, two_clouds=False, batch=1,
-                 bf16=False, bf16_features=False):
+                 bf16=False, bf16_features=False, stage0=True):
         """raw_cap / n0_cap: raw points / voxels per FRAGMENT that a slot can take (a fragment beyond them is recomputed by
         the eager path).
         batch: fragments per graph replay.  The per-fragment cost of this path is dominated by the ~270 dependent launches
@@ -70,7 +70,10 @@ class FragmentEngine:
         bf16=True: every unary / unfused KPConv contraction runs with bf16 operands and fp32 accumulation (ops.bf16_contraction;
         BASELINE configs[4]) -- NOT the parity path: results differ from fp32 by the operand rounding.
         bf16_features=True (implies bf16): the activations between the layers are additionally STORED as bfloat16 -- "bf16
-        features with MFMA contraction"; arithmetic inside every kernel stays fp32."""
+        features with MFMA contraction"; arithmetic inside every kernel stays fp32.
+        stage0=False: the submitted clouds are ALREADY at the first subsampling resolution (the reference's scripts subsample
+        before the dataset sees a cloud: demo_registration.py:24, datasets/ThreeDMatch.py:349) -- no stage-0 voxelisation, the
+        cloud is stacked with itself as it is; raw_cap is then the voxel capacity n0_cap."""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.device = config, device
@@ -78,6 +81,11 @@ class FragmentEngine:
         self.raw_cap, self.n0_cap = int(raw_cap), int(n0_cap)
         self.mirror = bool(mirror_self_pair)
         self.two = bool(two_clouds)
+        self.stage0 = bool(stage0)
+        if not self.stage0:
+            if self.mirror or self.two:
+                raise ValueError("stage0=False is implemented for stacked self-pairs only")
+            self.raw_cap = self.n0_cap
         self.F = int(batch)
         self.bf16 = bool(bf16) or bool(bf16_features)
         self.bf16_features = bool(bf16_features)
@@ -114,9 +122,13 @@ class FragmentEngine:
     # ---- the fixed launch sequence -------------------------------------------------------------------------------
     def _sequence(self, sl):
         cfg = self.cfg
-        sub, sub_l, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.F * self.n0_cap,
-                                                         status=sl.status0, m_hint=self.F * self.n0_hint,
-                                                         elem_cap=self.n0_cap)
+        if self.stage0:
+            sub, sub_l, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.F * self.n0_cap,
+                                                             status=sl.status0, m_hint=self.F * self.n0_hint,
+                                                             elem_cap=self.n0_cap)
+        else:
+            sub, sub_l = sl.raw, sl.raw_len            # already at first_subsampling_dl: the stack is made of the clouds as fed
+            sub.n_hint = self.F * self.n0_hint
         if self.mirror or self.two:
             pts, lens = sub, sub_l     # the stack as subsampled: lens = [m_1 .. m_F] (mirror) or [m_a1, m_b1, ...] (two clouds)
         else:
@@ -261,7 +273,13 @@ class FragmentEngine:
             # isolated -- each goes through the graph again as a batch of one (stand-ins fill the stack: a fraction of a full
             # replay's time), and only those that still do not fit take the eager path.  One outlier costs its own eager run
             # plus nfrag short replays, not nfrag eager runs.
-            srcs, single = sl.raw_src, sl.single
+            # (an in-place producer's fragment lives in the slot's own raw buffer, which the re-submits below overwrite)
+            base, end = sl.raw.data_ptr(), sl.raw.data_ptr() + sl.raw.numel() * 4
+            srcs = [tuple(x.clone() if isinstance(x, torch.Tensor) and x.is_cuda and base <= x.data_ptr() < end else x for x in fr)
+                    if isinstance(fr, (tuple, list)) else
+                    (fr.clone() if isinstance(fr, torch.Tensor) and fr.is_cuda and base <= fr.data_ptr() < end else fr)
+                    for fr in sl.raw_src]
+            single = sl.single
             self.isolated += 1
             outs = []
             for fr in srcs:
@@ -308,7 +326,7 @@ class FragmentEngine:
             lens = ops.as_lens([int(x.shape[0]) for x in subs], self.device)
         else:
             raw = raw if raw.is_cuda else raw.to(self.device)
-            sub = tfo.grid_subsampling(raw, self.cfg.first_subsampling_dl)
+            sub = tfo.grid_subsampling(raw, self.cfg.first_subsampling_dl) if self.stage0 else raw
             n = sub.shape[0]
             pts = torch.cat([sub, sub], 0)
             lens = ops.as_lens([n, n], self.device)

@@ -44,7 +44,7 @@ def _gather_index_lists(mine, n_items, device):
 
 
 def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibrate, device, out_root=None, gather=True,
-                save=None, log=None, keep="first", overlap_chunk=0):
+                save=None, log=None, keep="first", overlap_chunk=0, dst=0):
     """fragment_ids: list of id strings ('<scene>/cloud_bin_<k>.ply'); sizes: raw point count per fragment (all ranks pass the
     same lists); load(i) -> float32 [n,3] raw cloud of fragment i (called by the owner only).
     make_engine(config, weights, limits, raw_cap, n0_cap_hint) -> engine with .F, .slots, submit(slot, [raw...]),
@@ -54,7 +54,10 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
     utils/tester.py:208-229 keeps of a stacked self-pair; "pair": the whole stacked block (KITTI pairs).  `save` always
     receives the whole block.
     overlap_chunk > 0: the shards are exchanged while they are produced, `overlap_chunk` fragments per asynchronous collective
-    (parallel.ShardCollector overlapped mode; fixed stride = the engine's row capacity of one contribution).
+    (parallel.ShardCollector overlapped mode; fixed stride = the engine's row capacity of one contribution, `engine.n0_cap` --
+    required, the same number on every rank; a fragment beyond it, i.e. the engine's eager fallback of an oversize cloud, goes
+    through the collector's trailing variable-length exchange).
+    dst: the rank that receives the shards (default 0: north_star's "gather of descriptors only at the end"); None = every rank.
     -> dict(limits, mine, order (rank 0..W-1 -> fragment indices), shards (list over ranks of (records, frag_rows)) | None)."""
     assert keep in ("first", "pair")
     rank, world = parallel.world()
@@ -71,6 +74,12 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
     # ---- one engine per rank, sized for the largest fragment of the WHOLE list (same graph shape on every rank)
     engine = make_engine(config, weights, limits, int(max(sizes) * 1.05) + 1024 if sizes else 1024)
     collector = None
+    stride = 0
+    if overlap_chunk > 0 and gather:
+        if not hasattr(engine, "n0_cap"):
+            raise ValueError("run_sharded(overlap_chunk > 0) needs engine.n0_cap: the per-fragment stride of the chunk collectives "
+                             "must be the same number on every rank")
+        stride = int(engine.n0_cap) * (1 if keep == "first" else 2)
     S, F = len(engine.slots), engine.F
     pending = [None] * S
     produced = []
@@ -81,13 +90,13 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
             if collector is None:
                 if overlap_chunk > 0 and gather:
                     # fixed stride = the engine's row capacity of one contribution: the SAME number on every rank (the chunk
-                    # collectives have one size); a fragment beyond it (eager fallback of an oversize cloud) cannot be kept
-                    cap_rows = int(getattr(engine, "n0_cap", rec.shape[0] // 2)) * (1 if keep == "first" else 2)
-                    collector = parallel.ShardCollector(rows_cap=cap_rows * max(len(mine), 1), width=rec.shape[1], device=rec.device,
-                                                        chunk_frags=overlap_chunk, frag_rows=cap_rows, async_chunks=async_chunks)
+                    # collectives have one size; engines are built from the same arguments everywhere)
+                    collector = parallel.ShardCollector(rows_cap=stride * max(len(mine), 1), width=rec.shape[1], device=rec.device,
+                                                        chunk_frags=overlap_chunk, frag_rows=stride, async_chunks=async_chunks,
+                                                        dst=dst)
                 else:
                     collector = parallel.ShardCollector(rows_cap=max(int(rec.shape[0]) * max(len(mine), 1), 1), width=rec.shape[1],
-                                                        device=rec.device)
+                                                        device=rec.device, dst=dst)
             collector.add(rec[: rec.shape[0] // 2] if keep == "first" else rec)
             produced.append(i)
             if save is not None:
@@ -113,8 +122,8 @@ def run_sharded(fragment_ids, sizes, load, config, weights, make_engine, calibra
     if gather:
         if collector is None:     # a rank without fragments still takes part in every collective
             collector = (parallel.ShardCollector(rows_cap=1, width=36, device=device, chunk_frags=overlap_chunk, async_chunks=0,
-                                                 frag_rows=int(getattr(engine, "n0_cap", 1)) * (1 if keep == "first" else 2))
-                         if overlap_chunk > 0 else parallel.ShardCollector(rows_cap=1, width=36, device=device))
+                                                 frag_rows=stride, dst=dst)
+                         if overlap_chunk > 0 else parallel.ShardCollector(rows_cap=1, width=36, device=device, dst=dst))
         shards = collector.gather()
     return dict(limits=limits, mine=list(mine), order=order, shards=shards, fallbacks=getattr(engine, "fallbacks", 0),
                 isolated=getattr(engine, "isolated", 0))

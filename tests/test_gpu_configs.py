@@ -145,3 +145,57 @@ def test_config5_eight_fragments_one_stack(device, coracle):
     assert np.abs(d2 - d[off: off + lens[3]]).max() <= 2e-5
     # ... and neither do its scores: the head normalises per cloud (D3Feat.py:84-90), for any number of clouds
     assert np.abs(s2 - s[off: off + lens[3]]).max() <= 2e-5 * max(1.0, np.abs(s2).max())
+
+
+def test_engine_without_stage0_on_the_demo_pair(device, coracle):
+    """BASELINE configs[0] as the reference's script feeds it (demo_registration.py:24,30-95): the clouds arrive ALREADY at
+    0.03 m, the engine stacks each with itself without a stage-0 pass (FragmentEngine(stage0=False)); both demo clouds in one
+    replay vs the oracle on the same clouds."""
+    import os
+    from conftest import GOLDEN
+    from d3feat_amd.engine import FragmentEngine
+    from d3feat_amd.models.variables import build_variables
+    from d3feat_amd.utils.config import threedmatch_config
+    from oracle import parity as par
+    cfg = threedmatch_config()
+    W = build_variables(cfg, seed=42, randomize_bn=True).values
+    limits = np.asarray([37, 35, 36, 38, 38], np.int32)
+    clouds = [np.load(os.path.join(GOLDEN, "demo_bin%d_sub003.npy" % i)) for i in (0, 1)]
+    eng = FragmentEngine(cfg, W, limits, n0_cap=15360, level_ratio=0.32, slots=1, device=device, batch=2, stage0=False)
+    eng.submit(0, [_t(c, device) for c in clouds])
+    outs = eng.fetch(0, packed=True)
+    assert eng.fallbacks == 0 and len(outs) == 2
+    for c, rec in zip(clouds, outs):
+        ref = par.fragment_reference(cfg, W, None, limits, co=coracle, clouds=[c, c])
+        r = rec.cpu().numpy()
+        cmp = par.compare_fragment(ref, r[:, :3], r[:, 3:35], r[:, 35:36])
+        assert cmp["points_equal"] and cmp["desc_max_abs"] <= 1e-4 and cmp["score_max_abs"] <= 1e-4, cmp
+    # a cloud beyond the capacity takes the eager path and still equals the oracle
+    small = FragmentEngine(cfg, W, limits, n0_cap=8192, level_ratio=0.32, slots=1, device=device, batch=1, stage0=False)
+    r = small.run(_t(clouds[0], device))
+    assert small.fallbacks == 1
+    ref = par.fragment_reference(cfg, W, None, limits, co=coracle, clouds=[clouds[0], clouds[0]])
+    cmp = par.compare_fragment(ref, r[0].cpu().numpy(), r[1].cpu().numpy(), r[2].cpu().numpy())
+    assert cmp["points_equal"] and cmp["desc_max_abs"] <= 1e-4 and cmp["score_max_abs"] <= 1e-4, cmp
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("flag,frames", [("--config4", 2), ("--demo", 1)])
+def test_bench_lines_of_the_other_configurations(device, flag, frames):
+    """bench.py --config4 (KITTI-like stacks of two different sweeps, real trained weights) and --demo (the reference's demo
+    pair): a full line each -- parity object against the oracle from the timed execution, cpu_baseline, latency, no fallback."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "bench.py", flag, "--steps", "8", "--warmup", "2", "--windows", "3", "--cpu-fragments", "2",
+                        "--no-cpu-1thread"], capture_output=True, text=True, cwd=ROOT, timeout=850,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["parity"]["ok"] and line["parity"]["points_equal"] and line["parity"]["idx_equal"], line["parity"]
+    assert line["config"]["engine_fallbacks"] == 0 and line["parity"]["engine_fallbacks"] == 0
+    assert line["cpu_baseline"]["value"] > 0 and line["latency_ms"]["median"] > 0 and line["latency_ms"]["engine_fallbacks"] == 0
+    assert len(line["timing"]["window_ms"]) == 3 and line["roofline"]["frac"] > 0
+    assert abs(line["value"] - 8 * frames / (line["ms_per_step"] * 8 * 1e-3)) <= 1e-2 * line["value"]

@@ -38,6 +38,9 @@ class _Engine:
         self.slots = [None, None]
         self.held = {}
         self.fallbacks = 0
+        # row capacity of one fragment's contribution = the stride of the overlapped exchange.  Deliberately BELOW the largest
+        # fragments: those stand for the eager fallback of an oversize cloud and must survive the exchange
+        self.n0_cap = int(np.sort(np.asarray(SIZES))[len(SIZES) * 2 // 3])
 
     def submit(self, slot, raws):
         assert slot not in self.held and 1 <= len(raws) <= self.F
@@ -65,7 +68,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, overlap_chunk=0):
+def _worker(rank, world, port, out_dir, overlap_chunk=0, dst=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -80,7 +83,7 @@ def _worker(rank, world, port, out_dir, overlap_chunk=0):
             return _Engine()
         saved = []
         res = runner.run_sharded(IDS, SIZES, _load, None, None, make_engine, _hist, torch.device("cpu"),
-                                 save=lambda fid, rec: saved.append(fid), overlap_chunk=overlap_chunk)
+                                 save=lambda fid, rec: saved.append(fid), overlap_chunk=overlap_chunk, dst=dst)
         want_limits = runner.limits_from_histograms(_hist([_load(i) for i in range(N_FRAG)]))
         assert np.array_equal(res["limits"], want_limits) and np.array_equal(seen_limits["limits"], want_limits)
         # ownership: a partition of the fragment list, the same on every rank
@@ -90,6 +93,10 @@ def _worker(rank, world, port, out_dir, overlap_chunk=0):
         assert len(res["shards"]) == world
         for r, (rec, rows) in enumerate(res["shards"]):
             assert len(rows) == len(res["order"][r])
+            assert rows == [_records(_load(i)).shape[0] // 2 for i in res["order"][r]]      # row counts reach every rank
+            if dst is not None and rank != dst and r != rank:
+                assert rec is None                     # rank-0 gather: the payload lands on the receiver only
+                continue
             o = 0
             for i, n in zip(res["order"][r], rows):
                 full = _records(_load(i))
@@ -107,12 +114,12 @@ def _worker(rank, world, port, out_dir, overlap_chunk=0):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("overlap_chunk", [0, 2, 3])
-def test_sharded_runner_two_ranks_gloo(tmp_path, overlap_chunk):
+@pytest.mark.parametrize("overlap_chunk,dst", [(0, 0), (2, 0), (3, 0), (0, None), (2, None)])
+def test_sharded_runner_two_ranks_gloo(tmp_path, overlap_chunk, dst):
     """overlap_chunk > 0: the shards are exchanged in asynchronous chunks of that many fragments while they are produced (shards
     of 5 and 4 fragments: the shorter one decides how many chunks go early, the rest follows in gather)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap_chunk), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap_chunk, dst), nprocs=world, join=True)
     owned = [open(tmp_path / ("ok_%d" % r)).read().split(",") for r in range(world)]
     assert sorted(int(i) for o in owned for i in o if i) == list(range(N_FRAG))
     for i in range(N_FRAG):

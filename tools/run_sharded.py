@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-to", default="0", help="rank that receives the shards (default 0: gather at the end), or 'all'")
     ap.add_argument("--overlap-chunk", type=int, default=0,
                     help="exchange the shards in asynchronous chunks of this many fragments while they are produced (0: one "
                          "all_gather at the end)")
@@ -83,7 +84,8 @@ def main():
             return read_ply_xyz(os.path.join(a.fragments, ids[i]))
     t0 = time.perf_counter()
     res = runner.run_sharded(ids, sizes, load, cfg, W, runner.gpu_engine_factory(a.slots, a.batch), runner.gpu_calibrate(cfg), dev,
-                             gather=not a.no_gather, save=runner.save_records_3dmatch(a.out), overlap_chunk=a.overlap_chunk)
+                             gather=not a.no_gather, save=runner.save_records_3dmatch(a.out), overlap_chunk=a.overlap_chunk,
+                             dst=None if a.gather_to == "all" else int(a.gather_to))
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if rank == 0:
