@@ -764,9 +764,26 @@ gemm_bf16_kernel(const float* __restrict__ A, int lda, const unsigned short* __r
     }
 }
 
+// K split of the bf16 contraction (its tile is 64 x 64 whatever N is; the fp32 plan only decides the number of K slices)
+static void gemm_bf16_split(int M, int N, int K, int M_hint, int& S, int& tps) {
+    int bm, bn;
+    gemm_plan(M, N > 32 ? N : 64, K, M_hint, bm, bn, S, tps);
+    const int nt = ((K + GB_BK - 1) / GB_BK * GB_BK) / GB_BK;
+    if (S > nt) S = nt;
+    tps = d3f_cdiv(nt, S);
+    S = d3f_cdiv(nt, tps);
+}
+
+extern "C" size_t d3f_gemm_bf16_workspace_bytes(int M, int N, int K, int M_hint) {
+    if (M <= 0 || N <= 0 || K <= 0) return 256;
+    int S, tps;
+    gemm_bf16_split(M, N, K, M_hint, S, tps);
+    return S > 1 ? d3f_align((size_t)S * M * N * sizeof(float)) + 256 : 256;
+}
+
 // A f32[M,K] (lda) or the composite [ x'[idx[m,0]] | skip[m] ] (idx != NULL / skip != NULL, as d3f_gemm_upsample_cat_f32);
 // Wt = d3f_gemm_pack_bf16(W [K,N]).  K, K1 = C1, lda, lds multiples of 4 and 16-byte aligned bases (else D3F_ERR_ARG: use the
-// fp32 entry points).  workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint).
+// fp32 entry points).  workspace >= d3f_gemm_bf16_workspace_bytes(M, N, K, M_hint).
 extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int* idx, int ld_idx, const void* skip_, int lds,
                              int C2, const void* Wt, void* C_, int ldc, int M, int N, const float* row_scale,
                              const float* col_scale, const float* col_shift, const void* residual_, int ldr, int leaky,
@@ -785,12 +802,8 @@ extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int*
     if (!A || !Wt || !C || (C2 > 0 && !skip) || ((uintptr_t)Wt & 15) || (((uintptr_t)A | (uintptr_t)skip) & (a_bf16 ? 7 : 15)))
         return D3F_ERR_ARG;
     const int Kp = (K + GB_BK - 1) / GB_BK * GB_BK;
-    int bm, bn, S, tps;
-    gemm_plan(M, N > 32 ? N : 64, K, M_hint, bm, bn, S, tps);   // (tile is 64 x 64 here; the plan only decides the K split)
-    const int nt = Kp / GB_BK;
-    if (S > nt) S = nt;
-    tps = d3f_cdiv(nt, S);
-    S = d3f_cdiv(nt, tps);
+    int S, tps;
+    gemm_bf16_split(M, N, K, M_hint, S, tps);
     float* slab = nullptr;
     if (S > 1) {
         if (!workspace || workspace_bytes < (size_t)S * M * N * sizeof(float)) return D3F_ERR_WORKSPACE;

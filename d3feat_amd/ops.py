@@ -443,7 +443,7 @@ def _gemm_bf16(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, M, N, row_sca
     lib = _lib.load()
     Wp = packed_bf16_weights(W)
     # (the bf16 launcher plans its K split for a 64-column tile even when N <= 32: ask for the same plan's slab)
-    ws = workspace(lib.d3f_gemm_workspace_bytes(M, max(N, 64), C1 + C2, hint), dev)
+    ws = workspace(lib.d3f_gemm_bf16_workspace_bytes(M, N, C1 + C2, hint), dev)
     if out.data_ptr() % 16 or (residual is not None and (residual.data_ptr() % 8 or ldr % 4)):
         raise ValueError("gemm (bf16): output / residual must be 16 / 8-byte aligned with a leading dimension of 4 k")
     with _timed("gemm_bf16", dict(M=M, N=N, K=C1 + C2), dev):

@@ -309,7 +309,10 @@ int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, co
  * with both operands rounded to bfloat16 (nearest even) and multiplied by v_mfma_f32_32x32x16_bf16, fp32 accumulate.
  * NOT bit-compatible with the fp32 path (2^-9 relative operand rounding); separate tolerance, separate bench configuration.
  * W_packed: d3f_gemm_pack_bf16(W f32[K,N]) -> bf16 [N][Kp], Kp = K rounded up to 32 (2 * N * Kp bytes).
- * C1, C2, lda, lds multiples of 4, 16-byte aligned bases.  workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint). */
+ * C1, C2, lda, lds multiples of 4, 16-byte aligned bases.  workspace >= d3f_gemm_bf16_workspace_bytes(M, N, K, M_hint) -- its
+ * OWN sizing function: the bf16 kernel's tile and K split differ from the fp32 kernel's (round-3 header pointed at
+ * d3f_gemm_workspace_bytes, which under-sizes the slabs for N <= 32). */
+size_t d3f_gemm_bf16_workspace_bytes(int M, int N, int K, int M_hint);
 int d3f_gemm_pack_bf16(const float* W, int ldb, int K, int N, void* W_packed, void* stream);
 /* a_bf16: A, skip and residual hold bfloat16 values (bf16 feature storage, see d3f_row_positive); c_bf16: C is written as bfloat16.
  * Both 0: the operands are f32 in HBM and only rounded on their way into the multiply (the round-2 form of configs[4]). */

@@ -161,3 +161,28 @@ def test_config5_bf16_feature_storage_vs_fp32_oracle(device, coracle):
     p2, d2, s2 = eng.run_eager(torch.from_numpy(raws_host[0]).to(device))
     assert torch.equal(p2, outs[0][0])
     assert (d2 - outs[0][1]).abs().max().item() <= FEAT_DESC_TOL and (s2 - outs[0][2]).abs().max().item() <= FEAT_SCORE_TOL
+
+
+@pytest.mark.parametrize("N", [8, 32, 64])
+def test_cabi_gemm_bf16_with_header_documented_workspace(device, N):
+    """A C caller's view: d3f_gemm_bf16 called straight through the C ABI with the workspace sized by the
+    function include/d3feat_amd.h names for it, d3f_gemm_bf16_workspace_bytes, and nothing else -- at N <= 32 the fp32 sizing
+    function the round-3 header pointed at under-sized the K-split slabs (D3F_ERR_WORKSPACE)."""
+    from d3feat_amd import _lib
+    lib = _lib.load()
+    M, K = 700, 4096                                            # skinny and deep: the plan splits K
+    g = torch.Generator(device="cpu").manual_seed(N)
+    A = torch.randn((M, K), generator=g).to(device)
+    W = (torch.randn((K, N), generator=g) * 0.05).to(device)
+    Kp = (K + 31) // 32 * 32
+    Wp = torch.empty((N * Kp,), dtype=torch.int16, device=device)
+    s = torch.cuda.current_stream(device).cuda_stream
+    assert lib.d3f_gemm_pack_bf16(W.data_ptr(), N, K, N, Wp.data_ptr(), s) == 0
+    nbytes = lib.d3f_gemm_bf16_workspace_bytes(M, N, K, 0)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    out = torch.empty((M, N), dtype=torch.float32, device=device)
+    rc = lib.d3f_gemm_bf16(A.data_ptr(), M, K, K, None, 0, None, 0, 0, Wp.data_ptr(), out.data_ptr(), N, M, N, None, None, None, None, 0,
+                           0, 0.2, ws.data_ptr(), nbytes, None, None, 0, 0, 0, s)
+    assert rc == 0, rc
+    want = A.bfloat16().double() @ W.bfloat16().double()
+    assert (out.double() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
