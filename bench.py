@@ -940,11 +940,12 @@ def parity_check(cfg, engine, step, raws_dev, refs, device, tol):
     import torch
     from oracle import parity as par
     n = len(refs)
-    worst = dict(points_equal=True, idx_equal=True, desc_max_abs=0.0, score_max_abs=0.0)
+    worst = dict(points_equal=True, idx_equal=True, idx_tie_rows=0, desc_max_abs=0.0, score_max_abs=0.0)
 
     def fold(c):
         worst["points_equal"] &= c["points_equal"]
         worst["idx_equal"] &= c.get("idx_equal", True)
+        worst["idx_tie_rows"] += c.get("idx_tie_rows", 0)
         worst["desc_max_abs"] = max(worst["desc_max_abs"], c["desc_max_abs"])
         worst["score_max_abs"] = max(worst["score_max_abs"], c["score_max_abs"])
     if engine is None:
@@ -980,6 +981,7 @@ def parity_check(cfg, engine, step, raws_dev, refs, device, tol):
         how = "graph engine, %d fragment(s) per replay, %d replays in flight" % (F, S)
     ok = bool(worst["points_equal"] and worst["idx_equal"] and worst["desc_max_abs"] <= tol and worst["score_max_abs"] <= tol)
     return {"ok": ok, "fragments": n, "points_equal": worst["points_equal"], "idx_equal": worst["idx_equal"],
+            "idx_rows_differing_only_inside_bit_equal_distance_ties": worst["idx_tie_rows"],
             "desc_max_abs": float("%.3e" % worst["desc_max_abs"]), "score_max_abs": float("%.3e" % worst["score_max_abs"]),
             "tolerance": tol, "against": "oracle (reference C++ geometry when built + torch-CPU restatement of the TF graph)",
             "execution": how, "engine_fallbacks": engine.fallbacks if engine is not None else None}

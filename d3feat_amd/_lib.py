@@ -61,6 +61,9 @@ SIGNATURES = {
     "d3f_ransac_draw": (_i, [C.c_uint64, C.c_uint64, _i, _i]),
     "d3f_neighbor_grid_score": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "d3f_gemm_pack_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "d3f_gemm_pack_f32t": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "d3f_gemm_f32t": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
+                           _vp, _vp, _i, _vp]),
     "d3f_gemm_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
                            _vp, _vp, _i, _i, _i, _vp]),
     "d3f_decode_xyz_records": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -453,6 +453,8 @@ gemm_fast_kernel(const float* __restrict__ A, int lda, const float* __restrict__
     }
 }
 
+#include "gemm_dma.h"
+
 // res_bf16 / c_bf16: the residual operand / the output hold bfloat16 values (bf16 feature storage, d3f_gemm_bf16)
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ slab, int S, int M, int N, float* __restrict__ C, int ldc, GemmEpi E,
@@ -593,6 +595,139 @@ static int gemm_run(const float* A, int lda, const float* B, int ldb, float* C, 
         else D3F_GEMM(2, 2, 1, 1);
 #undef D3F_GEMM
     }
+    if (S > 1)
+        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+// ---- LDS-DMA form (gemm_dma.h): weights pre-transposed once, k-tiles in a STAGES-deep LDS ring ------------------------
+extern "C" int d3f_gemm_pack_f32t(const float* B, int ldb, int K, int N, float* Wt, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 1 || N < 1 || ldb < N || !B || !Wt) return D3F_ERR_ARG;
+    const int Kp = (K + GD_BK - 1) / GD_BK * GD_BK;
+    gemm_pack_f32t_kernel<<<d3f_cdiv((long long)N * Kp, 256), 256, 0, stream>>>(B, ldb, K, N, Kp, Wt);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+static int gd_tile_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("D3F_GEMM_TILE");
+        v = e ? atoi(e) : 1;
+        if (v < 0 || v > 3) v = 1;
+    }
+    return v;
+}
+
+static int gd_persistent() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("D3F_GEMM_PERSIST");
+        v = e ? (atoi(e) != 0) : 0;     // measured equal at the network's shapes (profiles/r04_experiments.txt g5): one item per workgroup
+    }
+    return v;
+}
+
+static int gd_stages() {      // measurement knob (tools/gemm_bench.py A/B inside one visit); the default is the shipped form
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("D3F_GEMM_STAGES");
+        v = e ? atoi(e) : 3;
+        if (v < 2 || v > 3) v = 3;
+    }
+    return v;
+}
+
+// Same operator and argument meaning as d3f_gemm_bf16 (the union of d3f_gemm_f32 and d3f_gemm_upsample_cat_f32), in fp32:
+//   C = act( ([ A'[idx[m,0]] | skip[m] ] @ W) * row_scale * col_scale + col_shift + residual ),  Wt = d3f_gemm_pack_f32t(W).
+// Operands must be float4-addressable (C1, C2, lda, lds, ldc, ldr multiples of 4; 16-byte aligned bases) -- D3F_ERR_ARG otherwise:
+// the caller then uses d3f_gemm_f32 / d3f_gemm_upsample_cat_f32, which take any shape.
+extern "C" int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
+                             const float* Wt, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
+                             const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
+                             size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K = C1 + C2;
+    if (M < 0 || N < 1 || N1 < 0 || C1 < 4 || C2 < 0 || (C1 % 4) || (C2 % 4) || (N % 4) || lda < C1 || (lda % 4) || ldc < N || (ldc % 4) ||
+        (C2 > 0 && (lds < C2 || (lds % 4))) || (residual && (ldr < N || (ldr % 4))) || (idx && ld_idx < 1) || (!idx && N1 < M))
+        return D3F_ERR_ARG;
+    if (M == 0) return D3F_OK;
+    if (!A || !Wt || !C || (C2 > 0 && !skip) ||
+        (((uintptr_t)A | (uintptr_t)Wt | (uintptr_t)C | (uintptr_t)skip | (uintptr_t)residual | (uintptr_t)col_scale | (uintptr_t)col_shift) & 15))
+        return D3F_ERR_ARG;
+    const int Kp = (K + GD_BK - 1) / GD_BK * GD_BK;
+    int bm, bn, S, tps;
+    gemm_plan(M, N, K, M_hint, bm, bn, S, tps);
+    // register-tiled forms (two / four accumulator chains per wave, half the barriers and LDS reads per MFMA) where the problem
+    // still fills the chip with the larger tiles; D3F_GEMM_TILE = 0 (64 x 64 only) / 1 (auto) / 2 (128 x 64 wherever legal) / 3 (128 x 128)
+    const int tile_mode = gd_tile_mode();
+    const long long Mh = (M_hint > 0 && M_hint < M) ? M_hint : M;
+    int tm = 1, tn = 1;
+    if (bn == 64 && S == 1 && tile_mode > 0) {
+        const long long wg128x64 = (long long)d3f_cdiv(Mh, 128) * d3f_cdiv(N, 64), wg128x128 = (long long)d3f_cdiv(Mh, 128) * d3f_cdiv(N, 128);
+        if (tile_mode == 3 && N >= 128) { tm = 2; tn = 2; }
+        else if (tile_mode == 2) tm = 2;
+        else if (tile_mode == 1) {
+            if (N >= 128 && wg128x128 >= 1536) { tm = 2; tn = 2; }
+            else if (wg128x64 >= 2048) tm = 2;
+        }
+        bm = 64 * tm;
+        bn = 64 * tn;
+    }
+    float* slab = nullptr;
+    if (S > 1) {
+        if (!workspace || workspace_bytes < (size_t)S * M * N * sizeof(float)) return D3F_ERR_WORKSPACE;
+        slab = (float*)workspace;
+    }
+    GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
+    GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
+    const int st = gd_stages();
+    const size_t lds_bytes = (size_t)st * (bm + bn) * GD_BK * sizeof(float);
+    // persistent grid: every item when they are all resident at once, else what the chip holds (LDS-limited workgroups per CU x
+    // 256 CUs), rounded to a multiple of 8 so that a workgroup's items stay on its XCD (gemm_dma.h)
+    const long long items_cap = (long long)d3f_cdiv(N, bn) * S * d3f_cdiv(M, bm);
+    long long resident = (long long)(160 * 1024 / lds_bytes) * 256;
+    if (resident > 256 * 8) resident = 256 * 8;
+    const int pers = gd_persistent();
+    long long gsz = pers ? (items_cap < resident ? items_cap : resident) : items_cap;
+    gsz = (gsz + 7) / 8 * 8;
+    if (gsz > 0x7fffffffll) return D3F_ERR_ARG;
+    dim3 grid((unsigned)gsz, 1, 1);
+#define D3F_GD_E(WM_, WN_, TM_, TN_, ST_, EPI_)                                                                                 \
+    do {                                                                                                                       \
+        if (lds_bytes > 65536) {                                                                                               \
+            static std::atomic<int> done{0};                                                                                   \
+            if (!done.load(std::memory_order_acquire)) {                                                                       \
+                if (hipFuncSetAttribute((const void*)gemm_dma_kernel<WM_, WN_, TM_, TN_, ST_, EPI_>,                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return D3F_ERR_HIP; \
+                done.store(1, std::memory_order_release);                                                                      \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        gemm_dma_kernel<WM_, WN_, TM_, TN_, ST_, EPI_><<<grid, 256, lds_bytes, stream>>>(A, lda, Wt, Kp, C, ldc, M, N, K, tps, S, slab, \
+                                                                                          E, M_dev, G);                        \
+    } while (0)
+#define D3F_GD_S(WM_, WN_, TM_, TN_, ST_)                                                                                       \
+    do {                                                                                                                       \
+        const int epi = (E.row_scale ? 1 : 0) | (E.residual ? 2 : 0);                                                          \
+        if (epi == 0) D3F_GD_E(WM_, WN_, TM_, TN_, ST_, 0);                                                                    \
+        else if (epi == 1) D3F_GD_E(WM_, WN_, TM_, TN_, ST_, 1);                                                               \
+        else if (epi == 2) D3F_GD_E(WM_, WN_, TM_, TN_, ST_, 2);                                                               \
+        else D3F_GD_E(WM_, WN_, TM_, TN_, ST_, 3);                                                                             \
+    } while (0)
+#define D3F_GD(WM_, WN_, TM_, TN_)                                                                                              \
+    do {                                                                                                                       \
+        if (st == 2) D3F_GD_S(WM_, WN_, TM_, TN_, 2);                                                                          \
+        else D3F_GD_S(WM_, WN_, TM_, TN_, 3);                                                                                  \
+    } while (0)
+    if (bn == 32) D3F_GD(4, 1, 1, 1);
+    else if (tm == 2 && tn == 2) D3F_GD(2, 2, 2, 2);
+    else if (tm == 2) D3F_GD(2, 2, 2, 1);
+    else D3F_GD(2, 2, 1, 1);
+#undef D3F_GD
+#undef D3F_GD_S
+#undef D3F_GD_E
     if (S > 1)
         gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
     D3F_LAUNCH_CHECK();

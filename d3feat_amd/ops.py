@@ -6,6 +6,8 @@ computes with torch ops and nothing falls back to the CPU.
 """
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 
@@ -428,6 +430,58 @@ def packed_bf16_weights(W):
     return hit[1]
 
 
+_F32T_PACKED = {}
+# the LDS-DMA form of the fp32 contraction (d3f_gemm_f32t) is the default; D3F_GEMM_DMA=0 selects round 3's register-staged kernel
+GEMM_DMA = os.environ.get("D3F_GEMM_DMA", "1") != "0"
+
+
+def packed_f32t_weights(W):
+    """W f32[K,N] (contiguous rows) -> the transposed, K-padded f32 [N][Kp] copy d3f_gemm_f32t reads (LDS-DMA copies 16
+    contiguous bytes per lane: it cannot transpose); made once per (tensor, shape, version), outside any captured graph."""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), W._version)
+    hit = _F32T_PACKED.get(key)
+    if hit is None:
+        lib = _lib.load()
+        K, N = W.shape
+        Kp = (K + 31) // 32 * 32
+        t = torch.empty((N, Kp), dtype=torch.float32, device=W.device)
+        _lib.check(lib.d3f_gemm_pack_f32t(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_f32t")
+        if len(_F32T_PACKED) > 512:
+            _F32T_PACKED.clear()
+        hit = _F32T_PACKED[key] = (W, t)     # (keeps W alive: see packed_bf16_weights)
+    return hit[1]
+
+
+def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):
+    """Can d3f_gemm_f32t address this call?  (every shape of the network can)"""
+    if not GEMM_DMA or N % 4 or ldc % 4 or out.data_ptr() % 16:
+        return False
+    if residual is not None and (ldr % 4 or residual.data_ptr() % 16):
+        return False
+    if any(v is not None and v.data_ptr() % 16 for v in vectors):
+        return False
+    for t, ld, cols in operands:
+        if t is not None and (cols % 4 or ld % 4 or t.data_ptr() % 16 or cols < 4):
+            return False
+    return True
+
+
+def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky,
+               alpha, m_dev, n1_dev, hint, dev):
+    lib = _lib.load()
+    Wt = packed_f32t_weights(W)
+    ws = workspace(lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint), dev)
+    with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
+        rc = lib.d3f_gemm_f32t(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
+                               skip.data_ptr() if skip is not None else None, lds, C2, Wt.data_ptr(), out.data_ptr(), ldc, M, N,
+                               row_scale.data_ptr() if row_scale is not None else None,
+                               col_scale.data_ptr() if col_scale is not None else None,
+                               col_shift.data_ptr() if col_shift is not None else None,
+                               residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0, float(alpha),
+                               ws.data_ptr(), ws.numel(), m_dev, n1_dev, hint, _stream(dev))
+    _lib.check(rc, "gemm_f32t")
+
+
 def _bf16_ok(*operands):
     """(tensor, leading dimension, columns) triples: float4-addressable?"""
     for t, ld, cols in operands:
@@ -487,6 +541,10 @@ def gemm(A, Bm, row_scale=None, col_scale=None, col_shift=None, residual=None, l
         return _tag(out, A)
     if _h(A) or _h(out):
         raise TypeError("gemm: bfloat16 operands that the bf16 contraction cannot address (K %d, lda %d)" % (K, lda))
+    if Bm.is_contiguous() and _f32t_ok(N, ldc, out, residual, ldr, (col_scale, col_shift), (A, lda, K)):
+        _gemm_f32t(A, M, lda, K, None, 0, None, 0, 0, Bm, out, ldc, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky, alpha,
+                   _nd(A), None, hint, dev)
+        return _tag(out, A)
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, K, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=K), dev):
@@ -539,6 +597,10 @@ def gemm_upsample_cat(u, W, col_scale=None, col_shift=None, leaky=False, alpha=0
         return _tag(out, inds)
     if _h(x) or _h(out):
         raise TypeError("gemm_upsample_cat: bfloat16 operands that the bf16 contraction cannot address")
+    if W.is_contiguous() and _f32t_ok(N, N, out, None, 0, (col_scale, col_shift), (x, ldx, C1), (skip, lds, C2) if C2 else (None, 0, 0)):
+        _gemm_f32t(x, x.shape[0], ldx, C1, inds, ldi, skip, lds, C2, W, out, N, M, N, None, col_scale, col_shift, None, 0, leaky, alpha,
+                   _nd(inds), _nd(x), hint, dev)
+        return _tag(out, inds)
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
@@ -571,6 +633,10 @@ def gemm_cat2(A1, A2, W, col_scale=None, col_shift=None, leaky=False, alpha=0.2)
         return _tag(out, A1)
     if _h(A1) or _h(A2) or _h(out):
         raise TypeError("gemm_cat2: bfloat16 operands that the bf16 contraction cannot address")
+    if W.is_contiguous() and _f32t_ok(N, N, out, None, 0, (col_scale, col_shift), (A1, ld1, C1), (A2, ld2, C2)):
+        _gemm_f32t(A1, M, ld1, C1, None, 0, A2, ld2, C2, W, out, N, M, N, None, col_scale, col_shift, None, 0, leaky, alpha,
+                   _nd(A1), _nd(A1), hint, dev)
+        return _tag(out, A1)
     nbytes = lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint)
     ws = workspace(nbytes, dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):

@@ -303,6 +303,20 @@ int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int l
 int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
                          int ldo, const int* N_dev, void* stream);
 
+/* LDS-DMA form of the fp32 contractions (round 4): the operator of d3f_gemm_f32 / d3f_gemm_upsample_cat_f32 with the same
+ * composite A operand as d3f_gemm_bf16 below -- A f32[., C1] (rows in place when idx == NULL, else the gathered rows x'[idx[m,0]],
+ * zero row for indices outside [0, N1)), optional second operand skip f32[M, C2], K = C1 + C2 -- and the same epilogue
+ * (kernels/convolution_ops.py:90-99,243-253 + models/network_blocks.py:149-160,185-186 + the resnet residual add), exact fp32
+ * products and sums on v_mfma_f32_32x32x2_f32.  The weights are handed over PRE-TRANSPOSED: Wt = d3f_gemm_pack_f32t(W f32[K,N])
+ * -> f32 [N][Kp], Kp = K rounded up to 32, zero padded (4 * N * Kp bytes), made once per weight tensor.  Requires float4-addressable
+ * operands (C1, C2, N, lda, lds, ldc, ldr multiples of 4; 16-byte aligned bases): D3F_ERR_ARG otherwise -- use d3f_gemm_f32 then.
+ * workspace >= d3f_gemm_workspace_bytes(M, N, K, M_hint). */
+int d3f_gemm_pack_f32t(const float* W, int ldb, int K, int N, float* Wt, void* stream);
+int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
+                  const float* Wt, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
+                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
+                  size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream);
+
 /* bf16-operand form of the contractions (BASELINE.json configs[4]: batched inference, bf16 MFMA contraction): the operator of
  * d3f_gemm_f32 / d3f_gemm_upsample_cat_f32 -- A f32[M, C1] (rows in place when idx == NULL, else the gathered rows
  * x'[idx[m,0]], zero row for indices outside [0, N1)), optional second operand skip f32[M, C2], K = C1 + C2, same epilogue --

@@ -57,6 +57,30 @@ def local_indices(mat, row0, nrows, sup0, nsup, pad_from):
     return out.astype(np.int32)
 
 
+def equal_up_to_ties(got, want, q, s):
+    """Index matrices [n, K] equal, except that a row may differ by a permutation INSIDE a run of bit-equal fp32 squared distances.
+    The reference's active search (nanoflann + std::sort, tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:211-332) leaves the
+    order inside such a run unspecified; the restatement and the HIP kernel order by (d2, index) = the reference's own
+    batch_ordered_neighbors (neighbors.cpp:125-208; SURVEY.md section 8c "parity definitions").  q / s: the query / support points
+    (shadow index = len(s)).  -> (ok, number of rows that differ inside ties)."""
+    got, want = np.asarray(got), np.asarray(want)
+    if got.shape != want.shape:
+        return False, 0
+    rows = np.nonzero(np.any(got != want, axis=1))[0]
+    if not len(rows):
+        return True, 0
+    sp = np.concatenate([np.asarray(s, np.float32), np.full((1, 3), 1e6, np.float32)])
+
+    def d2(r, row):
+        d = (sp[np.minimum(row, len(sp) - 1)] - q[r]).astype(np.float32)
+        d = d * d
+        return ((d[:, 0] + d[:, 1]) + d[:, 2]).view(np.uint32)      # nanoflann's metric: ((0 + dx^2) + dy^2) + dz^2 in fp32
+    for r in rows:
+        if sorted(got[r]) != sorted(want[r]) or not np.array_equal(d2(r, got[r]), d2(r, want[r])):
+            return False, len(rows)
+    return True, len(rows)
+
+
 def compare_fragment(ref, pts, desc, score, nb0=None, row0=0, total=None):
     """ref: fragment_reference(...) result; pts/desc/score: numpy arrays of THIS fragment's rows; nb0: the level-0
     neighbour matrix of the whole stack the fragment was computed in (global indices), row0 the fragment's first row,
@@ -69,8 +93,9 @@ def compare_fragment(ref, pts, desc, score, nb0=None, row0=0, total=None):
         n = want_p.shape[0]
         w = inp["neighbors"][0]
         g = local_indices(nb0, row0, n, row0, n, total if total is not None else n)
-        res["idx_equal"] = bool(g.shape[0] == w.shape[0] and np.array_equal(g[:, :w.shape[1]], w)
-                                and (g[:, w.shape[1]:] == n).all())
+        ok, ties = equal_up_to_ties(g[:, :w.shape[1]], w, want_p, want_p) if g.shape[0] == w.shape[0] else (False, 0)
+        res["idx_equal"] = bool(ok and (g[:, w.shape[1]:] == n).all())
+        res["idx_tie_rows"] = int(ties)       # rows that differ from the reference's nanoflann order only inside bit-equal-d2 runs
     if desc is not None and ref["desc"] is not None:
         res["desc_max_abs"] = float(np.abs(desc.astype(np.float64) - ref["desc"]).max()) if desc.shape == ref["desc"].shape \
             else float("inf")

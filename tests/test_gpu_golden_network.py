@@ -139,16 +139,10 @@ def test_pools_and_unary_equal_the_reference_python(device):
 
 
 def _equal_up_to_ties(got, want, q, s, what):
-    rows = np.nonzero(np.any(got != want, axis=1))[0]
-    sp = np.concatenate([s, np.full((1, 3), 1e6, np.float32)])
-    for r in rows:
-        def d2(row):
-            d = (sp[row] - q[r]).astype(np.float32)
-            d = d * d
-            return ((d[:, 0] + d[:, 1]) + d[:, 2]).view(np.uint32)
-        assert sorted(got[r]) == sorted(want[r]), (what, r)
-        assert np.array_equal(d2(got[r]), d2(want[r])), (what, r)
-    return len(rows)
+    from oracle.parity import equal_up_to_ties
+    ok, ties = equal_up_to_ties(got, want, q, s)
+    assert ok, what
+    return ties
 
 
 @pytest.mark.parametrize("name", ["3dmatch", "kitti"])

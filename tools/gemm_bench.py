@@ -12,14 +12,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from d3feat_amd import ops  # noqa: E402
 
 SCALE = int(os.environ.get("D3F_GEMM_BENCH_SCALE", "1"))   # fragments per stack (FragmentEngine batch)
-N0, N1, N2, N3, N4 = (SCALE * n for n in (58739, 14580, 3632, 905, 197))
+N0, N1, N2, N3, N4 = (SCALE * n for n in (58966, 14630, 3632, 905, 198))
+# the 26 contraction launches of one replay as the engine issues them since round 3 (fused KPConv forms at levels 0-2, stacked
+# resnet branches, decoder contractions on [gathered | skip]): bench.py's roofline.contraction_launches, per fragment
 SHAPES = [  # (M, K, N, count)
-    (N0, 64, 32, 1), (N0, 480, 32, 1), (N0, 32, 128, 1), (N0, 64, 128, 1), (N0, 128, 32, 1), (N1, 480, 32, 1), (N1, 32, 128, 1),
-    (N1, 128, 64, 1), (N1, 960, 64, 1), (N1, 64, 256, 1), (N1, 128, 256, 1), (N1, 256, 64, 1), (N2, 960, 64, 1), (N2, 64, 256, 1),
-    (N2, 256, 128, 1), (N2, 1920, 128, 1), (N2, 128, 512, 1), (N2, 256, 512, 1), (N2, 512, 128, 1), (N3, 1920, 128, 1),
-    (N3, 128, 512, 1), (N3, 512, 256, 1), (N3, 3840, 256, 1), (N3, 256, 1024, 1), (N3, 512, 1024, 1), (N3, 1024, 256, 1),
-    (N4, 3840, 256, 1), (N4, 256, 1024, 1), (N4, 1024, 512, 1), (N4, 7680, 512, 1), (N4, 512, 2048, 1), (N4, 1024, 2048, 1),
-    (N3, 3072, 512, 1), (N2, 1024, 256, 1), (N1, 512, 128, 1), (N0, 256, 64, 1), (N0, 64, 32, 1)]
+    (N0, 64, 32, 1), (N0, 96, 128, 1), (N0, 128, 32, 1), (N1, 32, 128, 1), (N1, 128, 64, 1), (N1, 192, 256, 1), (N1, 256, 64, 1),
+    (N2, 64, 256, 1), (N2, 256, 128, 1), (N2, 384, 512, 1), (N2, 512, 128, 1), (N3, 128, 512, 1), (N3, 512, 256, 1),
+    (N3, 3840, 256, 1), (N3, 768, 1024, 1), (N3, 1024, 256, 1), (N4, 3840, 256, 1), (N4, 256, 1024, 1), (N4, 1024, 512, 1),
+    (N4, 7680, 512, 1), (N4, 1536, 2048, 1), (N3, 3072, 512, 1), (N2, 1024, 256, 1), (N1, 512, 128, 1), (N0, 256, 64, 1),
+    (N0, 64, 32, 1)]
 
 
 ONLY = [tuple(int(v) for v in t.split(",")) for t in os.environ.get("D3F_GEMM_BENCH_ONLY", "").split(";") if t]   # "M,K,N;..."
