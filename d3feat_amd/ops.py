@@ -355,7 +355,6 @@ _AGGREGATION = {"sum": 0, "closest": 1}
 # Off by default: the fp32 path is the parity path.  `with bf16_contraction():` routes every contraction issued inside it (the
 # engine wraps its capture in it when built with bf16=True) through d3f_gemm_bf16.
 BF16_CONTRACTION = False
-_BF16_PACKED = {}
 
 
 BF16_FEATURES = False     # bf16 feature STORAGE (needs BF16_CONTRACTION): activations live in HBM as torch.bfloat16
@@ -412,44 +411,51 @@ def _out_dtype():
     return torch.bfloat16 if (BF16_FEATURES and not F32_OUTPUT) else torch.float32
 
 
+def _packed_on_tensor(W, slot, make):
+    """A packed copy of a weight matrix that LIVES AND DIES WITH THE WEIGHT TENSOR: the copy rides on the tensor object that owns
+    the storage (the view's base), keyed by the view's offset / shape / stride and the tensor's version.  (A global cache with
+    eviction would free copies that captured graphs still read: round 4 found exactly that -- an engine's replays computed with
+    another model's packed weights once 512 entries had gone through the cache.)"""
+    base = W._base if W._base is not None else W
+    store = getattr(base, slot, None)
+    if store is None:
+        store = {}
+        setattr(base, slot, store)
+    key = (W.storage_offset(), tuple(W.shape), W.stride(0))
+    hit = store.get(key)
+    if hit is None or hit[0] != base._version:
+        hit = store[key] = (base._version, make())
+    return hit[1]
+
+
 def packed_bf16_weights(W):
-    """W f32[K,N] (contiguous rows) -> the bf16 [N][Kp] copy d3f_gemm_bf16 reads; made once per (tensor, shape, version)."""
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), W._version)
-    hit = _BF16_PACKED.get(key)
-    if hit is None:
+    """W f32[K,N] (contiguous rows) -> the bf16 [N][Kp] copy d3f_gemm_bf16 reads; made once per (weight tensor, view, version)."""
+    def make():
         lib = _lib.load()
         K, N = W.shape
         Kp = (K + 31) // 32 * 32
         t = torch.empty((N, Kp), dtype=torch.int16, device=W.device)
         _lib.check(lib.d3f_gemm_pack_bf16(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_bf16")
-        if len(_BF16_PACKED) > 512:
-            _BF16_PACKED.clear()
-        # the entry keeps W alive: while the key is in use no other tensor can be allocated at its address (a key of
-        # address + shape + version alone would hand a recycled address the previous owner's packed copy)
-        hit = _BF16_PACKED[key] = (W, t)
-    return hit[1]
+        return t
+    return _packed_on_tensor(W, "_d3f_bf16t", make)
 
 
-_F32T_PACKED = {}
 # the LDS-DMA form of the fp32 contraction (d3f_gemm_f32t) is the default; D3F_GEMM_DMA=0 selects round 3's register-staged kernel
 GEMM_DMA = os.environ.get("D3F_GEMM_DMA", "1") != "0"
 
 
 def packed_f32t_weights(W):
     """W f32[K,N] (contiguous rows) -> the transposed, K-padded f32 [N][Kp] copy d3f_gemm_f32t reads (LDS-DMA copies 16
-    contiguous bytes per lane: it cannot transpose); made once per (tensor, shape, version), outside any captured graph."""
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), W._version)
-    hit = _F32T_PACKED.get(key)
-    if hit is None:
+    contiguous bytes per lane: it cannot transpose); made once per (weight tensor, view, version) -- at a model's first eager
+    use, i.e. the engine's warm-up, never inside a captured graph."""
+    def make():
         lib = _lib.load()
         K, N = W.shape
         Kp = (K + 31) // 32 * 32
         t = torch.empty((N, Kp), dtype=torch.float32, device=W.device)
         _lib.check(lib.d3f_gemm_pack_f32t(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_f32t")
-        if len(_F32T_PACKED) > 512:
-            _F32T_PACKED.clear()
-        hit = _F32T_PACKED[key] = (W, t)     # (keeps W alive: see packed_bf16_weights)
-    return hit[1]
+        return t
+    return _packed_on_tensor(W, "_d3f_f32t", make)
 
 
 def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):

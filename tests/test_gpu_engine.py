@@ -242,3 +242,38 @@ def test_engine_flagged_batch_isolates_the_outlier(device, setup):
     assert torch.equal(outs[0][0], refs[0][0]) and torch.equal(outs[2][0], refs[2][0])
     packed = eng.run([raws[3], raws[2]])                     # and the graph is healthy afterwards
     assert eng.fallbacks == 2 and torch.equal(packed[0][0], refs[3][0])
+
+
+def test_packed_weight_copies_outlive_any_cache_traffic(device):
+    """A captured graph reads the PACKED copy of its weights (transposed fp32 for the LDS-DMA contraction, bf16 for configs[4]) by
+    raw pointer.  The copies therefore ride on the weight tensor itself: no amount of other models' weights going through the
+    library afterwards may free or recycle them (round 4: a global 512-entry cache did, and an engine replayed with another
+    model's weights)."""
+    from d3feat_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    A = torch.randn((3000, 128), generator=g).to(device)
+    W = (torch.randn((128, 64), generator=g) * 0.1).to(device)
+    want = (A.double() @ W.double()).float()
+    ops.gemm(A, W)                                         # eager warm-up: packs W outside the capture
+    stream = torch.cuda.Stream(device=device)
+    graph = torch.cuda.CUDAGraph()
+    with ops.private_workspace() as pw:
+        with torch.cuda.graph(graph, stream=stream):
+            out = ops.gemm(A, W)
+    keep = pw.kept
+    for i in range(700):                                   # 700 other weight tensors come and go
+        Wi = torch.full((128, 64), float(i), device=device)
+        ops.gemm(A[:64], Wi)
+        del Wi
+    torch.cuda.synchronize(device)
+    graph.replay()
+    torch.cuda.synchronize(device)
+    assert (out - want).abs().max().item() <= 1e-3
+    # a view of a bigger weight tensor (K_values.reshape in kernels/convolution_ops.py) gets its own copy on the base tensor
+    K_values = (torch.randn((15, 8, 16), generator=g) * 0.1).to(device)
+    A2 = torch.randn((500, 120), generator=g).to(device)
+    o1 = ops.gemm(A2, K_values.reshape(120, 16))
+    o2 = ops.gemm(A2, K_values.reshape(120, 16))
+    assert torch.equal(o1, o2) and hasattr(K_values, "_d3f_f32t") and len(K_values._d3f_f32t) == 1
+    assert (o1.double() - A2.double() @ K_values.reshape(120, 16).double()).abs().max().item() <= 1e-3
+    del keep
