@@ -615,8 +615,8 @@ static int gd_tile_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("D3F_GEMM_TILE");
-        v = e ? atoi(e) : 1;
-        if (v < 0 || v > 3) v = 1;
+        v = e ? atoi(e) : 0;            // 64 x 64 everywhere: the register-tiled forms measured slower on every shape of the network (g2)
+        if (v < 0 || v > 3) v = 0;
     }
     return v;
 }

@@ -52,15 +52,21 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
     num_kp, cin, cout = K_values.shape
     if features.shape[1] != cin:
         raise ValueError('KPConv: features have %d channels, K_values expects %d' % (features.shape[1], cin))
+    # the fused forms address rows with one 24-bit multiply (csrc/common.h d3f_fits_u24: rows and leading dimensions < 2^24, rows x
+    # leading dimension < 2^31) and return D3F_ERR_ARG beyond it; such stacks take aggregation + contraction, which has a general form
+    def _u24(rows, ld):
+        return rows < (1 << 24) and ld < (1 << 24) and rows * ld < (1 << 31)
+    fused_ok = _u24(int(query_points.shape[0]), int(neighbors_indices.stride(0))) and \
+        _u24(int(features.shape[0]), int(features.stride(0)))
     if cin == 1 and cout <= 256:
         # input layer: one fused kernel (gather + influences + 15-term contraction + epilogue)
         return ops.kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values,
                                    KP_extent, KP_influence, aggregation_mode, **(epilogue or {}))
-    if cin == 32 and cout == 32 and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0:
+    if fused_ok and cin == 32 and cout == 32 and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0:
         # level-0 convolutions: aggregation + contraction + epilogue in one kernel, the 113 MB wf tensor stays in LDS
         return ops.kpconv_fused32(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
                                   KP_influence, aggregation_mode, **(epilogue or {}))
-    if features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and \
+    if fused_ok and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and \
             ops.kpconv_fused_supported(cin, cout, num_kp, KP_influence, aggregation_mode):
         # levels 1 and 2 (Cin = Cout = 64 / 128): the same, in tiles of 16 queries, the contraction fed from LDS
         return ops.kpconv_fused(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
