@@ -694,7 +694,7 @@ def classify_record(cfg, name, info):
         nbytes = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], cin, cout)
         flops = sum(kpconv_flops(info["Nq"], info["K"], cin, cout))
     elif name == "gemm_f32":
-        key = "gemm_fast_kernel"       # the contraction family: tile kernel (+ split-K reduce kernel)
+        key = "gemm_dma_kernel"        # the contraction family: LDS-DMA tile kernel (+ split-K reduce kernel)
         nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
         flops = 2.0 * info["M"] * info["N"] * info["K"]
     elif name == "nb_search":  # SURVEY §8(d) bytes_alg = 12*(Nq+Ns) + 4*Nq*K_out
@@ -801,7 +801,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
         # collected for different kernel sources than the ones running now.
         if traffic is not None:
             base = name.split("<")[0].split(" ")[0]
-            names = ("gemm_fast_kernel", "gemm_stream_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
+            names = ("gemm_dma_kernel", "gemm_fast_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
             ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
                    and "traffic_bytes_per_launch" in v]
             m = re.match(r"kpconv_fused_kernel<Cin=(\d+)>", name)     # template argument = lanes per query = Cin / 4

@@ -179,3 +179,25 @@ def test_pyramid_equals_the_reference_python(device, name):
     assert np.array_equal(flat[4 * L + 2].cpu().numpy(), g.inputs["in_batches"])
     assert np.array_equal(flat[4 * L + 3].cpu().numpy(), g.inputs["out_batches"])
     assert np.array_equal(flat[4 * L + 1].cpu().numpy().view(np.uint32), g.inputs["batch_weights"].view(np.uint32))
+
+
+def test_engine_replay_equals_the_reference_python(device):
+    """The production execution -- FragmentEngine: capacity-mode pyramid + network captured as ONE HIP graph and replayed -- on the
+    fixture's cloud (already at 0.03 m: stage0=False, the cloud is stacked with itself like datasets/ThreeDMatch.py:190-192) against
+    the descriptors and scores the reference's Python produced; also as one of three fragments of a batched replay."""
+    from d3feat_amd.engine import FragmentEngine
+    g = GoldenNetwork("3dmatch")
+    cfg = g.config()
+    cloud = g.clouds()[0]
+    assert np.array_equal(cloud.view(np.uint32), g.clouds()[1].view(np.uint32))
+    for batch in (1, 3):
+        eng = FragmentEngine(cfg, dict(g.W), g.limits, n0_cap=1536, level_ratio=0.45, slots=1, device=device, batch=batch, stage0=False)
+        other = np.ascontiguousarray(cloud[::-1] + np.float32(0.5))          # a different stack mate (batch 3)
+        frs = [_dev(cloud, device)] if batch == 1 else [_dev(other, device), _dev(cloud, device), _dev(other[:700], device)]
+        eng.submit(0, frs)
+        outs = eng.fetch(0)
+        assert eng.fallbacks == 0
+        p, d, s = (t.cpu().numpy() for t in outs[0 if batch == 1 else 1])
+        assert np.array_equal(p.view(np.uint32), g.inputs["points"][0].view(np.uint32))
+        ed, es = np.abs(d - g.descriptors).max(), np.abs(s - g.scores).max()
+        assert ed <= TOL and es <= TOL, (batch, ed, es)

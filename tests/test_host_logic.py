@@ -268,11 +268,11 @@ def test_bench_roofline_selection_never_picks_a_multi_launch_group():
     assert not any(v["multi"] for k, v in fam.items() if k not in ("grid_subsample", "nb_grid_build"))
     order, dominant = bench.select_dominant(fam)
     assert order[0] == "grid_subsample" and order[1] == "nb_grid_build"
-    assert dominant == "gemm_fast_kernel", dominant                    # 2 x 26 x 0.06 = 3.12 ms
+    assert dominant == "gemm_dma_kernel", dominant                    # 2 x 26 x 0.06 = 3.12 ms
     # the searches: 2 x 9 x 0.12 = 2.16 ms < 3.12 ms; a label that happens to contain "launches)" changes nothing
-    fam["weird (9 launches)"] = dict(fam["gemm_fast_kernel"], ms=100.0, multi=False)
+    fam["weird (9 launches)"] = dict(fam["gemm_dma_kernel"], ms=100.0, multi=False)
     assert bench.select_dominant(fam)[1] == "weird (9 launches)"
-    g = fam["gemm_fast_kernel"]
+    g = fam["gemm_dma_kernel"]
     assert g["launches"] == 52 and abs(g["flops"] - 52 * 2.0 * 235000 * 64 * 128) < 1
     # a run made of groups only has no headline kernel rather than a wrong one
     assert bench.select_dominant({k: v for k, v in fam.items() if v["multi"]})[1] is None
