@@ -167,7 +167,7 @@ class FragmentEngine:
         # warm-up on tiny synthetic clouds (uploads weights, sizes the allocator), then capture
         with torch.cuda.stream(sl.stream):
             g = torch.Generator(device="cpu").manual_seed(0)
-            per = 2048
+            per = min(2048, self.raw_cap)
             warm = (torch.rand((per * self.nin, 3), generator=g) * torch.tensor([1.0, 1.0, 0.05])).to(dev)
             sl.raw[: per * self.nin].copy_(warm)
             sl.raw_len.fill_(per)
