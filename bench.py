@@ -659,7 +659,7 @@ def install_ablation(families):
             return getattr(lib, name)
     skip = set()
     for f in families:
-        skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32"},
+        skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32", "d3f_gemm_f32t"},
                  "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused"},
                  "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_aggregate"},
                  "kpconv32": {"d3f_kpconv_fused32"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
