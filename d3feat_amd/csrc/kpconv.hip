@@ -107,13 +107,34 @@ static inline KpParams kp_make_params(const float* kp_host, int num_kp, float KP
     return P;
 }
 // (row addressing by one 24-bit multiply: common.h, d3f_fits_u24)
-static inline bool kp_fits_u24(int Nq, int Ns, int ld_idx, int ldf) { return d3f_fits_u24(Nq, ld_idx) && d3f_fits_u24(Ns, ldf); }
-// one 16-byte piece (channels c4 .. c4+3) of feature row `id`; a shadow neighbour (id < 0) reads row 0 instead -- its influences are
-// exactly 0, so whatever (finite) values arrive contribute nothing, and the load needs no branch, no select and no zero fill
-template <class FT>
-__device__ __forceinline__ float4 kp_gather4(const FT* __restrict__ f, int id, int ldf, int c4) {
-    const unsigned off = __umul24((unsigned)max(id, 0), (unsigned)ldf) + (unsigned)c4;
-    return D3fFeat<FT>::ld4(f + off);
+// (and the feature matrix must fit a buffer resource: rows * ld * 4 bytes < 2^32)
+static inline bool kp_fits_u24(int Nq, int Ns, int ld_idx, int ldf) {
+    return d3f_fits_u24(Nq, ld_idx) && d3f_fits_u24(Ns, ldf) && (long long)Ns * ldf < (1ll << 30);
+}
+// one 16-byte piece (channels c4 .. c4+3) of feature row `id`, fetched with a BUFFER load: the feature matrix is described by a
+// buffer resource (base + size in SGPRs), the lane supplies a 32-bit byte offset -- no 64-bit address arithmetic per gather -- and
+// a shadow neighbour (id < 0) supplies an offset beyond the buffer: the hardware's range check returns exact zeros for it, with no
+// branch, no select and no zero fill.  (Round 3 read row 0 for shadows and relied on their influences being exactly 0: a
+// non-finite value in row 0 turned 0 * Inf into NaN for every query with a shadow slot -- ADVICE r03.)
+template <class FT> struct KpFeatBuf {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ KpFeatBuf(const FT* f, int rows, int ldf) {
+        const unsigned long long bytes = (unsigned long long)(rows > 0 ? rows : 1) * (unsigned)ldf * sizeof(FT);   // < 2^32: kp_fits_u24
+        r = __builtin_amdgcn_make_buffer_rsrc((void*)f, 0, (int)(unsigned)bytes, 0x00020000);
+    }
+};
+__device__ __forceinline__ float4 kp_gather4(const KpFeatBuf<float>& B, int id, int ldf, int c4) {
+    const unsigned off = id >= 0 ? (__umul24((unsigned)id, (unsigned)ldf) + (unsigned)c4) * 4u : 0xfffffff0u;
+    typedef unsigned kp_u4 __attribute__((ext_vector_type(4)));
+    const kp_u4 v = __builtin_amdgcn_raw_buffer_load_b128(B.r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float4 kp_gather4(const KpFeatBuf<unsigned short>& B, int id, int ldf, int c4) {
+    const unsigned off = id >= 0 ? (__umul24((unsigned)id, (unsigned)ldf) + (unsigned)c4) * 2u : 0xfffffff0u;
+    typedef unsigned kp_u2 __attribute__((ext_vector_type(2)));
+    const kp_u2 w = __builtin_amdgcn_raw_buffer_load_b64(B.r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
 }
 static inline bool kp_fast_config(int num_kp, int influence, int aggregation) {
     return num_kp == KP_MAXP - 1 && influence == 1 && aggregation == 0;
@@ -235,6 +256,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
     constexpr int TQ = 256 / LQ;  // queries per workgroup
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
+    const KpFeatBuf<FT> fbuf(f, Ns, ldf);          // feature rows as a buffer resource (kp_gather4)
     if ((int)(blockIdx.x * TQ) >= Nq) return;   // capacity-sized grid: whole block beyond the real query count
     const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + TQ - 1) / TQ));   // one contiguous run of tiles per XCD
     constexpr int KC = LQ;        // neighbours per chunk (TQ*KC = 256 pairs = one per thread)
@@ -281,7 +303,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                fv[u] = kp_gather4(f, ids[u], ldf, 4 * cl);
+                fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -640,6 +662,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
                       const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
+    const KpFeatBuf<FT> fbuf(f, Ns, ldf);          // feature rows as a buffer resource (kp_gather4)
     if ((int)(blockIdx.x * KF_TQ) >= Nq) return;
     const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + KF_TQ - 1) / KF_TQ));   // one contiguous run of tiles per XCD
     // One LDS region serves three lives: phase-A influences [32][132] during the neighbour loop, then the weighted-feature
@@ -686,7 +709,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = lidx[ql * KF_LQ + k1 + u];
-                fv[u] = kp_gather4(f, ids[u], ldf, 4 * cl);
+                fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -802,6 +825,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     static_assert(KG_TQ * WS <= KG_TQ * KG_TS, "the influence region must fit the tile region");
     Nq = d3f_dyn(Nq, Nq_dev);
     Ns = d3f_dyn(Ns, Ns_dev);
+    const KpFeatBuf<FT> fbuf(f, Ns, ldf);          // feature rows as a buffer resource (kp_gather4)
     if ((int)(blockIdx.x * KG_TQ) >= Nq) return;
     const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + KG_TQ - 1) / KG_TQ));   // one contiguous run of tiles per XCD
     __shared__ __attribute__((aligned(16))) float region[KG_TQ * KG_TS];   // influences, then the wf tile of each pass
@@ -846,7 +870,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                fv[u] = kp_gather4(f, ids[u], ldf, 4 * cl);
+                fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {

@@ -430,6 +430,8 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
     hd_f2 sum01 = {0.f, 0.f}, sum23 = {0.f, 0.f};
     int cnt = 0;
     const int hbase = threadIdx.x & 32;
+    // the feature matrix as a buffer resource (U24 launches: rows * ldx * 4 bytes < 2^32)
+    const __amdgpu_buffer_rsrc_t xbuf = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)N * (unsigned)ldx * 4u), 0x00020000);
     for (int k0 = 0; k0 < K; k0 += 32) {
         int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;   // 32 indices per half-wave load
         if (mine < 0 || mine >= N) mine = -1;                                // shadow row: zeros, never counted
@@ -445,10 +447,17 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
                 const int kq = kk + u * 4 + slot;
                 id[u] = __shfl(mine, hbase + min(kq, 31), 64);
                 if (kq >= kn) id[u] = -1;
-                // a shadow slot reads row 0 (24-bit row addressing: common.h) and is multiplied by 0 instead of 1 / den below
-                const float* xr = U24 ? x + (__umul24((unsigned)max(id[u], 0), (unsigned)ldx) + (unsigned)c4)
-                                      : x + ((size_t)max(id[u], 0) * ldx + c4);
-                v[u] = *(const float4*)xr;
+                if (U24) {
+                    // buffer load (24-bit row addressing: common.h): a shadow slot supplies an offset beyond the buffer and the
+                    // hardware's range check returns exact zeros -- never row 0's values times a zero factor (0 * Inf = NaN)
+                    const unsigned off = id[u] >= 0 ? (__umul24((unsigned)id[u], (unsigned)ldx) + (unsigned)c4) * 4u : 0xfffffff0u;
+                    typedef unsigned hd_u4 __attribute__((ext_vector_type(4)));
+                    const hd_u4 w = __builtin_amdgcn_raw_buffer_load_b128(xbuf, (int)off, 0, 0);
+                    v[u] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+                } else {
+                    const float4 t = *(const float4*)(x + ((size_t)max(id[u], 0) * ldx + c4));
+                    v[u] = id[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : t;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -511,7 +520,7 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
         // one flag byte per row, behind the 2 B + 2 scratch words
         unsigned char* nz = (unsigned char*)(scratch_dev + 2 * B + 2);
         head32_rowflag_kernel<<<d3f_cdiv(N, 256), 256, 0, stream>>>(x, N, ldx, offs, B, mx, nz);
-        if (d3f_fits_u24(N, ldx))
+        if (d3f_fits_u24(N, ldx) && (long long)N * ldx < (1ll << 30))
             head32_kernel<true><<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
         else
             head32_kernel<false><<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);

@@ -373,3 +373,32 @@ def test_kpconv_fused_256_equals_the_two_kernel_form(device):
     want = ops.gemm(wf, W.reshape(15 * 256, 256), row_scale=inv, leaky=True)
     torch.cuda.synchronize()
     assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("cin", [32, 64, 128, 256])
+def test_kpconv_shadow_slots_do_not_see_a_non_finite_row_zero(device, coracle, cin):
+    """A shadow neighbour contributes the reference's ZERO feature row (kernels/convolution_ops.py:234).  The aggregation kernels
+    fetch it as an out-of-range buffer load (exact zeros from the hardware's range check) -- not as row 0 times a zero influence,
+    which turned every query with a shadow slot into NaN as soon as row 0 held Inf / NaN.  With NaN and Inf planted in
+    row 0 the output is non-finite exactly where the reference's is: at the queries that have row 0 as a REAL neighbour."""
+    from d3feat_amd.kernels import convolution_ops as conv_ops
+    from d3feat_amd.kernels.kernel_points import create_kernel_points
+    from oracle import network_np as onp
+    s0 = surface_cloud(300 + cin, n_raw=20000)
+    rng = np.random.default_rng(cin)
+    lens = np.asarray([len(s0)], np.int32)
+    nb = coracle.batch_neighbors(s0, s0, lens, lens, np.float32(0.075))[:, :37]
+    assert (nb == len(s0)).any()                                   # shadow slots exist
+    f = rng.standard_normal((len(s0), cin)).astype(np.float32)
+    f[0, 0], f[0, 1] = np.nan, np.inf
+    W = (rng.standard_normal((15, cin, cin)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    KP = create_kernel_points(0.045, 15, 1, 3, 'center', rng=np.random.default_rng(1)).reshape(15, 3).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        want = onp.KPConv_ops(s0, s0, nb, f, KP, W, 0.03, 'linear', 'sum').numpy()
+    got = conv_ops.KPConv_ops(_t(s0, device), _t(s0, device), _t(nb.astype(np.int32), device), _t(f, device), KP,
+                              _t(W, device), 0.03, 'linear', 'sum').cpu().numpy()
+    touched = (nb == 0).any(1)                                     # queries with row 0 among their real neighbours
+    assert touched.sum() < 100 and np.isfinite(want[~touched]).all()
+    assert np.isfinite(got[~touched]).all(), int((~np.isfinite(got[~touched])).any(1).sum())
+    _close(got[~touched], want[~touched])
+    assert not np.isfinite(got[touched]).all(1).any()             # where the reference is non-finite, so is the kernel
