@@ -43,7 +43,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 PARITY_TOL = 1e-4          # BASELINE.json north_star: descriptors and scores within 1e-4 (absolute), indices bit-exact
-BF16_TOL = 3e-2            # documented tolerance of the bf16-contraction configuration vs the fp32 oracle (tests/test_gpu_bf16.py)
+BF16_TOL = 2e-2            # documented tolerance of the bf16-contraction configuration vs the fp32 oracle (tests/test_gpu_bf16.py)
 
 
 def parse():
