@@ -611,34 +611,11 @@ extern "C" int d3f_gemm_pack_f32t(const float* B, int ldb, int K, int N, float* 
     return D3F_OK;
 }
 
-static int gd_tile_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("D3F_GEMM_TILE");
-        v = e ? atoi(e) : 0;            // 64 x 64 everywhere: the register-tiled forms measured slower on every shape of the network (g2)
-        if (v < 0 || v > 3) v = 0;
-    }
-    return v;
-}
-
-static int gd_persistent() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("D3F_GEMM_PERSIST");
-        v = e ? (atoi(e) != 0) : 0;     // measured equal at the network's shapes (profiles/r04_experiments.txt g5): one item per workgroup
-    }
-    return v;
-}
-
-static int gd_stages() {      // measurement knob (tools/gemm_bench.py A/B inside one visit); the default is the shipped form
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("D3F_GEMM_STAGES");
-        v = e ? atoi(e) : 3;
-        if (v < 2 || v > 3) v = 3;
-    }
-    return v;
-}
+// The measured variants of this launcher (2 / 3 / 4 ring stages, 128 x 64 and 128 x 128 register tiles, a persistent grid whose DMA
+// ring runs across tile boundaries, a loader wavefront) are recorded in profiles/r04_experiments.txt g1-g6 with their numbers; the
+// persistent walk is still in the kernel (grid = items is its degenerate case), the others live in git history /
+// tools/ubench/gemm_dma_loader_wave.patch.  What ships: 3 stages, 64 x 64 tiles (128 x 32 when N <= 32), one item per workgroup.
+#define GD_STAGES 3
 
 // Same operator and argument meaning as d3f_gemm_bf16 (the union of d3f_gemm_f32 and d3f_gemm_upsample_cat_f32), in fp32:
 //   C = act( ([ A'[idx[m,0]] | skip[m] ] @ W) * row_scale * col_scale + col_shift + residual ),  Wt = d3f_gemm_pack_f32t(W).
@@ -660,22 +637,6 @@ extern "C" int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int*
     const int Kp = (K + GD_BK - 1) / GD_BK * GD_BK;
     int bm, bn, S, tps;
     gemm_plan(M, N, K, M_hint, bm, bn, S, tps);
-    // register-tiled forms (two / four accumulator chains per wave, half the barriers and LDS reads per MFMA) where the problem
-    // still fills the chip with the larger tiles; D3F_GEMM_TILE = 0 (64 x 64 only) / 1 (auto) / 2 (128 x 64 wherever legal) / 3 (128 x 128)
-    const int tile_mode = gd_tile_mode();
-    const long long Mh = (M_hint > 0 && M_hint < M) ? M_hint : M;
-    int tm = 1, tn = 1;
-    if (bn == 64 && S == 1 && tile_mode > 0) {
-        const long long wg128x64 = (long long)d3f_cdiv(Mh, 128) * d3f_cdiv(N, 64), wg128x128 = (long long)d3f_cdiv(Mh, 128) * d3f_cdiv(N, 128);
-        if (tile_mode == 3 && N >= 128) { tm = 2; tn = 2; }
-        else if (tile_mode == 2) tm = 2;
-        else if (tile_mode == 1) {
-            if (N >= 128 && wg128x128 >= 1536) { tm = 2; tn = 2; }
-            else if (wg128x64 >= 2048) tm = 2;
-        }
-        bm = 64 * tm;
-        bn = 64 * tn;
-    }
     float* slab = nullptr;
     if (S > 1) {
         if (!workspace || workspace_bytes < (size_t)S * M * N * sizeof(float)) return D3F_ERR_WORKSPACE;
@@ -683,16 +644,9 @@ extern "C" int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int*
     }
     GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
     GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
-    const int st = gd_stages();
-    const size_t lds_bytes = (size_t)st * (bm + bn) * GD_BK * sizeof(float);
-    // persistent grid: every item when they are all resident at once, else what the chip holds (LDS-limited workgroups per CU x
-    // 256 CUs), rounded to a multiple of 8 so that a workgroup's items stay on its XCD (gemm_dma.h)
+    const size_t lds_bytes = (size_t)GD_STAGES * (bm + bn) * GD_BK * sizeof(float);
     const long long items_cap = (long long)d3f_cdiv(N, bn) * S * d3f_cdiv(M, bm);
-    long long resident = (long long)(160 * 1024 / lds_bytes) * 256;
-    if (resident > 256 * 8) resident = 256 * 8;
-    const int pers = gd_persistent();
-    long long gsz = pers ? (items_cap < resident ? items_cap : resident) : items_cap;
-    gsz = (gsz + 7) / 8 * 8;
+    const long long gsz = (items_cap + 7) / 8 * 8;        // one item per workgroup; a multiple of 8 keeps the XCD item order whole
     if (gsz > 0x7fffffffll) return D3F_ERR_ARG;
     dim3 grid((unsigned)gsz, 1, 1);
 #define D3F_GD_E(WM_, WN_, TM_, TN_, ST_, EPI_)                                                                                 \
@@ -716,15 +670,8 @@ extern "C" int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int*
         else if (epi == 2) D3F_GD_E(WM_, WN_, TM_, TN_, ST_, 2);                                                               \
         else D3F_GD_E(WM_, WN_, TM_, TN_, ST_, 3);                                                                             \
     } while (0)
-#define D3F_GD(WM_, WN_, TM_, TN_)                                                                                              \
-    do {                                                                                                                       \
-        if (st == 2) D3F_GD_S(WM_, WN_, TM_, TN_, 2);                                                                          \
-        else D3F_GD_S(WM_, WN_, TM_, TN_, 3);                                                                                  \
-    } while (0)
-    if (bn == 32) D3F_GD(4, 1, 1, 1);
-    else if (tm == 2 && tn == 2) D3F_GD(2, 2, 2, 2);
-    else if (tm == 2) D3F_GD(2, 2, 2, 1);
-    else D3F_GD(2, 2, 1, 1);
+    if (bn == 32) D3F_GD_S(4, 1, 1, 1, GD_STAGES);
+    else D3F_GD_S(2, 2, 1, 1, GD_STAGES);
 #undef D3F_GD
 #undef D3F_GD_S
 #undef D3F_GD_E

@@ -12,8 +12,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DESC_TOL = 3e-2       # max |descriptor component| difference vs the fp32 oracle (unit-norm 32-d descriptors); measured 5e-3
-SCORE_TOL = 3e-2      # max |score| difference; measured 1e-2
+DESC_TOL = 1.5e-2     # max |descriptor component| difference vs the fp32 oracle (unit-norm 32-d descriptors); measured 5e-3 .. 6.5e-3
+SCORE_TOL = 2e-2      # max |score| difference; measured 1e-2 .. 1.1e-2
 FEAT_DESC_TOL = 6e-2  # bf16 feature STORAGE on top (38 layers of 2^-9 roundings of the activations): set from the measured value
 FEAT_SCORE_TOL = 6e-2
 

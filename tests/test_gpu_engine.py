@@ -244,6 +244,30 @@ def test_engine_flagged_batch_isolates_the_outlier(device, setup):
     assert eng.fallbacks == 2 and torch.equal(packed[0][0], refs[3][0])
 
 
+def test_engine_isolates_a_flagged_batch_of_in_place_producers(device, setup):
+    """submit() accepts fragments that a producer wrote straight into the slot's raw buffer (no copy: the data_ptr shortcut).  When
+    such a replay is flagged, the isolation re-submits the fragments one by one THROUGH THE SAME BUFFER: fragment 0's re-run
+    would overwrite fragments 1.. before they are re-submitted -- the engine clones aliased sources first."""
+    from d3feat_amd.engine import FragmentEngine
+    cfg, W, limits = setup
+    eng = FragmentEngine(cfg, W, limits, raw_cap=45000, n0_cap=9000, slots=1, device=device, batch=3)
+    sizes = (6000, 40000, 8000)                              # fragment 1 exceeds the voxel capacity: the replay is flagged
+    hosts = [_frag(190 + i, n) for i, n in enumerate(sizes)]
+    refs = [tuple(t.clone() for t in eng.run_eager(torch.from_numpy(h).to(device))) for h in hosts]
+    raw = eng.slots[0].raw
+    views, o = [], 0
+    for h in hosts:                                          # the producer: decode / copy straight into the slot's buffer
+        raw[o:o + len(h)].copy_(torch.from_numpy(h).to(device))
+        views.append(raw[o:o + len(h)])
+        o += len(h)
+    outs = eng.run(views)
+    assert eng.isolated == 1 and eng.fallbacks == 1
+    for (p, d, s), (rp, rd, rs) in zip(outs, refs):
+        assert torch.equal(p, rp)
+        _close(d, rd, 5e-6)
+        _close(s, rs, 5e-6)
+
+
 def test_packed_weight_copies_outlive_any_cache_traffic(device):
     """A captured graph reads the PACKED copy of its weights (transposed fp32 for the LDS-DMA contraction, bf16 for configs[4]) by
     raw pointer.  The copies therefore ride on the weight tensor itself: no amount of other models' weights going through the
