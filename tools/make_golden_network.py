@@ -214,7 +214,47 @@ def run_ops(tf, mods, base):
     return out
 
 
+def live_check(n_points):
+    """No fixture: the reference's Python (under the stand-in) and oracle/network_np.py on a LARGER crop of the demo cloud, same inputs and
+    weights, in this process; prints one JSON line with the largest differences (tests/test_oracle_vs_reference_python.py)."""
+    tf = setup_imports()
+    work = tempfile.mkdtemp(prefix="d3f_golden_net_")
+    os.chdir(work)
+    import kernels.convolution_ops as conv_ops
+    import models.network_blocks as network_blocks
+    import models.D3Feat as d3feat
+    import datasets.common as common
+    from utils.config import Config
+    mods = (conv_ops, network_blocks, d3feat, common)
+    cfg = Config()
+    cfg.load(os.path.join(REF, "results", "Log_contraloss"))
+    bin0 = np.load(os.path.join(OUT, "demo_bin0_sub003.npy"))
+    c = crop(bin0, 7000, n_points)
+    global ROWS
+    ROWS = 1 << 30                                    # keep whole block outputs
+    a = run_case(tf, mods, cfg, [c, c], [37, 35, 36, 38, 38], tag="live")
+    from oracle import network_np as onp
+    from oracle import seeded_variables as sv
+    W = sv.resolve(a)
+    L = cfg.num_layers
+    inputs = dict(points=[a["points_%d" % l] for l in range(L)], neighbors=[a["neighbors_%d" % l] for l in range(L)],
+                  pools=[a["pools_%d" % l] for l in range(L)], upsamples=[a["upsamples_%d" % l] for l in range(L)],
+                  features=a["features"], batch_weights=a["batch_weights"], in_batches=a["in_batches"], out_batches=a["out_batches"],
+                  stack_lengths=a["stack_lengths"])
+    trace = {}
+    desc, score = onp.forward(cfg, W, inputs, trace=trace)
+    worst = 0.0
+    for scope in json.loads(str(a["block_order"])):
+        want = a["block/" + scope]
+        worst = max(worst, float(np.abs(trace[scope].numpy() - want).max() / max(1.0, np.abs(want).max())))
+    print(json.dumps({"points_per_cloud": int(n_points), "rows": int(len(a["points_0"])), "blocks": len(trace),
+                      "block_rel_max": worst, "desc_max_abs": float(np.abs(desc - a["descriptors"]).max()),
+                      "score_max_abs": float(np.abs(score - a["scores"]).max())}))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--live-check":
+        return live_check(int(sys.argv[2]))
     tf = setup_imports()
     from oracle import clib
     assert clib.ref_available(), "build oracle/_ref first: make -C oracle ref"
