@@ -64,6 +64,11 @@ SIGNATURES = {
     "d3f_gemm_pack_f32t": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "d3f_gemm_f32t": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
                            _vp, _vp, _i, _vp]),
+    "d3f_gemm_x3_packed_bytes": (_sz, [_i, _i]),
+    "d3f_gemm_pack_x3": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "d3f_gemm_x3_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "d3f_gemm_x3": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
+                         _vp, _vp, _i, _vp]),
     "d3f_gemm_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
                            _vp, _vp, _i, _i, _i, _vp]),
     "d3f_decode_xyz_records": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -904,3 +904,91 @@ extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int*
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
+
+// =====================================================================================================================
+// fp32 contraction by exact operand splitting on the bf16 matrix cores (gemm_x3.h)
+// =====================================================================================================================
+#include "gemm_x3.h"
+
+static int gemm_x3_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// 128-row workgroups (x 64 columns, 32 when N <= 32); K split for the skinny deep layers as gemm_plan does it, for this tile
+static void gemm_x3_plan(int M, int N, int K, int M_hint, int& tn, int& S, int& tps) {
+    static const int want_wg = gemm_x3_knob("D3F_X3_WANT", 1024), min_tiles = gemm_x3_knob("D3F_X3_MINT", 4),
+                     below = gemm_x3_knob("D3F_X3_BELOW", 512);
+    if (M_hint > 0 && M_hint < M) M = M_hint;
+    tn = N <= 32 ? 1 : 2;
+    const long long blocks = (long long)d3f_cdiv(M, 128) * d3f_cdiv(N, 32 * tn);
+    const int nt = K / GX_BK;
+    S = 1;
+    if (blocks < below && nt >= 2 * min_tiles) {
+        const long long want = (want_wg + blocks - 1) / blocks, maxs = nt / min_tiles;
+        S = (int)(want < maxs ? want : maxs);
+        if (S > 64) S = 64;
+        if (S < 1) S = 1;
+    }
+    tps = d3f_cdiv(nt, S);
+    S = d3f_cdiv(nt, tps);
+}
+
+extern "C" size_t d3f_gemm_x3_packed_bytes(int K, int N) {
+    if (K < 1 || N < 1) return 0;
+    return (size_t)d3f_cdiv(N, 32) * d3f_cdiv(K, GX_BK) * GX_CHUNK * sizeof(unsigned short);
+}
+
+extern "C" int d3f_gemm_pack_x3(const float* B, int ldb, int K, int N, void* Wx, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 1 || N < 1 || ldb < N || !B || !Wx || ((uintptr_t)Wx & 15)) return D3F_ERR_ARG;
+    const int nkt = d3f_cdiv(K, GX_BK);
+    const long long total = (long long)d3f_cdiv(N, 32) * nkt * GX_CHUNK;
+    gemm_pack_x3_kernel<<<d3f_cdiv(total, 256), 256, 0, stream>>>(B, ldb, K, N, nkt, total, (unsigned short*)Wx);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
+extern "C" size_t d3f_gemm_x3_workspace_bytes(int M, int N, int K, int M_hint) {
+    if (M <= 0 || N <= 0 || K < GX_BK) return 256;
+    int tn, S, tps;
+    gemm_x3_plan(M, N, K, M_hint, tn, S, tps);
+    return S > 1 ? d3f_align((size_t)S * M * N * sizeof(float)) + 256 : 256;
+}
+
+// Same operator and argument meaning as d3f_gemm_f32t; Wx = d3f_gemm_pack_x3(W [K,N]).  On top of d3f_gemm_f32t's addressing rules:
+// K = C1 + C2 a multiple of 32 and, for a concatenated operand, C1 a multiple of 32 too (else D3F_ERR_ARG: use d3f_gemm_f32t).
+// workspace >= d3f_gemm_x3_workspace_bytes(M, N, K, M_hint).
+extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
+                           const void* Wx, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
+                           const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
+                           size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K = C1 + C2;
+    if (M < 0 || N < 1 || N1 < 0 || C1 < 4 || C2 < 0 || (C1 % 4) || (C2 % 4) || (N % 4) || lda < C1 || (lda % 4) || ldc < N || (ldc % 4) ||
+        (C2 > 0 && (lds < C2 || (lds % 4))) || (residual && (ldr < N || (ldr % 4))) || (idx && ld_idx < 1) || (!idx && N1 < M))
+        return D3F_ERR_ARG;
+    if ((K % GX_BK) || (C2 > 0 && (C1 % GX_BK))) return D3F_ERR_ARG;
+    if (M == 0) return D3F_OK;
+    if (!A || !Wx || !C || (C2 > 0 && !skip) ||
+        (((uintptr_t)A | (uintptr_t)Wx | (uintptr_t)C | (uintptr_t)skip | (uintptr_t)residual | (uintptr_t)col_scale | (uintptr_t)col_shift) & 15))
+        return D3F_ERR_ARG;
+    int tn, S, tps;
+    gemm_x3_plan(M, N, K, M_hint, tn, S, tps);
+    float* slab = nullptr;
+    if (S > 1) {
+        if (!workspace || workspace_bytes < (size_t)S * M * N * sizeof(float)) return D3F_ERR_WORKSPACE;
+        slab = (float*)workspace;
+    }
+    if (d3f_cdiv(M, 128) > 65535) return D3F_ERR_ARG;
+    GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
+    GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
+    const int nkt = K / GX_BK, NG = d3f_cdiv(N, 32);
+    dim3 grid(d3f_cdiv(N, 32 * tn), S, d3f_cdiv(M, 128));
+    if (tn == 1) gemm_x3_kernel<1><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G);
+    else gemm_x3_kernel<2><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G);
+    if (S > 1)
+        gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}

@@ -458,6 +458,28 @@ def packed_f32t_weights(W):
     return _packed_on_tensor(W, "_d3f_f32t", make)
 
 
+# The operand-split form (d3f_gemm_x3: exact 3 x bf16 split of both fp32 operands, six bf16 MFMA products per fp32 product, fp32
+# accumulate -- fp32 in, fp32 out, fp32-grade error; csrc/gemm_x3.h) takes every contraction it can address; D3F_GEMM_X3=0 keeps
+# them all on the fp32 MFMA kernel.
+GEMM_X3 = os.environ.get("D3F_GEMM_X3", "1") != "0"
+
+
+def packed_x3_weights(W):
+    """W f32[K,N] (contiguous rows) -> the pre-split bf16 planes d3f_gemm_x3 stages ([column group][k-tile][plane][32][40]); made
+    once per (weight tensor, view, version), like the transposed fp32 copy."""
+    def make():
+        lib = _lib.load()
+        K, N = W.shape
+        t = torch.empty((int(lib.d3f_gemm_x3_packed_bytes(K, N)) // 2,), dtype=torch.int16, device=W.device)
+        _lib.check(lib.d3f_gemm_pack_x3(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_x3")
+        return t
+    return _packed_on_tensor(W, "_d3f_x3", make)
+
+
+def _x3_ok(C1, C2):
+    return GEMM_X3 and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0)
+
+
 def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):
     """Can d3f_gemm_f32t address this call?  (every shape of the network can)"""
     if not GEMM_DMA or N % 4 or ldc % 4 or out.data_ptr() % 16:
@@ -475,6 +497,19 @@ def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):
 def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky,
                alpha, m_dev, n1_dev, hint, dev):
     lib = _lib.load()
+    if _x3_ok(C1, C2):
+        Wx = packed_x3_weights(W)
+        ws = workspace(lib.d3f_gemm_x3_workspace_bytes(M, N, C1 + C2, hint), dev)
+        with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
+            rc = lib.d3f_gemm_x3(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
+                                 skip.data_ptr() if skip is not None else None, lds, C2, Wx.data_ptr(), out.data_ptr(), ldc, M, N,
+                                 row_scale.data_ptr() if row_scale is not None else None,
+                                 col_scale.data_ptr() if col_scale is not None else None,
+                                 col_shift.data_ptr() if col_shift is not None else None,
+                                 residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0, float(alpha),
+                                 ws.data_ptr(), ws.numel(), m_dev, n1_dev, hint, _stream(dev))
+        _lib.check(rc, "gemm_x3")
+        return
     Wt = packed_f32t_weights(W)
     ws = workspace(lib.d3f_gemm_workspace_bytes(M, N, C1 + C2, hint), dev)
     with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):

@@ -317,6 +317,21 @@ int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int* idx, int l
                   const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
                   size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream);
 
+/* Operand-split form of the fp32 contractions: the operator, operands and epilogue of d3f_gemm_f32t, with every fp32 operand value
+ * written EXACTLY as the sum of three bfloat16 values (8 + 8 + 8 significant bits) and every fp32 product as the six exact bf16
+ * products whose sum differs from it by < 2^-23 relative, accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (d3feat_amd/csrc/gemm_x3.h).
+ * fp32 in, fp32 out, fp32-grade error (tests/test_gpu_gemm_x3.py measures it against float64 beside d3f_gemm_f32t's); the weights are
+ * handed over PRE-SPLIT: Wx = d3f_gemm_pack_x3(W f32[K,N]), d3f_gemm_x3_packed_bytes(K, N) bytes, made once per weight tensor.
+ * On top of d3f_gemm_f32t's addressing rules: K = C1 + C2 a multiple of 32 and, with a second operand, C1 a multiple of 32 too --
+ * D3F_ERR_ARG otherwise (use d3f_gemm_f32t).  workspace >= d3f_gemm_x3_workspace_bytes(M, N, K, M_hint). */
+size_t d3f_gemm_x3_packed_bytes(int K, int N);
+int d3f_gemm_pack_x3(const float* W, int ldb, int K, int N, void* Wx, void* stream);
+size_t d3f_gemm_x3_workspace_bytes(int M, int N, int K, int M_hint);
+int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
+                const void* Wx, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
+                const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,
+                size_t workspace_bytes, const int* M_dev, const int* N1_dev, int M_hint, void* stream);
+
 /* bf16-operand form of the contractions (BASELINE.json configs[4]: batched inference, bf16 MFMA contraction): the operator of
  * d3f_gemm_f32 / d3f_gemm_upsample_cat_f32 -- A f32[M, C1] (rows in place when idx == NULL, else the gathered rows
  * x'[idx[m,0]], zero row for indices outside [0, N1)), optional second operand skip f32[M, C2], K = C1 + C2, same epilogue --
