@@ -910,22 +910,17 @@ extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int*
 // =====================================================================================================================
 #include "gemm_x3.h"
 
-static int gemm_x3_knob(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-// 128-row workgroups (x 64 columns, 32 when N <= 32); K split for the skinny deep layers as gemm_plan does it, for this tile
+// 128-row workgroups x 64 columns (32 when N <= 32).  K split for the skinny deep layers, as gemm_plan does it: only below 384
+// workgroups, towards 512, with at least 8 k-tiles per slice (tools/ubench/x3_knobs.sh sweep, profiles/r04_experiments.txt x3-6:
+// fewer, longer slices beat the fp32 kernel's plan here -- a slice costs a slab pass and the reduce launch grows with S).
 static void gemm_x3_plan(int M, int N, int K, int M_hint, int& tn, int& S, int& tps) {
-    static const int want_wg = gemm_x3_knob("D3F_X3_WANT", 1024), min_tiles = gemm_x3_knob("D3F_X3_MINT", 4),
-                     below = gemm_x3_knob("D3F_X3_BELOW", 512);
     if (M_hint > 0 && M_hint < M) M = M_hint;
     tn = N <= 32 ? 1 : 2;
     const long long blocks = (long long)d3f_cdiv(M, 128) * d3f_cdiv(N, 32 * tn);
     const int nt = K / GX_BK;
     S = 1;
-    if (blocks < below && nt >= 2 * min_tiles) {
-        const long long want = (want_wg + blocks - 1) / blocks, maxs = nt / min_tiles;
+    if (blocks < 384 && nt >= 16) {
+        const long long want = (512 + blocks - 1) / blocks, maxs = nt / 8;
         S = (int)(want < maxs ? want : maxs);
         if (S > 64) S = 64;
         if (S < 1) S = 1;
@@ -985,8 +980,10 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
     GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
     const int nkt = K / GX_BK, NG = d3f_cdiv(N, 32);
     dim3 grid(d3f_cdiv(N, 32 * tn), S, d3f_cdiv(M, 128));
-    if (tn == 1) gemm_x3_kernel<1><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G);
-    else gemm_x3_kernel<2><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G);
+#define D3F_GX(TN_, ST_) gemm_x3_kernel<TN_, ST_><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G)
+    if (tn == 1) D3F_GX(1, 3);
+    else D3F_GX(2, 3);
+#undef D3F_GX
     if (S > 1)
         gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);
     D3F_LAUNCH_CHECK();

@@ -12,14 +12,22 @@
 //
 // Layout.  Workgroup = 4 wavefronts stacked along M: 128 rows x 32 TN columns; wave w owns rows 32 w .. 32 w + 31 and ALL the
 // workgroup's columns (TN accumulator tiles), so no A element is loaded or split twice inside a workgroup.
-//   A  never touches LDS: the MFMA A operand wants, per lane (row = lane & 31, half = lane >> 5), eight consecutive k of one
-//      row -- 32 contiguous bytes of the fp32 row.  Each lane loads them straight from global memory (two float4 per 16-deep
-//      step, one k-tile ahead), splits them in registers (v_cvt_pk_bf16_f32 + shift / mask + subtract) into the three operand
-//      planes.  Gathered / concatenated operands ([ x'[idx[m]] | skip[m] ]) are a per-lane row pointer.
+//   A  never touches LDS: the MFMA operand wants, per lane (row = lane & 31, half = lane >> 5), eight consecutive k of one row --
+//      32 contiguous bytes of the fp32 row.  Each lane requests them straight from global memory (four float4 per k-tile, TWO
+//      k-tiles ahead, two register sets) and splits them in registers into the three operand planes (v_cvt_pk_bf16_f32, shift /
+//      mask, packed subtract: 72 vector instructions per k-tile).  Gathered / concatenated operands ([ x'[idx[m]] | skip[m] ])
+//      are a per-lane row pointer; rows that do not exist read a zero line.
 //   W  pre-split ONCE (d3f_gemm_pack_x3): bf16 [column group of 32][k-tile of 32][plane 3][32 rows][40] -- the LDS image itself,
 //      rows padded to 80 bytes (the 16 lanes of a ds_read_b128 group on 16 distinct 4-bank slots), so staging a k-tile is a
-//      linear 7680-byte copy per column group (global -> registers -> ds_write_b128), double buffered, one barrier per k-tile.
-// Per k-tile and wave: 4 global loads, ~90 vector ALU instructions of splitting, 6 TN ds_read_b128, 12 TN MFMAs (384 TN cycles).
+//      linear copy of 7680 bytes per column group: LDS-DMA (global_load_lds_dwordx4) into a ring of three slots, two k-tiles
+//      ahead, no staging registers and no ds_write pass; one barrier per k-tile.
+// Per k-tile and wave: 4 global loads + NB DMA pieces, 72 splitting instructions, 6 TN ds_read_b128, 12 TN MFMAs (384 TN cycles).
+//
+// Measured (profiles/r04_experiments.txt x1-x8): error against float64 BELOW the fp32 MFMA kernel's on the same operands (3e-7 vs
+// 4.4e-7 of max |C|); 1.15x the LDS-DMA fp32 kernel over the network's 26 launches, 1.3-1.4x on its K-long ones.  On gfx950 vector
+// ALU work does NOT hide behind MFMAs of other wavefronts of the SIMD (tools/ubench/mfma_valu_overlap.hip: 24 MFMA + 120 VALU per
+// wave cost 0.48 us where the MFMAs alone cost 0.33, whatever the number of waves), which bounds this form at ~0.7 of the bf16
+// matrix rate it issues; the network's launches are short of that mostly for their size (<= 14 GFLOP, 2-24 k-tiles per workgroup).
 #pragma once
 
 #define GX_BK 32
@@ -36,27 +44,25 @@ __device__ __forceinline__ unsigned gx_cvt_pk(float lo, float hi) {     // two f
 // consumer can be scheduled above it): left to the compiler, the loads of the NEXT k-tile -- written before this tile's MFMAs --
 // are sunk to their first use at the top of the next iteration and the whole memory latency is exposed once per k-tile.
 typedef float gx_f4 __attribute__((ext_vector_type(4)));
-typedef unsigned gx_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gx_ld16(gx_f4& r, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
-__device__ __forceinline__ void gx_ld16o(gx_f4& r, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r) : "v"(p) : "memory");
+template <int OFF> __device__ __forceinline__ void gx_ld16o(gx_f4& r, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void gx_ld16(gx_u4& r, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
 
-// eight consecutive-k floats -> the three operand planes (eight bf16 = one uint4 each)
+// eight consecutive-k floats -> the three operand planes (eight bf16 = one uint4 each).  Per pair of floats and plane: one
+// v_cvt_pk_bf16_f32, the two pieces widened again (shift / mask), one packed subtract -- 9 vector instructions per pair in all.
+typedef float gx_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gx_split8(const gx_f4& x0, const gx_f4& x1, uint4 (&pl)[3]) {
-    float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    const gx_f2 v[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
     unsigned p[3][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float a = v[2 * i], b = v[2 * i + 1];
-        p[0][i] = gx_cvt_pk(a, b);
-        a -= __uint_as_float(p[0][i] << 16);
-        b -= __uint_as_float(p[0][i] & 0xffff0000u);
-        p[1][i] = gx_cvt_pk(a, b);
-        a -= __uint_as_float(p[1][i] << 16);
-        b -= __uint_as_float(p[1][i] & 0xffff0000u);
-        p[2][i] = gx_cvt_pk(a, b);
+        gx_f2 a = v[i];
+        p[0][i] = gx_cvt_pk(a[0], a[1]);
+        a -= gx_f2{__uint_as_float(p[0][i] << 16), __uint_as_float(p[0][i] & 0xffff0000u)};
+        p[1][i] = gx_cvt_pk(a[0], a[1]);
+        a -= gx_f2{__uint_as_float(p[1][i] << 16), __uint_as_float(p[1][i] & 0xffff0000u)};
+        p[2][i] = gx_cvt_pk(a[0], a[1]);
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) pl[s] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
@@ -85,16 +91,36 @@ __global__ void __launch_bounds__(256) gemm_pack_x3_kernel(const float* __restri
     Wx[t] = (unsigned short)out;
 }
 
-template <int TN>
-#ifndef GX_EXP_WAVES
-#define GX_EXP_WAVES 2, 3
-#endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GX_EXP_WAVES)))
+// One LDS-DMA round of a W k-tile: NB pieces (64 lanes x 16 bytes each, linear from the wave's base M0), the sources addressed
+// as scalar base + per-lane 32-bit byte offset.  M0 is saved / restored around the round; the asm is absent from the compiler's
+// vmcnt bookkeeping (see above).
+template <int NB>
+__device__ __forceinline__ void gx_dma_round(const void* sbase, unsigned dst, const unsigned (&vo)[4]) {
+    unsigned keep;
+    if constexpr (NB == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "s"(dst), "v"(vo[0]), "v"(vo[1]) : "memory", "scc");
+    else if constexpr (NB == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "s"(dst), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]) : "memory", "scc");
+    else static_assert(NB < 0, "add the round");
+}
+
+// TN: 32-column groups per workgroup (1 or 2); STAGES: k-tiles of W in the LDS ring
+template <int TN, int STAGES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
 gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wx, int nkt, int NG, float* __restrict__ C,
                int ldc, int M, int N, int tiles_per_split, float* __restrict__ slab, GemmEpi E, const int* __restrict__ M_dev,
                GemmGather G) {
     constexpr int BM = 128, BN = 32 * TN;
-    constexpr int NB = (480 * TN + 255) / 256;      // uint4 of W per thread and k-tile
+    constexpr int NB = (480 * TN + 255) / 256;      // DMA pieces (uint4 per thread) of a W k-tile: 2 or 4
+    constexpr int SB = NB * 4096;                   // bytes per ring slot: the TN chunks + the tail the surplus lanes of the last piece hit
+    constexpr int WAITN = 4 + (STAGES == 3 ? NB : 0);   // requests that may still be in flight when a tile is consumed (below)
+    static_assert((TN == 1 || TN == 2) && (STAGES == 2 || STAGES == 3), "tile shape");
     const int Mcap = M;
     M = d3f_dyn(M, M_dev);
     if ((int)(blockIdx.z * BM) >= M) return;        // capacity-sized grid (row tile = slowest dispatch dimension)
@@ -103,15 +129,15 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
     const unsigned gx_ = gridDim.x, gxy_ = gridDim.x * gridDim.y;
     const unsigned T_ = d3f_xcd_tile(blockIdx.x + gx_ * blockIdx.y + gxy_ * blockIdx.z, gxy_ * (unsigned)((M + BM - 1) / BM));
     const unsigned bz = T_ / gxy_, by = (T_ % gxy_) / gx_, bx = T_ % gx_;
-    // (+ 512: the last uint4 round of the staging copy is not full; its surplus threads store into this tail instead of branching)
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][TN * GX_CHUNK + 512];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[STAGES * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = bz * BM, n0 = bx * BN;
     const int t_begin = by * tiles_per_split;
     const int t_end = min(nkt, t_begin + tiles_per_split);
+    const int t_last = t_end - 1;
 
     // ---- the lane's A row: its own, or the gathered one; second operand of a concatenation.  Branch-free loads: a row that does not
-    // exist (beyond M, shadow / out-of-range index) is the zero line read at offset 0 (offset mask 0).
+    // exist (beyond M, shadow / out-of-range index) is the zero line, read at offset 0 whatever the k-tile (offset mask 0).
     const int gm_a = m0 + 32 * wave + (lane & 31);
     const float* arow = gd_zero_line;
     const float* a2row = gd_zero_line;
@@ -128,69 +154,56 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
     }
     const int kofs = (lane >> 5) << 3;
     const int K1 = G.K1;                                   // a multiple of 32 when there is a second operand: a k-tile has ONE source
+    // running pointer to the lane's eight floats of the next tile to REQUEST (requests go tile by tile, clamped at the last)
+    const float* pa;
+    unsigned astep;                                        // floats per k-tile for this lane: 32, or 0 on the zero line
+    int treq = t_begin;
+    auto a_rebase = [&](int t) {
+        const bool first = t * GX_BK < K1;                 // (wave-uniform)
+        const unsigned msk = first ? amask : a2mask;
+        pa = (first ? arow : a2row) + ((unsigned)((first ? t * GX_BK : t * GX_BK - K1) + kofs) & msk);
+        astep = (unsigned)GX_BK & msk;
+    };
+    a_rebase(t_begin);
 
-    // ---- the thread's share of a W k-tile: uint4 number e = tid + 256 i of the TN chunks of 480 (surplus: a valid chunk, LDS tail).
-    // (named scalars, not arrays: an array of uint4 that lives across the loop is demoted to LDS by the compiler)
-    auto wsrc = [&](int i) {
-        const int e = tid + 256 * i;
+    // ---- the thread's share of a W k-tile: uint4 number e = tid + 256 i of the TN chunks of 480; the LDS image of a slot is the
+    // chunks one after the other, i.e. uint4 number e lands at byte 16 e: an LDS-DMA piece per wave and i.  (Surplus lanes of the
+    // last piece: a valid chunk as source, the slot's tail as target.)  Source = scalar base of the k-tile + per-lane byte offset.
+    unsigned wofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * (i < NB ? i : 0);
         const int c = e / 480, o = e - 480 * c;
         const int ng = min((int)bx * TN + c, NG - 1);
-        return (const uint4*)(Wx + ((size_t)ng * nkt + t_begin) * GX_CHUNK) + o;
-    };
-    auto wdst = [&](int i) {
-        const int e = tid + 256 * i;
-        const int c = e / 480, o = e - 480 * c;
-        return c * GX_CHUNK + o * 8;
-    };
-    const uint4 *bsrc0 = wsrc(0), *bsrc1 = wsrc(1), *bsrc2 = wsrc(NB > 2 ? 2 : 0), *bsrc3 = wsrc(NB > 3 ? 3 : 0);
-    const int bdst0 = wdst(0), bdst1 = wdst(1), bdst2 = wdst(2), bdst3 = wdst(3);
-    gx_u4 rb0, rb1, rb2, rb3;
-    gx_f4 raw00, raw01, raw10, raw11;          // [16-deep step][float4 of the lane's eight k]
+        wofs[i] = (unsigned)ng * (unsigned)nkt * (unsigned)(GX_CHUNK * 2) + (unsigned)o * 16u;
+    }
+    const unsigned lds_wave = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)((unsigned)(unsigned long long)(gd_lptr)Bs + (unsigned)wave * 1024u));
+
+    gx_f4 rawA0, rawA1, rawA2, rawA3, rawB0, rawB1, rawB2, rawB3;      // two k-tiles of the lane's A floats in flight
     uint4 ap[2][3];
-    // W first, A second: the staging stores need only the older half of the queue (vmcnt(4))
-    auto request = [&](int t) {
-        const size_t wo = (size_t)(t - t_begin) * (GX_CHUNK / 8);
-        gx_ld16(rb0, bsrc0 + wo);
-        gx_ld16(rb1, bsrc1 + wo);
-        if (NB > 2) gx_ld16(rb2, bsrc2 + wo);
-        if (NB > 3) gx_ld16(rb3, bsrc3 + wo);
-        const bool first = t * GX_BK < K1;                 // (wave-uniform)
-        const float* base = first ? arow : a2row;
-        const unsigned msk = first ? amask : a2mask;
-        const int kk = (first ? t * GX_BK : t * GX_BK - K1) + kofs;
-        const float* p0 = base + ((unsigned)kk & msk);
-        const float* p1 = base + ((unsigned)(kk + 16) & msk);
-#ifdef GX_EXP_NOLOADA
-        gx_ld16(raw00, gd_zero_line);
-        gx_ld16(raw01, gd_zero_line);
-        gx_ld16(raw10, gd_zero_line);
-        gx_ld16(raw11, gd_zero_line);
-        asm volatile("" : : "v"(p0), "v"(p1));
-#else
-        gx_ld16(raw00, p0);
-        gx_ld16o(raw01, p0);
-        gx_ld16(raw10, p1);
-        gx_ld16o(raw11, p1);
-#endif
+    auto request_w = [&](int t, int slot) {
+        gx_dma_round<NB>((const char*)Wx + (size_t)t * (GX_CHUNK * 2), lds_wave + (unsigned)slot * (unsigned)SB, wofs);
     };
-    auto store_b = [&](int buf) {
-        if (NB > 3) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3) : : "memory");
-        else if (NB > 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rb0), "+v"(rb1), "+v"(rb2) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(rb0), "+v"(rb1) : : "memory");
-        *(gx_u4*)&Bs[buf][bdst0] = rb0;
-        *(gx_u4*)&Bs[buf][bdst1] = rb1;
-        if (NB > 2) *(gx_u4*)&Bs[buf][bdst2] = rb2;
-        if (NB > 3) *(gx_u4*)&Bs[buf][bdst3] = rb3;
+    auto request_a = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
+        gx_ld16(r0, pa);
+        gx_ld16o<16>(r1, pa);
+        gx_ld16o<64>(r2, pa);
+        gx_ld16o<80>(r3, pa);
+        if (treq < t_last) {                               // (wave-uniform) advance to the next tile; past the end: the last tile again
+            ++treq;
+            if (treq * GX_BK == K1) a_rebase(treq);
+            else pa += astep;
+        }
     };
-    auto split = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw00), "+v"(raw01), "+v"(raw10), "+v"(raw11) : : "memory");
-#ifdef GX_EXP_NOSPLIT
-        ap[0][0] = __builtin_bit_cast(uint4, raw00); ap[0][1] = __builtin_bit_cast(uint4, raw01); ap[0][2] = ap[0][0];
-        ap[1][0] = __builtin_bit_cast(uint4, raw10); ap[1][1] = __builtin_bit_cast(uint4, raw11); ap[1][2] = ap[1][0];
-#else
-        gx_split8(raw00, raw01, ap[0]);
-        gx_split8(raw10, raw11, ap[1]);
-#endif
+    // everything but the newest WAITN requests has landed -> split the older tile's floats
+    auto split = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
+        if constexpr (WAITN == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+        else if constexpr (WAITN == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+        static_assert(WAITN == 4 || WAITN == 6 || WAITN == 8, "wait count");
+        gx_split8(r0, r1, ap[0]);
+        gx_split8(r2, r3, ap[1]);
     };
 
     f32x16 acc[TN];
@@ -199,51 +212,66 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // W fragments: lane (c = lane & 31, h = lane >> 5) holds k = 8 h .. 8 h + 7 of a 16-deep step, row c of the column group
-    auto compute = [&](int buf) {
-        const unsigned short* bp = &Bs[buf][(lane & 31) * GX_LS + kofs];
+    // W fragments: lane (c = lane & 31, h = lane >> 5) holds k = 8 h .. 8 h + 7 of a 16-deep step, row c of the column group.
+    // Column groups two at a time: two accumulator chains alternate, smallest terms first.
+    auto compute = [&](int slot) {
+        const unsigned short* bp = (const unsigned short*)(Bs + slot * SB) + (lane & 31) * GX_LS + kofs;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            uint4 b[TN][3];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j0 = 0; j0 < TN; j0 += 2) {
+                constexpr int JW = TN >= 2 ? 2 : 1;
+                uint4 b[JW][3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[j][p] = *(const uint4*)(bp + j * GX_CHUNK + p * (32 * GX_LS) + 16 * s);
-            // smallest terms first; the TN accumulator chains alternate
+                for (int j = 0; j < JW; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[j][p] = *(const uint4*)(bp + (j0 + j) * GX_CHUNK + p * (32 * GX_LS) + 16 * s);
 #define GX_MFMA(PA_, PB_)                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                             \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, b[j][PB_]),                             \
-                                                         __builtin_bit_cast(gb_bf16x8, ap[s][PA_]), acc[j], 0, 0, 0)
-#ifndef GX_EXP_ONEMFMA
-            GX_MFMA(2, 0);
-            GX_MFMA(1, 1);
-            GX_MFMA(0, 2);
-            GX_MFMA(1, 0);
-            GX_MFMA(0, 1);
-#endif
-            GX_MFMA(0, 0);
+    _Pragma("unroll") for (int j = 0; j < JW; ++j)                                                                             \
+        acc[j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, b[j][PB_]),                        \
+                                                              __builtin_bit_cast(gb_bf16x8, ap[s][PA_]), acc[j0 + j], 0, 0, 0)
+                GX_MFMA(2, 0);
+                GX_MFMA(1, 1);
+                GX_MFMA(0, 2);
+                GX_MFMA(1, 0);
+                GX_MFMA(0, 1);
+                GX_MFMA(0, 0);
 #undef GX_MFMA
+            }
         }
     };
 
-    // One k-tile per iteration: the tile's operands were requested a whole compute phase ago (raw A floats and W in registers);
-    // they are staged / split at the top, one barrier publishes W (and fences the buffer the stores of the NEXT iteration reuse),
-    // the next tile's requests are issued and fly during this tile's 12 TN MFMAs.  (The last iteration re-requests its own tile:
-    // no branch in the loop; the final wait keeps the request registers alive until those loads have landed.)
+    // Requests run ahead of the MFMAs: W by LDS-DMA STAGES - 1 k-tiles ahead (ring of STAGES slots), the lane's A floats two tiles
+    // ahead (two register sets).  Iteration t: wait until at most WAITN requests are in flight (= tile t has landed: the queue retires
+    // in order), split its A floats, ONE barrier (tile t's W pieces of all four waves are visible; every wave is done with tile
+    // t - 1, whose ring slot and register set the next requests reuse), issue the next requests (W first), 12 TN MFMAs.  Tile
+    // indices are clamped, not branched on: past the end the last tile is requested again into a slot nobody reads, and the final
+    // wait keeps the request registers alive until those loads have landed.
     if (t_begin < t_end) {
-        request(t_begin);
-        int buf = 0;
-        for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
-            store_b(buf);
-            split();
+        int wslot = 0, cslot = 0;
+        auto next = [&](int sl) { return sl + 1 == STAGES ? 0 : sl + 1; };
+        request_w(t_begin, wslot); wslot = next(wslot);
+        request_a(rawA0, rawA1, rawA2, rawA3);
+        if (STAGES == 3) { request_w(min(t_begin + 1, t_last), wslot); wslot = next(wslot); }
+        request_a(rawB0, rawB1, rawB2, rawB3);
+        for (int t = t_begin; t < t_end; t += 2) {
+            split(rawA0, rawA1, rawA2, rawA3);
             __syncthreads();
-            request(min(t + 1, t_end - 1));
-            compute(buf);
+            request_w(min(t + STAGES - 1, t_last), wslot); wslot = next(wslot);
+            request_a(rawA0, rawA1, rawA2, rawA3);
+            compute(cslot); cslot = next(cslot);
+            if (t + 1 < t_end) {
+                split(rawB0, rawB1, rawB2, rawB3);
+                __syncthreads();
+                request_w(min(t + STAGES, t_last), wslot); wslot = next(wslot);
+                request_a(rawB0, rawB1, rawB2, rawB3);
+                compute(cslot); cslot = next(cslot);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb0), "+v"(rb1), "+v"(raw00), "+v"(raw01), "+v"(raw10), "+v"(raw11) : : "memory");
-        if (NB > 2) asm volatile("" : "+v"(rb2) : : "memory");
-        if (NB > 3) asm volatile("" : "+v"(rb3) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA0), "+v"(rawA1), "+v"(rawA2), "+v"(rawA3), "+v"(rawB0), "+v"(rawB1), "+v"(rawB2),
+                     "+v"(rawB3) : : "memory");
     }
+    __syncthreads();        // (no wave leaves -- and lets the workgroup's LDS be handed on -- while another wave's DMA may be in flight)
 
     // The product is computed transposed (W fragment as the MFMA's first operand): D[i][jm] with i = column of the group, jm = the
     // lane's own A row.  C/D layout of the 32x32 MFMA: jm = lane & 31, i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- four consecutive
