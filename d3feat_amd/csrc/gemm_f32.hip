@@ -910,23 +910,42 @@ extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int*
 // =====================================================================================================================
 #include "gemm_x3.h"
 
-// 128-row workgroups x 64 columns (32 when N <= 32).  K split for the skinny deep layers, as gemm_plan does it: only below 384
-// workgroups, towards 512, with at least 8 k-tiles per slice (tools/ubench/x3_knobs.sh sweep, profiles/r04_experiments.txt x3-6:
-// fewer, longer slices beat the fp32 kernel's plan here -- a slice costs a slab pass and the reduce launch grows with S).
-static void gemm_x3_plan(int M, int N, int K, int M_hint, int& tn, int& S, int& tps) {
-    if (M_hint > 0 && M_hint < M) M = M_hint;
-    tn = N <= 32 ? 1 : 2;
-    const long long blocks = (long long)d3f_cdiv(M, 128) * d3f_cdiv(N, 32 * tn);
-    const int nt = K / GX_BK;
+// Tile and K split.  Three workgroup shapes: 128 rows x 32 / 64 columns (4 wavefronts, 2 resident per CU) and 256 x 128 (8
+// wavefronts, 1 per CU: a quarter of the operand traffic per product -- both forms are bound by what the CUs can pull out of L2,
+// ~9 TB/s -- but a quarter of the workgroups).  For each candidate the K slice count that minimises
+//   rounds(workgroups / resident slots) x (k-tiles per slice + a workgroup's fixed cost) x its time per k-tile  +  the slab pass,
+// in units of one k-tile of the 128 x 64 form (the 256 x 128 form's k-tile costs 1.63 of them: 3.1 against 1.9 us at M = 65536,
+// K = 3072, N = 256); the cheaper candidate wins.  E.g. 288 workgroups x 96 k-tiles (M = 4525, K = 3072, N = 512) are ONE round
+// of 96 unsplit, two rounds of 48 halved (576 > 512 slots), 2 x 36 in thirds -- and one round of 36 x 1.63 as 72 x 3 big ones.
+struct GemmX3Plan { int tn, waves, S, tps; };
+static long long gemm_x3_cost(long long blocks, long long slots, int nt, int per_tile_x100, int& S) {
+    long long best = -1;
     S = 1;
-    if (blocks < 384 && nt >= 16) {
-        const long long want = (512 + blocks - 1) / blocks, maxs = nt / 8;
-        S = (int)(want < maxs ? want : maxs);
-        if (S > 64) S = 64;
-        if (S < 1) S = 1;
+    for (int s = 1; s <= 64 && s * 4 <= nt; ++s) {
+        const int t = d3f_cdiv(nt, s);
+        if (d3f_cdiv(nt, t) != s) continue;
+        const long long rounds = (blocks * s + slots - 1) / slots;
+        const long long cost = rounds * (t + 4) * per_tile_x100 + (s > 1 ? 200ll * s : 0);
+        if (best < 0 || cost < best) { best = cost; S = s; }
     }
-    tps = d3f_cdiv(nt, S);
-    S = d3f_cdiv(nt, tps);
+    if (best < 0) best = ((blocks + slots - 1) / slots) * (nt + 4) * per_tile_x100;      // fewer than 4 k-tiles: never split
+    return best;
+}
+static GemmX3Plan gemm_x3_plan(int M, int N, int K, int M_hint) {
+    if (M_hint > 0 && M_hint < M) M = M_hint;
+    const int nt = K / GX_BK;
+    GemmX3Plan p;
+    p.tn = N <= 32 ? 1 : 2;
+    p.waves = 4;
+    const long long c_small = gemm_x3_cost((long long)d3f_cdiv(M, 128) * d3f_cdiv(N, 32 * p.tn), 512, nt, 100, p.S);
+    if (N >= 128) {
+        int s_big;
+        const long long c_big = gemm_x3_cost((long long)d3f_cdiv(M, 256) * d3f_cdiv(N, 128), 256, nt, 163, s_big);
+        if (c_big < c_small) { p.tn = 4; p.waves = 8; p.S = s_big; }
+    }
+    p.tps = d3f_cdiv(nt, p.S);
+    p.S = d3f_cdiv(nt, p.tps);
+    return p;
 }
 
 extern "C" size_t d3f_gemm_x3_packed_bytes(int K, int N) {
@@ -946,9 +965,8 @@ extern "C" int d3f_gemm_pack_x3(const float* B, int ldb, int K, int N, void* Wx,
 
 extern "C" size_t d3f_gemm_x3_workspace_bytes(int M, int N, int K, int M_hint) {
     if (M <= 0 || N <= 0 || K < GX_BK) return 256;
-    int tn, S, tps;
-    gemm_x3_plan(M, N, K, M_hint, tn, S, tps);
-    return S > 1 ? d3f_align((size_t)S * M * N * sizeof(float)) + 256 : 256;
+    const GemmX3Plan p = gemm_x3_plan(M, N, K, M_hint);
+    return p.S > 1 ? d3f_align((size_t)p.S * M * N * sizeof(float)) + 256 : 256;
 }
 
 // Same operator and argument meaning as d3f_gemm_f32t; Wx = d3f_gemm_pack_x3(W [K,N]).  On top of d3f_gemm_f32t's addressing rules:
@@ -968,21 +986,22 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
     if (!A || !Wx || !C || (C2 > 0 && !skip) ||
         (((uintptr_t)A | (uintptr_t)Wx | (uintptr_t)C | (uintptr_t)skip | (uintptr_t)residual | (uintptr_t)col_scale | (uintptr_t)col_shift) & 15))
         return D3F_ERR_ARG;
-    int tn, S, tps;
-    gemm_x3_plan(M, N, K, M_hint, tn, S, tps);
+    const GemmX3Plan pl = gemm_x3_plan(M, N, K, M_hint);
+    const int S = pl.S, tps = pl.tps, bm = 32 * pl.waves;
     float* slab = nullptr;
     if (S > 1) {
         if (!workspace || workspace_bytes < (size_t)S * M * N * sizeof(float)) return D3F_ERR_WORKSPACE;
         slab = (float*)workspace;
     }
-    if (d3f_cdiv(M, 128) > 65535) return D3F_ERR_ARG;
+    if (d3f_cdiv(M, bm) > 65535) return D3F_ERR_ARG;
     GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
     GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
     const int nkt = K / GX_BK, NG = d3f_cdiv(N, 32);
-    dim3 grid(d3f_cdiv(N, 32 * tn), S, d3f_cdiv(M, 128));
-#define D3F_GX(TN_, ST_) gemm_x3_kernel<TN_, ST_><<<grid, 256, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G)
-    if (tn == 1) D3F_GX(1, 3);
-    else D3F_GX(2, 3);
+    dim3 grid(d3f_cdiv(N, 32 * pl.tn), S, d3f_cdiv(M, bm));
+#define D3F_GX(TN_, WV_) gemm_x3_kernel<TN_, WV_><<<grid, 64 * WV_, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G)
+    if (pl.waves == 8) D3F_GX(4, 8);
+    else if (pl.tn == 1) D3F_GX(1, 4);
+    else D3F_GX(2, 4);
 #undef D3F_GX
     if (S > 1)
         gemm_splitk_reduce_kernel<<<d3f_cdiv((long long)M * N, 256), 256, 0, stream>>>(slab, S, M, N, C, ldc, E, M_dev);

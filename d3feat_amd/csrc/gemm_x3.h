@@ -49,20 +49,28 @@ template <int OFF> __device__ __forceinline__ void gx_ld16o(gx_f4& r, const void
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
 }
 
-// eight consecutive-k floats -> the three operand planes (eight bf16 = one uint4 each).  Per pair of floats and plane: one
-// v_cvt_pk_bf16_f32, the two pieces widened again (shift / mask), one packed subtract -- 9 vector instructions per pair in all.
-typedef float gx_f2 __attribute__((ext_vector_type(2)));
+// eight consecutive-k floats -> the three operand planes (eight bf16 = one uint4 each).  Per pair of floats: v_cvt_pk_bf16_f32, the
+// two pieces widened again (shift / mask), two subtracts, twice, and a last v_cvt_pk: 11 vector instructions.  The subtracts go
+// through inline asm: left alone, the SLP vectoriser packs them into v_pk_add_f32, which costs ~13 extra cycles each beside MFMAs
+// (MI355X_MICROARCH.md "price of one filler beside MFMAs"; tools/ubench/mfma_valu_overlap.hip).
+__device__ __forceinline__ float gx_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void gx_split8(const gx_f4& x0, const gx_f4& x1, uint4 (&pl)[3]) {
-    const gx_f2 v[4] = {{x0[0], x0[1]}, {x0[2], x0[3]}, {x1[0], x1[1]}, {x1[2], x1[3]}};
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
     unsigned p[3][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        gx_f2 a = v[i];
-        p[0][i] = gx_cvt_pk(a[0], a[1]);
-        a -= gx_f2{__uint_as_float(p[0][i] << 16), __uint_as_float(p[0][i] & 0xffff0000u)};
-        p[1][i] = gx_cvt_pk(a[0], a[1]);
-        a -= gx_f2{__uint_as_float(p[1][i] << 16), __uint_as_float(p[1][i] & 0xffff0000u)};
-        p[2][i] = gx_cvt_pk(a[0], a[1]);
+        float a = v[2 * i], b = v[2 * i + 1];
+        p[0][i] = gx_cvt_pk(a, b);
+        a = gx_sub(a, __uint_as_float(p[0][i] << 16));
+        b = gx_sub(b, __uint_as_float(p[0][i] & 0xffff0000u));
+        p[1][i] = gx_cvt_pk(a, b);
+        a = gx_sub(a, __uint_as_float(p[1][i] << 16));
+        b = gx_sub(b, __uint_as_float(p[1][i] & 0xffff0000u));
+        p[2][i] = gx_cvt_pk(a, b);
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) pl[s] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
@@ -91,36 +99,36 @@ __global__ void __launch_bounds__(256) gemm_pack_x3_kernel(const float* __restri
     Wx[t] = (unsigned short)out;
 }
 
-// One LDS-DMA round of a W k-tile: NB pieces (64 lanes x 16 bytes each, linear from the wave's base M0), the sources addressed
-// as scalar base + per-lane 32-bit byte offset.  M0 is saved / restored around the round; the asm is absent from the compiler's
-// vmcnt bookkeeping (see above).
-template <int NB>
+// One LDS-DMA round of a W k-tile: NB pieces per wave (64 lanes x 16 bytes each, linear from the wave's base M0; consecutive pieces
+// of a workgroup are STRIDE = 1 KiB x its wavefronts apart), the sources addressed as scalar base + per-lane 32-bit byte offset.
+// M0 is saved / restored around the round; the asm is absent from the compiler's vmcnt bookkeeping (see above).
+template <int NB, int STRIDE>
 __device__ __forceinline__ void gx_dma_round(const void* sbase, unsigned dst, const unsigned (&vo)[4]) {
     unsigned keep;
     if constexpr (NB == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(sbase), "s"(dst), "v"(vo[0]), "v"(vo[1]) : "memory", "scc");
+                     "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "s"(dst), "v"(vo[0]), "v"(vo[1]), "n"(STRIDE) : "memory", "scc");
     else if constexpr (NB == 4)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(sbase), "s"(dst), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]) : "memory", "scc");
+                     "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+                     "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+                     "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "s"(dst), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "n"(STRIDE) : "memory", "scc");
     else static_assert(NB < 0, "add the round");
 }
 
-// TN: 32-column groups per workgroup (1 or 2); STAGES: k-tiles of W in the LDS ring
-template <int TN, int STAGES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
+// TN: 32-column groups per workgroup; WAVES: its wavefronts (32 rows each).  Shipped: 128 x 32, 128 x 64 (4 waves) and 256 x 128 (8)
+template <int TN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wx, int nkt, int NG, float* __restrict__ C,
                int ldc, int M, int N, int tiles_per_split, float* __restrict__ slab, GemmEpi E, const int* __restrict__ M_dev,
                GemmGather G) {
-    constexpr int BM = 128, BN = 32 * TN;
-    constexpr int NB = (480 * TN + 255) / 256;      // DMA pieces (uint4 per thread) of a W k-tile: 2 or 4
-    constexpr int SB = NB * 4096;                   // bytes per ring slot: the TN chunks + the tail the surplus lanes of the last piece hit
-    constexpr int WAITN = 4 + (STAGES == 3 ? NB : 0);   // requests that may still be in flight when a tile is consumed (below)
-    static_assert((TN == 1 || TN == 2) && (STAGES == 2 || STAGES == 3), "tile shape");
+    constexpr int BM = 32 * WAVES, BN = 32 * TN, NTH = 64 * WAVES;
+    constexpr int NB = (480 * TN + NTH - 1) / NTH;  // DMA pieces (uint4 per thread) of a W k-tile: 2 or 4
+    constexpr int SB = NB * NTH * 16;               // bytes per ring slot: the TN chunks + the tail the surplus lanes of the last piece hit
+    constexpr int WAITN = 4 + NB;                   // requests of ONE iteration: what may still be in flight when a tile is consumed
+    static_assert((TN == 1 || TN == 2 || TN == 4) && (WAVES == 4 || WAVES == 8), "tile shape");
     const int Mcap = M;
     M = d3f_dyn(M, M_dev);
     if ((int)(blockIdx.z * BM) >= M) return;        // capacity-sized grid (row tile = slowest dispatch dimension)
@@ -129,7 +137,7 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
     const unsigned gx_ = gridDim.x, gxy_ = gridDim.x * gridDim.y;
     const unsigned T_ = d3f_xcd_tile(blockIdx.x + gx_ * blockIdx.y + gxy_ * blockIdx.z, gxy_ * (unsigned)((M + BM - 1) / BM));
     const unsigned bz = T_ / gxy_, by = (T_ % gxy_) / gx_, bx = T_ % gx_;
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[STAGES * SB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = bz * BM, n0 = bx * BN;
     const int t_begin = by * tiles_per_split;
@@ -172,7 +180,7 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
     unsigned wofs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int e = tid + 256 * (i < NB ? i : 0);
+        const int e = tid + NTH * (i < NB ? i : 0);
         const int c = e / 480, o = e - 480 * c;
         const int ng = min((int)bx * TN + c, NG - 1);
         wofs[i] = (unsigned)ng * (unsigned)nkt * (unsigned)(GX_CHUNK * 2) + (unsigned)o * 16u;
@@ -180,10 +188,10 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
     const unsigned lds_wave = (unsigned)__builtin_amdgcn_readfirstlane(
         (int)((unsigned)(unsigned long long)(gd_lptr)Bs + (unsigned)wave * 1024u));
 
-    gx_f4 rawA0, rawA1, rawA2, rawA3, rawB0, rawB1, rawB2, rawB3;      // two k-tiles of the lane's A floats in flight
-    uint4 ap[2][3];
+    gx_f4 rA0, rA1, rA2, rA3, rB0, rB1, rB2, rB3, rC0, rC1, rC2, rC3;      // three k-tiles of the lane's A floats: two in flight
+    uint4 ap0[2][3], ap1[2][3];                                           // operand planes of the current / the next k-tile
     auto request_w = [&](int t, int slot) {
-        gx_dma_round<NB>((const char*)Wx + (size_t)t * (GX_CHUNK * 2), lds_wave + (unsigned)slot * (unsigned)SB, wofs);
+        gx_dma_round<NB, WAVES * 1024>((const char*)Wx + (size_t)t * (GX_CHUNK * 2), lds_wave + (unsigned)slot * (unsigned)SB, wofs);
     };
     auto request_a = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
         gx_ld16(r0, pa);
@@ -196,15 +204,6 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
             else pa += astep;
         }
     };
-    // everything but the newest WAITN requests has landed -> split the older tile's floats
-    auto split = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
-        if constexpr (WAITN == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
-        else if constexpr (WAITN == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
-        static_assert(WAITN == 4 || WAITN == 6 || WAITN == 8, "wait count");
-        gx_split8(r0, r1, ap[0]);
-        gx_split8(r2, r3, ap[1]);
-    };
 
     f32x16 acc[TN];
 #pragma unroll
@@ -212,64 +211,108 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    // One k-tile: the 12 TN MFMAs of tile t on planes `cur`, and IN THEIR SHADOW the splitting of tile t + 1's floats (r0..r3) into
+    // planes `nxt`.  On gfx950 vector instructions do not overlap with the MFMAs of OTHER wavefronts, only with the wave's own when
+    // they are interleaved a few per MFMA (tools/ubench/mfma_valu_overlap.hip: 24 MFMA + 120 VALU cost 0.57 us one after the other,
+    // 0.38 us interleaved 1 : 5, against 0.37 us for the MFMAs alone -- whatever the number of waves per SIMD).  The 88 splitting
+    // instructions are therefore written as a flat list of micro-operations (seven dependent levels over the 16 floats) and dealt
+    // out behind the MFMAs in program order, pinned by sched_barrier (the sched_group_barrier masks do not see inline asm).
     // W fragments: lane (c = lane & 31, h = lane >> 5) holds k = 8 h .. 8 h + 7 of a 16-deep step, row c of the column group.
-    // Column groups two at a time: two accumulator chains alternate, smallest terms first.
-    auto compute = [&](int slot) {
+    auto tile = [&](int slot, const uint4 (&cur)[2][3], uint4 (&nxt)[2][3], const gx_f4& r0, const gx_f4& r1, const gx_f4& r2,
+                    const gx_f4& r3) {
         const unsigned short* bp = (const unsigned short*)(Bs + slot * SB) + (lane & 31) * GX_LS + kofs;
+        constexpr int NM = 12 * TN, NOPS = 88;
+        // (operand plane of A, of W) per product.  First 16-deep step: smallest terms first.  Second step: W planes in the order
+        // 2, 1, 1, 0, 0, 0 -- its fragments are read into the registers of the first step's, plane by plane as the first step is
+        // done with them (plane 2 after its third product, plane 1 after the fifth, plane 0 after the sixth): no second set of
+        // fragment registers, which is what keeps three wavefronts per SIMD resident.
+        constexpr int PA[2][6] = {{2, 1, 0, 1, 0, 0}, {0, 1, 0, 2, 1, 0}}, PB[2][6] = {{0, 1, 2, 0, 1, 0}, {2, 1, 1, 0, 0, 0}};
+        uint4 b[TN][3];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j0 = 0; j0 < TN; j0 += 2) {
-                constexpr int JW = TN >= 2 ? 2 : 1;
-                uint4 b[JW][3];
+            for (int p = 0; p < 3; ++p) b[j][p] = *(const uint4*)(bp + j * GX_CHUNK + p * (32 * GX_LS));
+        float x[16] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], r2[0], r2[1], r2[2], r2[3], r3[0], r3[1], r3[2], r3[3]};
+        float hl[16];
+        unsigned P[3][8];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < JW; ++j)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) b[j][p] = *(const uint4*)(bp + (j0 + j) * GX_CHUNK + p * (32 * GX_LS) + 16 * s);
-#define GX_MFMA(PA_, PB_)                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < JW; ++j)                                                                             \
-        acc[j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, b[j][PB_]),                        \
-                                                              __builtin_bit_cast(gb_bf16x8, ap[s][PA_]), acc[j0 + j], 0, 0, 0)
-                GX_MFMA(2, 0);
-                GX_MFMA(1, 1);
-                GX_MFMA(0, 2);
-                GX_MFMA(1, 0);
-                GX_MFMA(0, 1);
-                GX_MFMA(0, 0);
-#undef GX_MFMA
+        for (int m = 0; m < NM; ++m) {
+            const int s = m / (6 * TN), prod = (m % (6 * TN)) / TN, j = m % TN;        // the TN accumulator chains alternate
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, b[j][PB[s][prod]]),
+                                                             __builtin_bit_cast(gb_bf16x8, cur[s][PA[s][prod]]), acc[j], 0, 0, 0);
+            if (s == 0 && (prod == 2 || prod >= 4)) {          // this chain's last use of a first-step plane: refill it for the second
+                const int p = prod == 2 ? 2 : prod == 4 ? 1 : 0;
+                b[j][p] = *(const uint4*)(bp + j * GX_CHUNK + p * (32 * GX_LS) + 16);
             }
+#pragma unroll
+            for (int k = m * NOPS / NM; k < (m + 1) * NOPS / NM; ++k) {
+                const int lvl = k < 8 ? 0 : k < 24 ? 1 : k < 40 ? 2 : k < 48 ? 3 : k < 64 ? 4 : k < 80 ? 5 : 6;
+                if (lvl == 0) P[0][k] = gx_cvt_pk(x[2 * k], x[2 * k + 1]);
+                else if (lvl == 3) P[1][k - 40] = gx_cvt_pk(x[2 * (k - 40)], x[2 * (k - 40) + 1]);
+                else if (lvl == 6) P[2][k - 80] = gx_cvt_pk(x[2 * (k - 80)], x[2 * (k - 80) + 1]);
+                else if (lvl == 1 || lvl == 4) {
+                    const int e = k - (lvl == 1 ? 8 : 48);
+                    const unsigned pk = P[lvl == 1 ? 0 : 1][e >> 1];
+                    hl[e] = __uint_as_float((e & 1) ? (pk & 0xffff0000u) : (pk << 16));
+                } else {
+                    const int e = k - (lvl == 2 ? 24 : 64);
+                    x[e] = gx_sub(x[e], hl[e]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) nxt[s][p] = make_uint4(P[p][4 * s], P[p][4 * s + 1], P[p][4 * s + 2], P[p][4 * s + 3]);
+    };
+    // everything but the newest WAITN requests has landed (the queue retires in order): W of tile t and the A floats of tile t + 1
+    auto landed = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
+        if constexpr (WAITN == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+        static_assert(WAITN == 6 || WAITN == 8, "wait count");
     };
 
-    // Requests run ahead of the MFMAs: W by LDS-DMA STAGES - 1 k-tiles ahead (ring of STAGES slots), the lane's A floats two tiles
-    // ahead (two register sets).  Iteration t: wait until at most WAITN requests are in flight (= tile t has landed: the queue retires
-    // in order), split its A floats, ONE barrier (tile t's W pieces of all four waves are visible; every wave is done with tile
-    // t - 1, whose ring slot and register set the next requests reuse), issue the next requests (W first), 12 TN MFMAs.  Tile
-    // indices are clamped, not branched on: past the end the last tile is requested again into a slot nobody reads, and the final
-    // wait keeps the request registers alive until those loads have landed.
+    // Requests run two k-tiles ahead of their use: W by LDS-DMA into a ring of three slots, the lane's A floats into three register
+    // sets.  Iteration t: wait until at most WAITN requests are in flight (= W of tile t and the floats of tile t + 1 have landed),
+    // ONE barrier (tile t's W pieces of all four waves are visible; every wave is done with tile t - 1, whose ring slot the next DMA
+    // reuses), request W of tile t + 2 and the floats of tile t + 3, then the MFMAs of tile t with the splitting of tile t + 1 in
+    // their shadow.  Tile indices are clamped, not branched on: past the end the last tile is requested (and split) again, into a
+    // slot / planes nobody reads; the final wait keeps the request registers alive until those loads have landed.
+    // Period of the rotation: 3 register sets x 2 plane buffers = 6 tiles per trip of the loop.
     if (t_begin < t_end) {
         int wslot = 0, cslot = 0;
-        auto next = [&](int sl) { return sl + 1 == STAGES ? 0 : sl + 1; };
+        auto next = [&](int sl) { return sl + 1 == 3 ? 0 : sl + 1; };
         request_w(t_begin, wslot); wslot = next(wslot);
-        request_a(rawA0, rawA1, rawA2, rawA3);
-        if (STAGES == 3) { request_w(min(t_begin + 1, t_last), wslot); wslot = next(wslot); }
-        request_a(rawB0, rawB1, rawB2, rawB3);
-        for (int t = t_begin; t < t_end; t += 2) {
-            split(rawA0, rawA1, rawA2, rawA3);
-            __syncthreads();
-            request_w(min(t + STAGES - 1, t_last), wslot); wslot = next(wslot);
-            request_a(rawA0, rawA1, rawA2, rawA3);
-            compute(cslot); cslot = next(cslot);
-            if (t + 1 < t_end) {
-                split(rawB0, rawB1, rawB2, rawB3);
-                __syncthreads();
-                request_w(min(t + STAGES, t_last), wslot); wslot = next(wslot);
-                request_a(rawB0, rawB1, rawB2, rawB3);
-                compute(cslot); cslot = next(cslot);
-            }
+        request_a(rA0, rA1, rA2, rA3);
+        request_a(rB0, rB1, rB2, rB3);
+        request_w(min(t_begin + 1, t_last), wslot); wslot = next(wslot);
+        request_a(rC0, rC1, rC2, rC3);
+        // the first tile's floats are split before the loop: nothing to hide them behind
+        if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(10)" : "+v"(rA0), "+v"(rA1), "+v"(rA2), "+v"(rA3) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" : "+v"(rA0), "+v"(rA1), "+v"(rA2), "+v"(rA3) : : "memory");
+        gx_split8(rA0, rA1, ap0[0]);
+        gx_split8(rA2, rA3, ap0[1]);
+#define GX_STEP(I_, CUR_, NXT_, C0_, C1_, C2_, C3_, Q0_, Q1_, Q2_, Q3_)                                                          \
+        if (t + I_ < t_end) {                                                                                                  \
+            landed(C0_, C1_, C2_, C3_);                                                                                        \
+            __syncthreads();                                                                                                   \
+            request_w(min(t + I_ + 2, t_last), wslot); wslot = next(wslot);                                                    \
+            request_a(Q0_, Q1_, Q2_, Q3_);                                                                                     \
+            tile(cslot, CUR_, NXT_, C0_, C1_, C2_, C3_); cslot = next(cslot);                                                  \
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA0), "+v"(rawA1), "+v"(rawA2), "+v"(rawA3), "+v"(rawB0), "+v"(rawB1), "+v"(rawB2),
-                     "+v"(rawB3) : : "memory");
+        for (int t = t_begin; t < t_end; t += 6) {
+            GX_STEP(0, ap0, ap1, rB0, rB1, rB2, rB3, rA0, rA1, rA2, rA3)
+            GX_STEP(1, ap1, ap0, rC0, rC1, rC2, rC3, rB0, rB1, rB2, rB3)
+            GX_STEP(2, ap0, ap1, rA0, rA1, rA2, rA3, rC0, rC1, rC2, rC3)
+            GX_STEP(3, ap1, ap0, rB0, rB1, rB2, rB3, rA0, rA1, rA2, rA3)
+            GX_STEP(4, ap0, ap1, rC0, rC1, rC2, rC3, rB0, rB1, rB2, rB3)
+            GX_STEP(5, ap1, ap0, rA0, rA1, rA2, rA3, rC0, rC1, rC2, rC3)
+        }
+#undef GX_STEP
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA0), "+v"(rA1), "+v"(rA2), "+v"(rA3), "+v"(rB0), "+v"(rB1), "+v"(rB2), "+v"(rB3), "+v"(rC0),
+                     "+v"(rC1), "+v"(rC2), "+v"(rC3) : : "memory");
     }
     __syncthreads();        // (no wave leaves -- and lets the workgroup's LDS be handed on -- while another wave's DMA may be in flight)
 

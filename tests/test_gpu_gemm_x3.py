@@ -30,9 +30,18 @@ class _fp32_mfma:
         self.ops.GEMM_X3 = self.prev
 
 
-def test_x3_is_the_default_contraction():
+@pytest.fixture(autouse=True)
+def _x3_for_every_width(monkeypatch):
+    """The host keeps 32-column layers on the fp32 MFMA kernel (faster there); this module exercises d3f_gemm_x3 at every width."""
     from d3feat_amd import ops
-    assert ops.GEMM_X3 and ops._x3_ok(64, 0) and ops._x3_ok(128, 64) and not ops._x3_ok(48, 0) and not ops._x3_ok(16, 48)
+    monkeypatch.setattr(ops, "_x3_ok", lambda C1, C2, N: ops.GEMM_X3 and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0))
+
+
+def test_x3_is_the_default_contraction(monkeypatch):
+    monkeypatch.undo()
+    from d3feat_amd import ops
+    assert ops.GEMM_X3 and ops._x3_ok(64, 0, 64) and ops._x3_ok(128, 64, 128) and not ops._x3_ok(48, 0, 64) and not ops._x3_ok(16, 48, 64)
+    assert not ops._x3_ok(64, 0, 32)        # 32-column layers: the fp32 MFMA kernel is the faster one
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 64), (333, 96, 32), (4100, 128, 100), (130, 2048, 36)])

@@ -7,6 +7,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ float sub1(float a, float b) {       // one v_sub_f32 the SLP vectoriser cannot pack into v_pk_add_f32
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -31,8 +36,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
                 for (int g = m * NVG / NM; g < (m + 1) * NVG / NM; ++g) {
                     const int i = g & 7;
                     const unsigned p = cvt_pk(x[i], y[i]);
-                    x[i] -= __uint_as_float(p << 16);
-                    y[i] -= __uint_as_float(p & 0xffff0000u);
+                    x[i] = sub1(x[i], __uint_as_float(p << 16));
+                    y[i] = sub1(y[i], __uint_as_float(p & 0xffff0000u));
                 }
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 5 * (NVG / NM), 0);
@@ -87,8 +92,9 @@ int main() {
         run<24, 16, 0>("24 MFMA", blocks, out);
         run<24, 24, 1>("120 VALU", blocks, out);
         run<24, 24, 2>("24 MFMA then 120 VALU (program order)", blocks, out);
-        run<24, 24, 3>("24 MFMA interleaved with 120 VALU (1 : 5)", blocks, out);
-        run<24, 48, 3>("24 MFMA interleaved with 240 VALU (1 : 10)", blocks, out);
+        run<24, 24, 3>("24 MFMA interleaved with 120 VALU (1 : 5), scalar subs", blocks, out);
+        run<24, 16, 3>("24 MFMA interleaved with 80 VALU (3 : 10), scalar subs", blocks, out);
+        run<24, 48, 3>("24 MFMA interleaved with 240 VALU (1 : 10), scalar subs", blocks, out);
     }
     return 0;
 }
