@@ -42,6 +42,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2516.6  # v_mfma_f32_32x32x16_bf16 dense peak (16 x the fp32 matrix rate; MI355X_MICROARCH.md: "~2.5 PF dense")
+# the operand-split contraction (csrc/gemm_x3.h) issues SIX bf16 products per fp32 product: the rate at which its instruction
+# stream could at best deliver fp32 products is a sixth of the bf16 peak -- 2.67 x the fp32 matrix pipe's
+X3_PRODUCTS = 6
+MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / X3_PRODUCTS
 PARITY_TOL = 1e-4          # BASELINE.json north_star: descriptors and scores within 1e-4 (absolute), indices bit-exact
 BF16_TOL = 2e-2            # documented tolerance of the bf16-contraction configuration vs the fp32 oracle (tests/test_gpu_bf16.py)
 
@@ -563,6 +568,12 @@ def main():
                        "points_per_cloud_pool": sorted(int(len(x)) for x in subs),
                        "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
                        "fragments_per_gpu": args.steps * frames, "parallelism": "fragment-dp%d" % world,
+                       "contraction": ("bf16 operands (configs[4])" if args.bf16 else
+                                       "f32 in / f32 out; unary + unfused KPConv contractions wider than 32 columns by EXACT operand "
+                                       "splitting (each f32 operand = 3 bf16 planes, 6 exact bf16 products per f32 product, f32 accumulate "
+                                       "on v_mfma_f32_32x32x16_bf16: csrc/gemm_x3.h; error vs float64 below the f32 MFMA kernel's, "
+                                       "tests/test_gpu_gemm_x3.py), the rest on v_mfma_f32_32x32x2_f32" if __import__("d3feat_amd.ops").ops.GEMM_X3
+                                       else "f32 on v_mfma_f32_32x32x2_f32 (D3F_GEMM_X3=0)"),
                        "rccl": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
                        "final_gather": {"ranks": len(gathered_rows), "to": "rank %d" % dst if dst is not None else "every rank",
                                         "received_on_rank0": received,
@@ -633,9 +644,15 @@ def marginal_costs(args, cfg, W, limits, engine, run, shard, device, nsteps, flo
             e = {"ablated_ms_per_fragment": round(ms, 4), "ms_per_fragment": round(d, 4)}
             if d > 0:
                 tf = flops[fam] / (d * 1e-3) / 1e12
-                e.update(alg_flops_per_fragment=int(flops[fam]), tflops=round(tf, 2), peak=MFMA_F32_PEAK_TF,
-                         frac=round(tf / MFMA_F32_PEAK_TF, 4),
-                         bound="mfma" if fam == "gemm" else "mfma (contraction) + valu (aggregation), both 157.3 TF/s pipes")
+                from d3feat_amd import ops as _ops
+                x3 = fam == "gemm" and _ops.GEMM_X3
+                pk = MFMA_X3_PEAK_TF if x3 else MFMA_F32_PEAK_TF
+                e.update(alg_flops_per_fragment=int(flops[fam]), tflops=round(tf, 2), peak=round(pk, 1), frac=round(tf / pk, 4),
+                         bound=("mfma (six bf16 products per fp32 product: dense bf16 peak / 6; the 32-column layers run on the fp32 "
+                                "pipe)" if x3 else "mfma") if fam == "gemm"
+                         else "mfma (contraction) + valu (aggregation), both 157.3 TF/s pipes")
+                if x3:
+                    e["over_fp32_mfma_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
             out[fam] = e
             del eng
     finally:
@@ -659,7 +676,7 @@ def install_ablation(families):
             return getattr(lib, name)
     skip = set()
     for f in families:
-        skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32", "d3f_gemm_f32t"},
+        skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32", "d3f_gemm_f32t", "d3f_gemm_x3"},
                  "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused"},
                  "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_aggregate"},
                  "kpconv32": {"d3f_kpconv_fused32"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
@@ -693,8 +710,10 @@ def classify_record(cfg, name, info):
             name, "kpconv_fused_kernel<Cin=%d>" % cin)
         nbytes = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], cin, cout)
         flops = sum(kpconv_flops(info["Nq"], info["K"], cin, cout))
-    elif name == "gemm_f32":
-        key = "gemm_dma_kernel"        # the contraction family: LDS-DMA tile kernel (+ split-K reduce kernel)
+    elif name in ("gemm_f32", "gemm_x3"):
+        # the contraction families (+ their split-K reduce kernel): operand-split form on the bf16 matrix cores (every layer wider
+        # than 32 columns), LDS-DMA fp32 MFMA tile kernel (the 32-column layers and whatever d3f_gemm_x3 cannot address)
+        key = "gemm_x3_kernel" if name == "gemm_x3" else "gemm_dma_kernel"
         nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
         flops = 2.0 * info["M"] * info["N"] * info["K"]
     elif name == "nb_search":  # SURVEY §8(d) bytes_alg = 12*(Nq+Ns) + 4*Nq*K_out
@@ -730,8 +749,13 @@ def accumulate_families(cfg, timed):
         f["launches"] += 1
         f["bytes"] += nbytes
         f["flops"] += flops
-        f["roof_ms"] += 1e3 * max(flops / (MFMA_F32_PEAK_TF * 1e12), nbytes / (HBM_PEAK_GBS * 1e9))
+        f["roof_ms"] += 1e3 * max(flops / (matrix_peak(key) * 1e12), nbytes / (HBM_PEAK_GBS * 1e9))
     return fam
+
+
+def matrix_peak(family):
+    """TFLOP/s of ALGORITHMIC (fp32) flops the family's matrix instructions could deliver at best."""
+    return MFMA_X3_PEAK_TF if family.startswith("gemm_x3") else MFMA_F32_PEAK_TF
 
 
 def select_dominant(fam):
@@ -766,8 +790,8 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
             per_step_agg[-1].append((info, ms))
         elif name in ("kpconv_fused_c1", "kpconv_fused32", "kpconv_fused"):
             per_step_agg[-1].append((dict(info, fused=True), ms))
-        elif name == "gemm_f32":
-            per_step_gemm[-1].append((info, ms))
+        elif name in ("gemm_f32", "gemm_x3"):
+            per_step_gemm[-1].append((dict(info, kernel="gemm_x3_kernel" if name == "gemm_x3" else "gemm_dma_kernel"), ms))
     fam = accumulate_families(cfg, timed)
 
     traffic, traffic_src, traffic_stale = load_traffic()
@@ -777,15 +801,23 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
         avg_ms = d["ms"] / d["launches"]
         # which roof binds the family: algorithmic flops against the fp32 matrix peak or algorithmic bytes against HBM,
         # whichever takes longer (the level-0 unary contractions move 10 flop per byte: HBM; the deep ones 100+: MFMA)
-        t_f, t_b = d["flops"] / (MFMA_F32_PEAK_TF * 1e12), d["bytes"] / (HBM_PEAK_GBS * 1e9)
+        peak_tf = matrix_peak(name)
+        t_f, t_b = d["flops"] / (peak_tf * 1e12), d["bytes"] / (HBM_PEAK_GBS * 1e9)
         tf_s = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
         gb_s = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
         if t_f >= t_b:
-            r = dict(kernel=name, bound="mfma", achieved=round(tf_s, 3), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                     frac=round(tf_s / MFMA_F32_PEAK_TF, 5), traffic=None)
+            r = dict(kernel=name, bound="mfma", achieved=round(tf_s, 3), peak=round(peak_tf, 1), unit="TFLOP/s",
+                     frac=round(tf_s / peak_tf, 5), traffic=None)
         else:
             r = dict(kernel=name, bound="hbm", achieved=round(gb_s, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(gb_s / HBM_PEAK_GBS, 5), traffic=None)
+        if name.startswith("gemm_x3"):
+            # algorithmic = fp32 products and sums (2 M N K); the kernel ISSUES six exact bf16 products per fp32 product
+            r["matrix_pipe"] = dict(instruction="v_mfma_f32_32x32x16_bf16", products_per_fp32_product=X3_PRODUCTS,
+                                    issued_tflops=round(X3_PRODUCTS * tf_s, 1), dense_peak=MFMA_BF16_PEAK_TF,
+                                    peak_is="dense bf16 MFMA peak / 6 = the fp32-product rate this instruction stream can reach at best",
+                                    fp32_mfma_peak=MFMA_F32_PEAK_TF, achieved_over_fp32_mfma_peak=round(tf_s / MFMA_F32_PEAK_TF, 4),
+                                    measured_limit="operand traffic L2 -> CU (~9 TB/s) and launch size: DESIGN.md section 5")
         r["alg_flops_per_launch"] = int(d["flops"] / d["launches"])
         r["alg_bytes_per_launch"] = int(d["bytes"] / d["launches"])
         r["tflops"], r["hbm_gbs"] = round(tf_s, 3), round(gb_s, 2)
@@ -801,7 +833,8 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
         # collected for different kernel sources than the ones running now.
         if traffic is not None:
             base = name.split("<")[0].split(" ")[0]
-            names = ("gemm_dma_kernel", "gemm_fast_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
+            names = ("gemm_x3_kernel",) if name.startswith("gemm_x3") else \
+                ("gemm_dma_kernel", "gemm_fast_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
             ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
                    and "traffic_bytes_per_launch" in v]
             m = re.match(r"kpconv_fused_kernel<Cin=(\d+)>", name)     # template argument = lanes per query = Cin / 4
@@ -850,10 +883,12 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
             ms_j = float(np.mean([st[j][1] for st in per_step_gemm if len(st) == len(per_step_gemm[-1])]))
             fl = 2.0 * g["M"] * g["N"] * g["K"]
             by = 4.0 * (g["M"] * g["K"] + g["K"] * g["N"] + g["M"] * g["N"])
-            roof_ms = 1e3 * max(fl / (MFMA_F32_PEAK_TF * 1e12), by / (HBM_PEAK_GBS * 1e9))
-            shapes.append(dict(M=int(g["M"]), N=int(g["N"]), K=int(g["K"]), us=round(ms_j * 1e3, 1),
+            pk = matrix_peak(g.get("kernel", "gemm_dma_kernel"))
+            roof_ms = 1e3 * max(fl / (pk * 1e12), by / (HBM_PEAK_GBS * 1e9))
+            shapes.append(dict(M=int(g["M"]), N=int(g["N"]), K=int(g["K"]), kernel=g.get("kernel", "gemm_dma_kernel"),
+                               us=round(ms_j * 1e3, 1),
                                tflops=round(fl / (ms_j * 1e-3) / 1e12, 1), gbs=round(by / (ms_j * 1e-3) / 1e9, 0),
-                               bound="mfma" if fl / (MFMA_F32_PEAK_TF * 1e12) > by / (HBM_PEAK_GBS * 1e9) else "hbm",
+                               bound="mfma" if fl / (pk * 1e12) > by / (HBM_PEAK_GBS * 1e9) else "hbm",
                                frac_of_roof=round(roof_ms / ms_j, 3)))
         roof["contraction_launches"] = shapes
     # algorithmic flops per fragment of the two matrix-pipe families, as launched (shapes of the instrumented pass)

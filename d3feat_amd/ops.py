@@ -502,7 +502,7 @@ def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, ro
     if _x3_ok(C1, C2, N):
         Wx = packed_x3_weights(W)
         ws = workspace(lib.d3f_gemm_x3_workspace_bytes(M, N, C1 + C2, hint), dev)
-        with _timed("gemm_f32", dict(M=M, N=N, K=C1 + C2), dev):
+        with _timed("gemm_x3", dict(M=M, N=N, K=C1 + C2), dev):
             rc = lib.d3f_gemm_x3(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
                                  skip.data_ptr() if skip is not None else None, lds, C2, Wx.data_ptr(), out.data_ptr(), ldc, M, N,
                                  row_scale.data_ptr() if row_scale is not None else None,

@@ -274,5 +274,10 @@ def test_bench_roofline_selection_never_picks_a_multi_launch_group():
     assert bench.select_dominant(fam)[1] == "weird (9 launches)"
     g = fam["gemm_dma_kernel"]
     assert g["launches"] == 52 and abs(g["flops"] - 52 * 2.0 * 235000 * 64 * 128) < 1
+    # the operand-split contraction is its own family, priced against a sixth of the dense bf16 matrix peak
+    fam2 = bench.accumulate_families(cfg, [("gemm_x3", dict(M=235000, N=64, K=128), 0.05)] * 3 + [("gemm_f32", dict(M=235000, N=32, K=64), 0.03)])
+    assert set(fam2) == {"gemm_x3_kernel", "gemm_dma_kernel"} and fam2["gemm_x3_kernel"]["launches"] == 3
+    assert abs(bench.matrix_peak("gemm_x3_kernel") - bench.MFMA_BF16_PEAK_TF / 6) < 1e-9 and bench.matrix_peak("gemm_dma_kernel") == 157.3
+    assert bench.matrix_peak("kpconv_fused32_kernel") == 157.3
     # a run made of groups only has no headline kernel rather than a wrong one
     assert bench.select_dominant({k: v for k, v in fam.items() if v["multi"]})[1] is None
