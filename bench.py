@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--cpu-fragments", type=int, default=5, help="fragments of the CPU / parity sample")
     ap.add_argument("--no-cpu-1thread", action="store_true", help="skip the 1-thread network row of the CPU baseline")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic fragments per rank (cycled)")
-    ap.add_argument("--slots", type=int, default=4, help="fragments in flight per GPU (HIP-graph slots on separate streams)")
+    ap.add_argument("--slots", type=int, default=0, help="replays in flight per GPU (HIP-graph slots on separate streams); 0 = 4, or "
+                                                         "3 for a job of fewer than 64 steps (one round of replays: r04 x9)")
     ap.add_argument("--batch", type=int, default=0,
                     help="fragments stacked into one graph replay (FragmentEngine(batch=F)); a step is still ONE fragment.  "
                          "0 = by job size: 12 from 384 fragments on (1591 / 1586 against 1558 / 1578 fragments/s at 8 and 1569 / 1570 at 16, "
@@ -264,6 +265,10 @@ def main():
         args.pool = max(args.pool if args.config4 else 2, 2)
         if args.demo:
             args.pool, args.cpu_fragments = 2, min(args.cpu_fragments, 2)
+    if args.slots <= 0:
+        # a job of one round of replays (the driver's 20 fragments): three replays of 7 beat four of 5 since the contractions moved
+        # to the operand-split form (1469 against 1437 fragments/s, three alternating pairs in one visit: r04_experiments.txt x9)
+        args.slots = 4 if (args.steps >= 64 or args.batch > 0) else 3
     if args.batch <= 0:
         args.batch = (12 if args.steps >= 384 else 8) if args.steps >= 64 else max(1, min(8, -(-args.steps // max(args.slots, 1))))
         if args.config4:
