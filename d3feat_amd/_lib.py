@@ -67,6 +67,7 @@ SIGNATURES = {
     "d3f_gemm_x3_packed_bytes": (_sz, [_i, _i]),
     "d3f_gemm_pack_x3": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "d3f_gemm_x3_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "d3f_gemm_x3_plan": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "d3f_gemm_x3": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,
                          _vp, _vp, _i, _vp]),
     "d3f_gemm_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz,

@@ -963,6 +963,16 @@ extern "C" int d3f_gemm_pack_x3(const float* B, int ldb, int K, int N, void* Wx,
     return D3F_OK;
 }
 
+// the plan d3f_gemm_x3 will use for a problem: rows / columns of its workgroups and the K slice count (diagnostics and tests)
+extern "C" int d3f_gemm_x3_plan(int M, int N, int K, int M_hint, int* rows, int* cols, int* slices) {
+    if (M <= 0 || N <= 0 || K < GX_BK || (K % GX_BK)) return D3F_ERR_ARG;
+    const GemmX3Plan p = gemm_x3_plan(M, N, K, M_hint);
+    if (rows) *rows = 32 * p.waves;
+    if (cols) *cols = 32 * p.tn;
+    if (slices) *slices = p.S;
+    return D3F_OK;
+}
+
 extern "C" size_t d3f_gemm_x3_workspace_bytes(int M, int N, int K, int M_hint) {
     if (M <= 0 || N <= 0 || K < GX_BK) return 256;
     const GemmX3Plan p = gemm_x3_plan(M, N, K, M_hint);

@@ -327,6 +327,9 @@ int d3f_gemm_f32t(const float* A, int N1, int lda, int C1, const int* idx, int l
 size_t d3f_gemm_x3_packed_bytes(int K, int N);
 int d3f_gemm_pack_x3(const float* W, int ldb, int K, int N, void* Wx, void* stream);
 size_t d3f_gemm_x3_workspace_bytes(int M, int N, int K, int M_hint);
+/* the workgroup shape (rows x cols: 128 x 32, 128 x 64 or 256 x 128) and K slice count d3f_gemm_x3 uses for a problem; D3F_ERR_ARG
+ * for a K it does not take.  Diagnostics / tests only: the launcher decides by itself. */
+int d3f_gemm_x3_plan(int M, int N, int K, int M_hint, int* rows, int* cols, int* slices);
 int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* idx, int ld_idx, const float* skip, int lds, int C2,
                 const void* Wx, float* C, int ldc, int M, int N, const float* row_scale, const float* col_scale,
                 const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* workspace,

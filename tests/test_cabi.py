@@ -115,3 +115,23 @@ def test_cpu_tensors_are_rejected():
     from d3feat_amd import _lib, ops
     with pytest.raises(_lib.D3FeatLibraryError):
         ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def _plan(M, N, K, hint=0):
+    from d3feat_amd import _lib
+    r, c, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert _lib.load().d3f_gemm_x3_plan(M, N, K, hint, ctypes.byref(r), ctypes.byref(c), ctypes.byref(s)) == 0
+    return r.value, c.value, s.value
+
+
+def test_gemm_x3_plans():
+    """The cost model of the launcher (rounds of resident workgroups x k-tiles per slice): which of tests/test_gpu_gemm_x3.py's problems run as
+    128 x 32, 128 x 64 and 256 x 128 workgroups, split in K or not -- so that every kernel instantiation is exercised there.  Host code only: no GPU."""
+    assert _plan(20000, 32, 64) == (128, 32, 1) and _plan(20000, 64, 128) == (128, 64, 1)
+    assert _plan(20001, 256, 1024)[:2] == (256, 128) and _plan(20001, 200, 1024)[:2] == (256, 128) and _plan(30000, 256, 256)[:2] == (256, 128)
+    assert _plan(4525, 512, 3072) == (256, 128, 3)                        # the network's level-3 decoder contraction at F = 5
+    rows, cols, s = _plan(900, 256, 3840)
+    assert (rows, cols) == (128, 64) and s > 1                            # skinny deep layer: split in K
+    assert _plan(300000, 64, 256, 171000)[:2] == (128, 64)
+    from d3feat_amd import _lib
+    assert _lib.load().d3f_gemm_x3_plan(100, 64, 48, 0, None, None, None) == -3

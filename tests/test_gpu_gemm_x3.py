@@ -3,6 +3,7 @@ bf16 products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Cl
   * the split is EXACT: products that fp32 can hold exactly come out exactly (all three planes of either operand are exercised);
   * against float64 its error is of the size of the fp32 MFMA kernel's (d3f_gemm_f32t), measured side by side on the same operands;
   * it is the same operator: epilogue, gathered / concatenated operands, ragged M / N, K split, device-resident row counts.
+Which problems run as 128 x 32, 128 x 64 and 256 x 128 workgroups is a host decision: tests/test_cabi.py::test_gemm_x3_plans (CPU).
 The network-level statement (same descriptors as the reference's Python at a few 1e-6) is tests/test_gpu_golden_network.py, which
 runs on this kernel since it is the default."""
 import ctypes as C
@@ -84,7 +85,7 @@ def test_integer_products_are_exact(device):
 
 
 @pytest.mark.parametrize("M,K,N", [(20000, 64, 32), (20000, 128, 64), (9000, 256, 128), (3000, 1024, 256), (900, 3840, 256),
-                                   (200, 7680, 512)])
+                                   (200, 7680, 512), (20001, 1024, 256), (40000, 512, 512)])
 def test_error_against_float64_beside_the_fp32_mfma_kernel(device, M, K, N):
     """max |C - C64| / max |C64| of both kernels on the same operands: the split form may not be worse than twice the fp32 MFMA
     kernel's error + 2^-23 (its dropped terms), and both stay below 4e-6."""
@@ -104,7 +105,8 @@ def test_error_against_float64_beside_the_fp32_mfma_kernel(device, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N,real", [(777, 64, 36, 0), (4097, 128, 100, 0), (260, 4096, 128, 0), (70001, 96, 128, 0),
-                                        (9000, 512, 128, 6100), (1580, 7680, 512, 1200), (5, 32, 4, 0)])
+                                        (9000, 512, 128, 6100), (1580, 7680, 512, 1200), (5, 32, 4, 0), (20001, 1024, 200, 0),
+                                        (33000, 512, 256, 24000)])
 def test_same_operator_every_epilogue_ragged_shapes_row_counts(device, M, K, N, real):
     from d3feat_amd import ops
     rng = np.random.default_rng(M + K + N)
@@ -138,12 +140,14 @@ def test_same_operator_every_epilogue_ragged_shapes_row_counts(device, M, K, N, 
         assert np.abs(got - f32).max() <= 4e-6 * max(1.0, np.abs(want).max())
 
 
-@pytest.mark.parametrize("C1,C2,N", [(128, 64, 64), (1024, 2048, 512), (64, 0, 32), (32, 32, 128)])
-def test_gathered_and_concatenated_operands(device, C1, C2, N):
-    """[ x'[idx[m, 0]] | skip[m] ] @ W: shadow / out-of-range indices read the zero row; the same bits as the materialised operand."""
+@pytest.mark.parametrize("C1,C2,N,m", [(128, 64, 64, 2500), (1024, 2048, 512, 2500), (64, 0, 32, 2500), (32, 32, 128, 2500),
+                                       (128, 128, 256, 30000)])
+def test_gathered_and_concatenated_operands(device, C1, C2, N, m):
+    """[ x'[idx[m, 0]] | skip[m] ] @ W: shadow / out-of-range indices read the zero row; the same bits as the materialised operand.
+    (The last case runs as 256 x 128 workgroups.)"""
     from d3feat_amd import ops
     rng = np.random.default_rng(C1 + C2 + N)
-    n1, m = 700, 2500
+    n1 = 700
     x = rng.standard_normal((n1, C1)).astype(np.float32)
     skip = rng.standard_normal((m, C2)).astype(np.float32) if C2 else None
     idx = rng.integers(0, n1 + 1, (m, 3)).astype(np.int32)
