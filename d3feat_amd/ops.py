@@ -482,6 +482,9 @@ def _x3_ok(C1, C2, N):
     return GEMM_X3 and N > 32 and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0)
 
 
+X3_MAX_ROWS = 65535 * 128      # d3f_gemm_x3's grid holds 65535 row tiles of (at least) 128 rows; beyond: the fp32 kernel
+
+
 def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):
     """Can d3f_gemm_f32t address this call?  (every shape of the network can)"""
     if not GEMM_DMA or N % 4 or ldc % 4 or out.data_ptr() % 16:
@@ -499,7 +502,7 @@ def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):
 def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky,
                alpha, m_dev, n1_dev, hint, dev):
     lib = _lib.load()
-    if _x3_ok(C1, C2, N):
+    if _x3_ok(C1, C2, N) and M <= X3_MAX_ROWS:
         Wx = packed_x3_weights(W)
         ws = workspace(lib.d3f_gemm_x3_workspace_bytes(M, N, C1 + C2, hint), dev)
         with _timed("gemm_x3", dict(M=M, N=N, K=C1 + C2), dev):
