@@ -913,10 +913,12 @@ extern "C" int d3f_gemm_bf16(const void* A_, int N1, int lda, int C1, const int*
 // Tile and K split.  Three workgroup shapes: 128 rows x 32 / 64 columns (4 wavefronts, 2 resident per CU) and 256 x 128 (8
 // wavefronts, 1 per CU: a quarter of the operand traffic per product -- both forms are bound by what the CUs can pull out of L2,
 // ~9 TB/s -- but a quarter of the workgroups).  For each candidate the K slice count that minimises
-//   rounds(workgroups / resident slots) x (k-tiles per slice + a workgroup's fixed cost) x its time per k-tile  +  the slab pass,
+//   rounds(workgroups / resident slots) x (k-tiles per slice + 12: a workgroup's fixed cost) x its time per k-tile  +  2 per slab,
 // in units of one k-tile of the 128 x 64 form (the 256 x 128 form's k-tile costs 1.63 of them: 3.1 against 1.9 us at M = 65536,
 // K = 3072, N = 256); the cheaper candidate wins.  E.g. 288 workgroups x 96 k-tiles (M = 4525, K = 3072, N = 512) are ONE round
-// of 96 unsplit, two rounds of 48 halved (576 > 512 slots), 2 x 36 in thirds -- and one round of 36 x 1.63 as 72 x 3 big ones.
+// of 96 unsplit, two rounds of 48 halved (576 > 512 slots), 2 x 32 in thirds -- and one round of 32 x 1.63 as 72 x 3 big ones.
+// (The constants are end-to-end fits, profiles/r04_experiments.txt x10: fixed cost 4 .. 16 k-tiles, 256 x 128 factor 1.0 .. 1.63 and
+// 2 .. 4 per slab are one plateau; 2.0 for the factor or 1 per slab lose 1-3 %.)
 struct GemmX3Plan { int tn, waves, S, tps; };
 static long long gemm_x3_cost(long long blocks, long long slots, int nt, int per_tile_x100, int& S) {
     long long best = -1;
@@ -925,10 +927,10 @@ static long long gemm_x3_cost(long long blocks, long long slots, int nt, int per
         const int t = d3f_cdiv(nt, s);
         if (d3f_cdiv(nt, t) != s) continue;
         const long long rounds = (blocks * s + slots - 1) / slots;
-        const long long cost = rounds * (t + 4) * per_tile_x100 + (s > 1 ? 200ll * s : 0);
+        const long long cost = rounds * (t + 12) * per_tile_x100 + (s > 1 ? 200ll * s : 0);
         if (best < 0 || cost < best) { best = cost; S = s; }
     }
-    if (best < 0) best = ((blocks + slots - 1) / slots) * (nt + 4) * per_tile_x100;      // fewer than 4 k-tiles: never split
+    if (best < 0) best = ((blocks + slots - 1) / slots) * (nt + 12) * per_tile_x100;     // fewer than 4 k-tiles: never split
     return best;
 }
 static GemmX3Plan gemm_x3_plan(int M, int N, int K, int M_hint) {
