@@ -817,6 +817,10 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
             r = dict(kernel=name, bound="hbm", achieved=round(gb_s, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(gb_s / HBM_PEAK_GBS, 5), traffic=None)
         if name.startswith("gemm_x3"):
+            r["note"] = ("frac = achieved / peak with peak = the roof of the instruction stream this kernel issues (dense bf16 MFMA peak / 6 "
+                         "products per fp32 product = %.1f TFLOP/s of fp32 products); against the fp32 MFMA peak of %.1f TFLOP/s -- the "
+                         "roof the contraction family was priced against in rounds 1-3 (0.43, 0.50) -- the same achieved figure is %.3f"
+                         % (peak_tf, MFMA_F32_PEAK_TF, tf_s / MFMA_F32_PEAK_TF))
             # algorithmic = fp32 products and sums (2 M N K); the kernel ISSUES six exact bf16 products per fp32 product
             r["matrix_pipe"] = dict(instruction="v_mfma_f32_32x32x16_bf16", products_per_fp32_product=X3_PRODUCTS,
                                     issued_tflops=round(X3_PRODUCTS * tf_s, 1), dense_peak=MFMA_BF16_PEAK_TF,
