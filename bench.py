@@ -39,6 +39,9 @@ if ROOT not in sys.path:
 # The engine keeps several fragments in flight on separate HIP streams; by default the ROCm runtime multiplexes all
 # streams of a process onto 4 hardware queues.  Must be set before the HIP runtime initialises (i.e. before torch).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this driver needs dmabuf IPC (RCCL / shared device tensors fail with `hipIpcGetMemHandle: invalid
+# argument` otherwise): set here too, not only in launch.relaunch, so a user's own `torchrun bench.py` gets the same environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
@@ -115,6 +118,14 @@ def parse():
     ap.add_argument("--gather-chunk", type=int, default=8,
                     help="N > 1: fragments per asynchronous shard-exchange chunk (parallel.ShardCollector overlapped mode: the "
                          "shards cross xGMI while the next fragments are computed); 0 = one all_gather of the whole shard at the end")
+    ap.add_argument("--seed-rank", type=int, default=-1, help="generate the synthetic pool of THIS rank of a larger job (default: the "
+                    "process's own rank): a single process reproduces what rank r of an N-rank run computed (tests/test_gpu_multi.py)")
+    ap.add_argument("--limits", default="", help="comma list: neighbourhood limits to use instead of calibrating (to repeat a multi-rank "
+                    "run's limits, which are calibrated over all ranks' pools, in one process)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file that receives the FULL result object (every family's roofline, per-launch tables, marginal costs, "
+                         "secondary measurements); stdout carries the compact line only")
+    ap.add_argument("--detail-stdout", action="store_true", help="also print the full object as an EARLIER stdout line")
     ap.add_argument("--raw-points", type=int, default=300000, help="raw points per synthetic fragment (config #2: 300k)")
     ap.add_argument("--kitti-points", type=int, default=120000, help="raw points per synthetic LiDAR sweep (config #4: 120k)")
     ap.add_argument("--edge", type=float, default=1.68, help="room edge in metres (config #2: 1.68 -> ~30k pts at 0.03 m)")
@@ -302,7 +313,7 @@ def main():
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if not do_cpu:
         args.cpu_fragments = 0
-    wl = Workload(args, rank)
+    wl = Workload(args, rank if args.seed_rank < 0 else args.seed_rank)
     cfg, W = wl.cfg, wl.W
     secondary_ok = wl.name in ("config2", "config3")           # mirror / PCIe / marginal-cost extras: headline workload only
     # this rank's synthetic items, resident in HBM before timing starts; the first `pool` are cycled through the timed region,
@@ -322,6 +333,9 @@ def main():
     hists = parallel.allreduce_histograms(hists, device)
     cumsum = np.cumsum(hists.T, axis=0)
     limits = np.sum(cumsum < (0.8 * cumsum[hist_n - 1, :]), axis=0).astype(np.int32)
+    if args.limits:
+        limits = np.array([int(x) for x in args.limits.split(",")], np.int32)
+        assert limits.shape == (cfg.num_layers,), "--limits wants %d numbers" % cfg.num_layers
 
     model = KernelPointFCNN(None, cfg, weights=W, device=device)
     step = Step(cfg, model, limits, device, bf16=args.bf16, bf16_features=args.bf16_features, two=wl.two, stage0=wl.stage0)
@@ -339,10 +353,17 @@ def main():
     # voxels per ITEM (both clouds of a two-frame stack together: the engine's capacities bound their sum)
     n0_items = [sum(len(x) for x in subs[i * per:(i + 1) * per]) for i in range(len(raws))]
     n0_max = max(n0_items)
+    raw_max = max(wl.raw_points(r) for r in raws_host)
+    if world > 1:
+        # the overlapped exchange addresses fragment k of EVERY rank at rows [k * frag_rows, ...): the stride (and with it the
+        # engine's capacities) must be one number on all ranks, not a function of a rank's own pool
+        agree = torch.tensor([n0_max, raw_max], dtype=torch.int64, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MAX)
+        n0_max, raw_max = int(agree[0].item()), int(agree[1].item())
 
     def make_engine(batch, slots, streams=None, mirror=False, bf16=args.bf16, bf16_features=args.bf16_features):
         from d3feat_amd.engine import FragmentEngine
-        raw_cap = int(max(wl.raw_points(r) for r in raws_host) * 1.05) + 1024
+        raw_cap = int(raw_max * 1.05) + 1024
         n0_cap = (int(n0_max * wl.cap_factor) + 1023) // 1024 * 1024
         return FragmentEngine(cfg, W, limits, raw_cap=raw_cap, n0_cap=n0_cap, level_ratio=wl.level_ratio, slots=slots, device=device,
                               n0_hint=int(np.mean(n0_items)), mirror_self_pair=mirror, batch=batch, bf16=bf16,
@@ -356,6 +377,9 @@ def main():
     dst = None if args.gather_to == "all" else int(args.gather_to)
     frag_rows = (int(n0_max * wl.cap_factor) + 1023) // 1024 * 1024
     if world > 1 and args.gather_chunk > 0:
+        strides = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(strides, torch.tensor([frag_rows], dtype=torch.int64, device=device))
+        assert all(int(x.item()) == frag_rows for x in strides), "fragment stride differs between ranks: %s" % [int(x.item()) for x in strides]
         shard = parallel.ShardCollector(rows_cap=(args.steps + args.gather_chunk) * frag_rows, width=36, device=device,
                                         chunk_frags=args.gather_chunk, frag_rows=frag_rows, dst=dst)
     else:
@@ -428,6 +452,16 @@ def main():
         gathered_rows = [int(sum(g[1])) for g in gathered]
         gathered_frags = [len(g[1]) for g in gathered]
         received = [g[0] is not None for g in gathered]
+        if w == R - 1:
+            # outside the clock: a float64 checksum of every received shard's VALID rows (rank 0's view of the job; a single process
+            # started with --seed-rank r --limits ... reproduces rank r's number: tests/test_gpu_multi.py)
+            checksums = []
+            for g in gathered:
+                if g[0] is None:
+                    checksums.append(None)
+                    continue
+                parts = g[0] if isinstance(g[0], (list, tuple)) else [g[0]]       # overlapped mode: one view per fragment
+                checksums.append(float(sum(float(p.double().sum().item()) for p in parts)))
         del gathered
         shard.reset()
     dt = float(np.median(windows))
@@ -584,6 +618,7 @@ def main():
                                         "received_on_rank0": received,
                                         "fragments_per_rank": gathered_frags,
                                         "rows_per_rank": gathered_rows, "bytes_per_rank": [r * 144 for r in gathered_rows],
+                                        "checksum_per_rank": checksums,
                                         "what": "every rank's whole shard of [xyz | desc | score] records (144 B/point, the first cloud "
                                                 "of every stacked self-pair: what utils/tester.py:208-229 keeps per fragment), inside "
                                                 "the timed region: " + ("asynchronous exchanges of %d-step chunks behind the compute"
@@ -608,7 +643,13 @@ def main():
         if args.ablate:
             res = {"INVALID": "ablation run (--ablate %s): op families skipped, outputs are garbage" % args.ablate,
                    "value": res["value"], "ms_per_step": res["ms_per_step"], "ablate": args.ablate}
-        print(json.dumps(res))
+        # the lab notebook (every family's roofline, per-launch tables, marginal costs, secondary measurements) goes to a FILE;
+        # the driver-facing stdout line is the compact object only (r04: a 20 KB line was cut by the driver's 8 KB tail and
+        # BENCH_r04.parsed came out null)
+        detail_path = write_detail(res, args.detail_out)
+        if args.detail_stdout:
+            print(json.dumps(res))
+        print(compact_line(res, detail_path))
         sys.stdout.flush()
     if dist.is_initialized():
         dist.barrier()
@@ -616,6 +657,116 @@ def main():
     if parity is not None and not parity["ok"]:
         print("PARITY FAILURE at the benchmarked configuration: %s" % json.dumps(parity), file=sys.stderr)
         sys.exit(3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+COMPACT_MAX_BYTES = 3072     # the driver keeps the last 8 KB of stdout; the line it must parse stays well inside
+
+
+def _pick(obj, keys):
+    return {k: obj[k] for k in keys if isinstance(obj, dict) and k in obj}
+
+
+def _short(v, n=200):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+
+def _finite(o):
+    """Strict JSON: NaN / Infinity (json.dumps would print them bare) become null."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def compact_line(res, detail_path=None):
+    """The ONE stdout line of a run: the contract's keys + parity / roofline / cpu_baseline / latency, every string bounded,
+    per-rank lists summarised, <= COMPACT_MAX_BYTES.  Everything else lives in the detail file."""
+    if "INVALID" in res:
+        return json.dumps(_finite(res), allow_nan=False)
+    out = _pick(res, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "data"])
+    out["metric"] = _short(out.get("metric"), 120)
+    dt = res.get("dtype") or ""
+    out["dtype"] = "f32" if dt == "f32" else ("bf16" if dt.startswith("bf16") else _short(dt, 40))
+    cfg = res.get("config") or {}
+    c = {"workload": _short(cfg.get("workload"), 240)}
+    c.update(_pick(cfg, ["points_per_cloud", "neighborhood_limits", "fragments_per_gpu", "parallelism", "fragments_per_replay",
+                         "engine_fallbacks", "engine_isolated_replays", "rccl"]))
+    c["contraction"] = _short(cfg.get("contraction"), 110)
+    c["execution"] = _short(cfg.get("execution"), 120)
+    fg = cfg.get("final_gather")
+    if fg and cfg.get("rccl"):
+        rec = fg.get("received_on_rank0") or []
+        fr, rows = fg.get("fragments_per_rank") or [], fg.get("rows_per_rank") or []
+        c["final_gather"] = {"ranks": fg.get("ranks"), "to": fg.get("to"), "received_on_rank0": rec,
+                             "fragments_per_rank": fr if len(fr) <= 16 else [min(fr), max(fr)],
+                             "rows_per_rank": rows if len(rows) <= 16 else [min(rows), max(rows)],
+                             "rows_total": int(sum(rows)), "bytes_total": int(sum(rows)) * 144}
+        if fg.get("checksum_per_rank") and len(rows) <= 16:
+            c["final_gather"]["checksum_per_rank"] = fg["checksum_per_rank"]
+    out["config"] = c
+    tm = res.get("timing") or {}
+    out["timing"] = _pick(tm, ["windows", "window_ms", "p10", "p90"])
+    if len(out["timing"].get("window_ms", [])) > 16:
+        out["timing"]["window_ms"] = out["timing"]["window_ms"][:16]
+    if res.get("parity") is not None:
+        out["parity"] = _pick(res["parity"], ["ok", "fragments", "points_equal", "idx_equal", "desc_max_abs", "score_max_abs", "tolerance",
+                                              "engine_fallbacks", "idx_rows_differing_only_inside_bit_equal_distance_ties"])
+    else:
+        out["parity"] = None
+    rf = res.get("roofline")
+    if rf:
+        r = _pick(rf, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_flops_per_launch", "alg_bytes_per_launch",
+                       "avg_launch_us", "launches_per_step", "fragments_per_launch", "traffic_source", "traffic_stale"])
+        mp = rf.get("matrix_pipe") or {}
+        if mp:
+            r["peak_is"] = "dense bf16 MFMA peak / 6 (six bf16 products per f32 product)"
+            r.update(_pick(mp, ["achieved_over_fp32_mfma_peak", "issued_tflops"]))
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    fams = res.get("rooflines")
+    if fams:   # one number per family: fraction of the roof that binds it (full objects: detail file)
+        out["roofline_frac_by_kernel"] = {_short(f.get("kernel"), 40): f.get("frac") for f in fams[:16]}
+    cb = res.get("cpu_baseline")
+    if cb:
+        b = _pick(cb, ["value", "unit", "cores", "host_cores", "kind", "geometry_kind", "value_1thread", "reference_python"])
+        b["sample"] = _short(cb.get("sample"), 180)
+        out["cpu_baseline"] = b
+    else:
+        out["cpu_baseline"] = None
+    lat = res.get("latency_ms")
+    out["latency_ms"] = _pick(lat, ["median", "p10", "p90", "n", "engine_fallbacks", "error"]) if lat else None
+    if "vs_cpu_baseline" in res:
+        out["vs_cpu_baseline"] = res["vs_cpu_baseline"]
+    if res.get("kpconv_layers_ms"):
+        out["ms_per_kpconv_layer"] = [round(l["total_ms_per_fragment"], 4) for l in res["kpconv_layers_ms"]
+                                      if l.get("total_ms_per_fragment") is not None][:16]
+    out["detail"] = detail_path
+    line = json.dumps(_finite(out), allow_nan=False, separators=(",", ":"))
+    for k in ("roofline_frac_by_kernel", "ms_per_kpconv_layer", "timing"):     # never reached by today's objects; a guard, not a plan
+        if len(line) <= COMPACT_MAX_BYTES:
+            break
+        out.pop(k, None)
+        line = json.dumps(_finite(out), allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def write_detail(res, path):
+    """The full object of the run as a file (tracked copies go to profiles/ by hand); returns the path relative to the repo, or
+    None when the directory is not writable -- a notebook must never cost the headline line."""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(_finite(res), f)
+            f.write("\n")
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
 
 
 # ---------------------------------------------------------------------------------------------------------------------

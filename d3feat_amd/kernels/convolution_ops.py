@@ -54,10 +54,11 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
         raise ValueError('KPConv: features have %d channels, K_values expects %d' % (features.shape[1], cin))
     # the fused forms address rows with one 24-bit multiply (csrc/common.h d3f_fits_u24: rows and leading dimensions < 2^24, rows x
     # leading dimension < 2^31) and return D3F_ERR_ARG beyond it; such stacks take aggregation + contraction, which has a general form
-    def _u24(rows, ld):
-        return rows < (1 << 24) and ld < (1 << 24) and rows * ld < (1 << 31)
+    # -- the same predicate as csrc/kpconv.hip kp_fits_u24: the feature matrix is also a buffer resource, rows x ld < 2^30
+    def _u24(rows, ld, lim=31):
+        return rows < (1 << 24) and ld < (1 << 24) and rows * ld < (1 << lim)
     fused_ok = _u24(int(query_points.shape[0]), int(neighbors_indices.stride(0))) and \
-        _u24(int(features.shape[0]), int(features.stride(0)))
+        _u24(int(features.shape[0]), int(features.stride(0)), 30)
     if cin == 1 and cout <= 256:
         # input layer: one fused kernel (gather + influences + 15-term contraction + epilogue)
         return ops.kpconv_fused_c1(query_points, support_points, neighbors_indices, features, K_points, K_values,

@@ -180,10 +180,10 @@ def test_engine_without_stage0_on_the_demo_pair(device, coracle):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("flag,frames", [("--config4", 2), ("--demo", 1)])
+@pytest.mark.parametrize("flag,frames", [("--config4", 2), ("--demo", 1), ("--bf16-features", 1)])
 def test_bench_lines_of_the_other_configurations(device, flag, frames):
-    """bench.py --config4 (KITTI-like stacks of two different sweeps, real trained weights) and --demo (the reference's demo
-    pair): a full line each -- parity object against the oracle from the timed execution, cpu_baseline, latency, no fallback."""
+    """bench.py --config4 (KITTI-like stacks of two different sweeps, real trained weights), --demo (the reference's demo
+    pair) and --bf16-features (configs[4]: batched fragments, bf16 features + bf16 contraction): a full line each -- parity object against the oracle from the timed execution, cpu_baseline, latency, no fallback."""
     import json
     import os
     import subprocess
@@ -193,7 +193,13 @@ def test_bench_lines_of_the_other_configurations(device, flag, frames):
                         "--no-cpu-1thread"], capture_output=True, text=True, cwd=ROOT, timeout=850,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert len(r.stdout.encode()) < 4096, len(r.stdout)           # stdout = ONE compact line (the driver keeps an 8 KB tail)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    if flag == "--bf16-features":       # configs[4]: bf16 features + bf16 contraction, documented tolerance (tests/test_gpu_bf16.py)
+        assert line["dtype"] == "bf16" and line["parity"]["tolerance"] == 2e-2
+        assert line["parity"]["desc_max_abs"] <= 1.5e-2 and line["parity"]["score_max_abs"] <= 2e-2, line["parity"]
+    else:
+        assert line["dtype"] == "f32" and line["parity"]["tolerance"] == 1e-4
     assert line["parity"]["ok"] and line["parity"]["points_equal"] and line["parity"]["idx_equal"], line["parity"]
     assert line["config"]["engine_fallbacks"] == 0 and line["parity"]["engine_fallbacks"] == 0
     assert line["cpu_baseline"]["value"] > 0 and line["latency_ms"]["median"] > 0 and line["latency_ms"]["engine_fallbacks"] == 0

@@ -15,14 +15,20 @@ tests-all)   # no -x: every failure of a visit in one go
   timeout ${TESTS_TIMEOUT:-600} python -m pytest tests -m gpu -q --durations=30 > $OUT/tests.log 2>&1; echo "pytest exit $?" >> $OUT/tests.log; tail -60 $OUT/tests.log;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log;;
+benchk20)   # the driver's command
+  timeout ${BENCH_TIMEOUT:-400} python bench.py --steps 20 --warmup 5 --detail-out $OUT/bench_k20.json > $OUT/bench_k20_line.json 2> $OUT/bench_k20.err; echo "bench exit $?" >> $OUT/bench_k20.err
+  wc -c $OUT/bench_k20_line.json; cut -c1-400 $OUT/bench_k20_line.json;;
 bench)
-  timeout ${BENCH_TIMEOUT:-400} python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
+  # stdout = the compact driver-facing line (bench_line.json); the full object goes to bench.json (as in earlier rounds)
+  timeout ${BENCH_TIMEOUT:-400} python bench.py ${BENCH_FLAGS:-} --detail-out $OUT/bench.json > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
   python - <<PY
 import json
 try:
-    r = json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
-    print({k: r[k] for k in ("value", "ms_per_step", "parity", "vs_cpu_baseline")})
-    print({k: r["roofline"][k] for k in ("kernel", "achieved", "frac")})
+    raw = open("$OUT/bench_line.json").read()
+    l = json.loads(raw.strip().splitlines()[-1])
+    print("stdout bytes", len(raw), {k: l[k] for k in ("value", "ms_per_step", "parity", "vs_cpu_baseline", "latency_ms")})
+    print(l["roofline"])
+    r = json.load(open("$OUT/bench.json"))
     print(r["roofline"]["timed_kernels_ms_per_step"])
     print(r["cpu_baseline"])
 except Exception as e:

@@ -21,6 +21,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 
 
 def main():
@@ -88,11 +89,13 @@ def main():
                              dst=None if a.gather_to == "all" else int(a.gather_to))
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if rank == 0:
+    dst_rank = 0 if a.gather_to == "all" else int(a.gather_to)
+    if rank == dst_rank:                 # the rank that holds the shards reports (--gather-to r: the others received None)
         print(json.dumps({"fragments": len(ids), "world": world, "seconds": round(dt, 3), "limits": [int(x) for x in res["limits"]],
                           "fragments_per_rank": [len(o) for o in res["order"]], "fallbacks": res["fallbacks"],
-                          "gathered_rows": [int(s[0].shape[0]) for s in res["shards"]] if res["shards"] else None,
-                          "gathered_checksum": [round(float(s[0].double().sum().item()), 3) for s in res["shards"]] if res["shards"] else None}))
+                          "gathered_rows": [int(s[0].shape[0]) for s in res["shards"] if s[0] is not None] if res["shards"] else None,
+                          "gathered_checksum": ([round(float(s[0].double().sum().item()), 3) for s in res["shards"] if s[0] is not None]
+                                                if res["shards"] else None)}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
