@@ -833,8 +833,8 @@ def install_ablation(families):
     skip = set()
     for f in families:
         skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32", "d3f_gemm_f32t", "d3f_gemm_x3"},
-                 "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused"},
-                 "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_aggregate"},
+                 "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused", "d3f_kpconv_fused_x3"},
+                 "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_fused_x3", "d3f_kpconv_aggregate"},
                  "kpconv32": {"d3f_kpconv_fused32"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
                  "rowpos": {"d3f_row_positive"}, "maxpool": {"d3f_ind_max_pool"}, "head": {"d3f_detect_head"},
                  "pack": {"d3f_pack_descriptors"},

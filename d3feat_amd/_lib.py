@@ -44,6 +44,10 @@ SIGNATURES = {
     "d3f_kpconv_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "d3f_kpconv_fused": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
                               _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "d3f_kpconv_packed_x3_bytes": (_sz, [_i, _i]),
+    "d3f_kpconv_pack_weights_x3": (_i, [_vp, _i, _i, _vp, _vp]),
+    "d3f_kpconv_fused_x3": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
+                                 _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "d3f_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_gemm_bf16_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _sz, _vp, _i, _vp]),

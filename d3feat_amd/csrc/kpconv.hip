@@ -804,6 +804,44 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 //     reaches memory.
 // VALU (aggregation) and matrix (contraction) phases of different workgroups on a CU overlap: the two pipes are separate.
 // ------------------------------------------------------------------------------------------------
+// ---- the contraction of the fused kernels by EXACT operand splitting (round 5; the scheme of gemm_x3.h) ------------------------
+// Levels 1 and 2 spend more matrix-pipe time in the 15*Cin-deep contraction than vector time in the aggregation (Cin = 64:
+// 240 v_mfma_f32_16x16x4_f32 of 32 cycles per wave and tile against ~5000 cycles of FMAs; Cin = 128: 480).  An fp32 value is three
+// bfloat16 planes exactly (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)), a product of two planes is exact in fp32, and
+// six of the nine plane products carry everything above 2^-23 of the product: 6 v_mfma_f32_16x16x32_bf16 (32 k, ~17 cycles each)
+// do the work of 8 v_mfma_f32_16x16x4_f32 (4 k, 32 cycles each): 2.5x less matrix-pipe time, fp32 in / fp32 out, error of the
+// order of the fp32 kernel's (tests/test_gpu_kpconv_x3.py).  The weighted features are split ONCE, when the accumulators are
+// written to the LDS tile (three planes [16][256 + 8] bf16, 528-byte rows: the 16 lanes of a fragment read hit 16 distinct 4-bank
+// groups); K_values is pre-split once per tensor in the B-fragment order (d3f_kpconv_pack_weights_x3): one coalesced 1 KB
+// load per wave, plane and 32-deep k-step.  Non-finite weighted features: Inf - Inf = NaN in the second plane -- non-finite in,
+// non-finite out, like the fp32 form (which yields +-Inf where this one yields NaN).
+typedef __bf16 kp_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned kx_cvt_pk(float lo, float hi) {     // two fp32 -> two bf16 (RNE), lo in bits 0..15
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// four consecutive-k floats -> the three operand planes (four bf16 = one uint2 each)
+__device__ __forceinline__ void kx_split4(float x0, float x1, float x2, float x3, uint2 (&pl)[3]) {
+    float v[4] = {x0, x1, x2, x3};
+    unsigned p[3][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float a = v[2 * i], b = v[2 * i + 1];
+        p[0][i] = kx_cvt_pk(a, b);
+        a -= __uint_as_float(p[0][i] << 16);
+        b -= __uint_as_float(p[0][i] & 0xffff0000u);
+        p[1][i] = kx_cvt_pk(a, b);
+        a -= __uint_as_float(p[1][i] << 16);
+        b -= __uint_as_float(p[1][i] & 0xffff0000u);
+        p[2][i] = kx_cvt_pk(a, b);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) pl[s] = make_uint2(p[s][0], p[s][1]);
+}
+#define KX_KT 256                       // k-values per contraction pass of the split form
+#define KX_TS (KX_KT + 8)               // bf16 per tile row (528 bytes)
+
 #define KG_TQ 16                        // queries per workgroup = rows of one 16x16x4 tile
 #define KG_KT 512                       // k-values per contraction pass
 #define KG_TS (KG_KT + 4)               // LDS row stride of the wf tile (floats): 16-byte aligned rows, TS/4 odd
@@ -811,8 +849,8 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 // Registers: 60 accumulators + the gather prefetch decide the occupancy.  512-thread workgroups (Cin = 128) are two waves
 // per SIMD each: at more than 128 registers only ONE workgroup fits a CU and its gather and matrix phases cannot overlap with
 // anybody's, so that variant prefetches four rows instead of eight and is held to 128 registers (two workgroups per CU).
-template <int LQ, int PF = (LQ >= 32 ? 4 : 8), class FT = float>   // lanes per query = Cin / 4 (16, 32 or 64); Cout == Cin; waves = LQ / 4 = Cout / 16
-__global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)
+template <int LQ, int PF = (LQ >= 32 ? 4 : 8), class FT = float, bool X3 = false>   // lanes per query = Cin / 4 (16, 32 or 64); Cout == Cin; waves = LQ / 4 = Cout / 16
+__global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)                      // X3: Wp = the pre-split planes (d3f_kpconv_pack_weights_x3)
 kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                     int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                     KpParams P, const float* __restrict__ Wp, KpEpi E, FT* __restrict__ out, int ldo,
@@ -892,7 +930,69 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     kp_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-    const int npass = (P.num_kp + HP - 1) / HP;
+    if constexpr (X3) {
+        // operand-split form: passes of 256 k-values (HP3 kernel points), the tile as three bf16 planes; products of one 32-deep
+        // step: (wf plane, W plane) = (2,0) (1,0) (0,0) (1,1) (0,1) (0,2) on three accumulator chains by magnitude class
+        constexpr int HP3 = KX_KT / CIN, NW = COUT / 16, PL3 = KG_TQ * KX_TS;
+        static_assert(HP3 >= 1 && 3 * PL3 * 2 <= KG_TQ * KG_TS * 4, "the plane tile must fit the region");
+        unsigned short* tile3 = (unsigned short*)region;                       // [3][16][KX_TS]
+        kp_f32x4 cS = {0.f, 0.f, 0.f, 0.f};
+        const int nsteps = P.num_kp * CIN / 32;                                // 32-deep steps over the whole k range (even)
+        const uint4* bw = (const uint4*)Wp + (size_t)wave * 64 + lane;         // + ((step * 3 + plane) * NW) * 64
+        uint4 b0[3], b1[3];
+#define KX_BLOAD(B_, SG_)                                                                                          \
+        do {                                                                                                       \
+            const int sg_ = min((SG_), nsteps - 1);                                                                \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) B_[pl] = bw[(size_t)((sg_ * 3 + pl) * NW) * 64];      \
+        } while (0)
+        KX_BLOAD(b0, 0);
+        KX_BLOAD(b1, 1);
+        const unsigned short* ap = tile3 + r16 * KX_TS + 8 * g;
+#define KX_STEP(B_, T_)                                                                                                        \
+        do {                                                                                                                   \
+            uint4 a_[3];                                                                                                       \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) a_[pl] = *(const uint4*)(ap + pl * PL3 + 32 * (T_));              \
+            cS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kp_bf16x8, a_[2]), __builtin_bit_cast(kp_bf16x8, B_[0]), cS, 0, 0, 0); \
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kp_bf16x8, a_[1]), __builtin_bit_cast(kp_bf16x8, B_[0]), c1, 0, 0, 0); \
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[0]), c0, 0, 0, 0); \
+            cS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kp_bf16x8, a_[1]), __builtin_bit_cast(kp_bf16x8, B_[1]), cS, 0, 0, 0); \
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[1]), c1, 0, 0, 0); \
+            cS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[2]), cS, 0, 0, 0); \
+        } while (0)
+        const int npass3 = (P.num_kp + HP3 - 1) / HP3;
+        int sg = 0;
+        for (int pass = 0; pass < npass3; ++pass) {
+            const int p0 = pass * HP3;
+            const int np = min(P.num_kp - p0, HP3);
+            if (pass) __syncthreads();                  // the previous pass's planes have been consumed
+#pragma unroll
+            for (int p = 0; p < KP_MAXP - 1; ++p) {
+                const int pp = p - p0;
+                if (pp >= 0 && pp < np) {               // (workgroup-uniform)
+                    uint2 pl[3];
+                    kx_split4(acc[p][0], acc[p][1], acc[p][2], acc[p][3], pl);
+                    unsigned short* d = tile3 + ql * KX_TS + pp * CIN + 4 * cl;
+                    *(uint2*)d = pl[0];
+                    *(uint2*)(d + PL3) = pl[1];
+                    *(uint2*)(d + 2 * PL3) = pl[2];
+                }
+            }
+            __syncthreads();
+            const int T = np * CIN / 32;                // (even: Cin is a multiple of 64)
+            for (int t = 0; t < T; t += 2) {
+                KX_STEP(b0, t);
+                KX_BLOAD(b0, sg + 2);
+                KX_STEP(b1, t + 1);
+                KX_BLOAD(b1, sg + 3);
+                sg += 2;
+            }
+        }
+#undef KX_STEP
+#undef KX_BLOAD
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c1[i] += cS[i];     // small terms first, then the leading products (c0) in the epilogue's sum
+    }
+    const int npass = X3 ? 0 : (P.num_kp + HP - 1) / HP;
     for (int pass = 0; pass < npass; ++pass) {
         const int p0 = pass * HP;
         const int np = min(P.num_kp - p0, HP);
@@ -987,6 +1087,35 @@ extern "C" int d3f_kpconv_pack_weights(const float* W, int K, int N, float* Wp, 
     return D3F_OK;
 }
 
+// Wx[((step * 3 + plane) * NW + w) * 64 + lane][j] = plane(W[32 step + 8 (lane >> 4) + j][16 w + (lane & 15)])   (K % 32 == 0,
+// N % 16 == 0): the B fragments of v_mfma_f32_16x16x32_bf16 for the wave that owns output columns 16 w .. 16 w + 15
+__global__ void __launch_bounds__(256) kp_pack_weights_x3_kernel(const float* __restrict__ W, int K, int N, unsigned short* __restrict__ Wx) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3ll * K * N) return;
+    const int j = (int)(t & 7);
+    long long u = t >> 3;
+    const int lane = (int)(u & 63); u >>= 6;
+    const int NW = N / 16;
+    const int w = (int)(u % NW); u /= NW;
+    const int pl = (int)(u % 3);
+    const int step = (int)(u / 3);
+    float x = W[(size_t)(32 * step + 8 * (lane >> 4) + j) * N + 16 * w + (lane & 15)];
+    unsigned h = d3f_bf16_rne(x);
+    if (pl > 0) { x -= __uint_as_float(h << 16); h = d3f_bf16_rne(x); }
+    if (pl > 1) { x -= __uint_as_float(h << 16); h = d3f_bf16_rne(x); }
+    Wx[t] = (unsigned short)h;
+}
+
+extern "C" size_t d3f_kpconv_packed_x3_bytes(int K, int N) { return (K > 0 && N > 0) ? (size_t)K * (size_t)N * 6u : 0; }
+
+extern "C" int d3f_kpconv_pack_weights_x3(const float* W, int K, int N, void* Wx, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 32 || (K % 32) || N < 16 || (N % 16) || !W || !Wx) return D3F_ERR_ARG;
+    kp_pack_weights_x3_kernel<<<d3f_cdiv(3ll * K * N, 256), 256, 0, stream>>>(W, K, N, (unsigned short*)Wx);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
 // the fused kernel exists for the configuration of the shipped models only (kp_influences_t<true>); anything else takes the
 // two-kernel form (d3f_kpconv_aggregate + d3f_gemm_f32)
 // 1: the one-kernel form exists AND is the faster choice; 2: it exists (d3f_kpconv_fused accepts the shape) but the two-kernel
@@ -997,12 +1126,13 @@ extern "C" int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int inf
     return (Cin == 64 || Cin == 128) ? 1 : (Cin == 256 ? 2 : 0);
 }
 
-extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                                const void* f_, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
-                                float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,
-                                const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
-                                float alpha, void* out_, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
-                                int feat_bf16, void* stream_) {
+template <bool X3>
+static int kp_fused_launch(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                           const void* f_, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                           float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,
+                           const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
+                           float alpha, void* out_, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                           int feat_bf16, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const float* f = (const float*)f_;
     float* out = (float*)out_;
@@ -1020,19 +1150,19 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const int blocks = d3f_cdiv(Nq, KG_TQ);
 #define D3F_KG(LQ_, PF_)                                                                                                    \
-    kpconv_fused_kernel<LQ_, PF_><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, E, \
-                                                                      out, ldo, Nq_dev, Ns_dev, q_order)
+    kpconv_fused_kernel<LQ_, PF_, float, X3><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, \
+                                                                                 E, out, ldo, Nq_dev, Ns_dev, q_order)
     if (feat_bf16) {
         const unsigned short* fh = (const unsigned short*)f_;
         unsigned short* oh = (unsigned short*)out_;
         if (Cin == 64)
-            kpconv_fused_kernel<16, D3F_KP_PF_H, unsigned short><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+            kpconv_fused_kernel<16, D3F_KP_PF_H, unsigned short, X3><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
         else if (Cin == 256)
-            kpconv_fused_kernel<64, 4, unsigned short><<<blocks, KG_TQ * 64, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+            kpconv_fused_kernel<64, 4, unsigned short, X3><<<blocks, KG_TQ * 64, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
         else
-            kpconv_fused_kernel<32, 4, unsigned short><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+            kpconv_fused_kernel<32, 4, unsigned short, X3><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
                                                                                          W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
     } else if (Cin == 64) D3F_KG(16, D3F_KP_PF);
     else if (Cin == 256) D3F_KG(64, 4);
@@ -1041,6 +1171,21 @@ extern "C" int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, 
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
+
+#define KP_FUSED_ARGS                                                                                                             \
+    const float *q, int Nq, const float *s, int Ns, const int *idx, int ld_idx, int K, const void *f_, int ldf, int Cin,          \
+        const unsigned char *rowpos, const float *kp_host, int num_kp, float KP_extent, int influence, int aggregation,           \
+        const float *W_packed, int Cout, const float *col_scale, const float *col_shift, const float *residual, int ldr,          \
+        int leaky, float alpha, void *out_, int ldo, const int *Nq_dev, const int *Ns_dev, const int *q_order, int feat_bf16,     \
+        void *stream_
+#define KP_FUSED_PASS                                                                                                             \
+    q, Nq, s, Ns, idx, ld_idx, K, f_, ldf, Cin, rowpos, kp_host, num_kp, KP_extent, influence, aggregation, W_packed, Cout,       \
+        col_scale, col_shift, residual, ldr, leaky, alpha, out_, ldo, Nq_dev, Ns_dev, q_order, feat_bf16, stream_
+extern "C" int d3f_kpconv_fused(KP_FUSED_ARGS) { return kp_fused_launch<false>(KP_FUSED_PASS); }
+// the same operator with the contraction in the operand-split form; W_packed = d3f_kpconv_pack_weights_x3's planes
+extern "C" int d3f_kpconv_fused_x3(KP_FUSED_ARGS) { return kp_fused_launch<true>(KP_FUSED_PASS); }
+#undef KP_FUSED_ARGS
+#undef KP_FUSED_PASS
 
 // ---- C ABI ---------------------------------------------------------------------------------------
 extern "C" int d3f_row_positive(const void* f_, int Ns, int ldf, int Cin, unsigned char* row_pos, const int* Ns_dev,

@@ -793,6 +793,27 @@ def packed_kpconv_weights(K_values):
     return Wp
 
 
+# The fused KPConv kernels of levels 1 and 2 contract their LDS tile in the operand-split form (csrc/kpconv.hip, round 5: three exact
+# bf16 planes per operand, six exact products per fp32 product, fp32 accumulate -- fp32 in, fp32 out); D3F_KP_X3=0 keeps the
+# v_mfma_f32_16x16x4_f32 form.
+KP_X3 = os.environ.get("D3F_KP_X3", "1") != "0"
+
+
+def packed_kpconv_weights_x3(K_values):
+    """K_values f32[num_kp, Cin, Cout] -> the pre-split bf16 planes d3f_kpconv_fused_x3 reads; made once per weight tensor and
+    version (rides on the tensor object like packed_kpconv_weights: never inside a captured graph)."""
+    cached = getattr(K_values, "_d3f_packed_x3", None)
+    if cached is not None and cached[0] == K_values._version:
+        return cached[1]
+    lib = _lib.load()
+    num_kp, cin, cout = K_values.shape
+    W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
+    Wx = torch.empty((int(lib.d3f_kpconv_packed_x3_bytes(num_kp * cin, cout)) // 2,), dtype=torch.int16, device=W.device)
+    _lib.check(lib.d3f_kpconv_pack_weights_x3(W.data_ptr(), num_kp * cin, cout, Wx.data_ptr(), _stream(W.device)), "kpconv_pack_weights_x3")
+    K_values._d3f_packed_x3 = (K_values._version, Wx)
+    return Wx
+
+
 def kpconv_fused(query_points, support_points, neighbors_indices, features, K_points, K_values, KP_extent,
                  KP_influence="linear", aggregation_mode="sum", col_scale=None, col_shift=None, residual=None,
                  leaky=False, alpha=0.2):
@@ -806,7 +827,8 @@ def kpconv_fused(query_points, support_points, neighbors_indices, features, K_po
     num_kp, cin, cout = K_values.shape
     if f.shape[1] != cin:
         raise ValueError("kpconv_fused: features have %d channels, K_values expects %d" % (f.shape[1], cin))
-    Wp = packed_kpconv_weights(K_values)
+    x3 = KP_X3 and (num_kp * cin) % 32 == 0 and cout % 16 == 0
+    Wp = packed_kpconv_weights_x3(K_values) if x3 else packed_kpconv_weights(K_values)
     Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
     dev = q.device
     out = torch.empty((Nq, cout), dtype=f.dtype, device=dev)
@@ -820,7 +842,8 @@ def kpconv_fused(query_points, support_points, neighbors_indices, features, K_po
         ns_dev = _nd(features)
     _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, cin, row_pos.data_ptr(), ns_dev, _h(f), st), "row_positive")
     with _timed("kpconv_fused", dict(Nq=Nq, Ns=Ns, K=K, Cin=cin, Cout=cout), dev):
-        rc = lib.d3f_kpconv_fused(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf, cin,
+        rc = (lib.d3f_kpconv_fused_x3 if x3 else lib.d3f_kpconv_fused)(
+                                  q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf, cin,
                                   row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
                                   _AGGREGATION[aggregation_mode], Wp.data_ptr(), cout,
                                   col_scale.data_ptr() if col_scale is not None else None,

@@ -217,6 +217,19 @@ int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int
  * such limit: beyond it they take their generic kernel). */
 int d3f_kpconv_fused_supported(int Cin, int Cout, int num_kp, int influence, int aggregation);
 int d3f_kpconv_pack_weights(const float* W, int K, int N, float* W_packed, void* stream);
+/* The same operator (kernels/convolution_ops.py:161-255 + epilogue) with its 15*Cin-deep contraction in the operand-split form of
+ * d3f_gemm_x3 (round 5): the weighted features are written to LDS as three exact bfloat16 planes, K_values is pre-split once per
+ * tensor by d3f_kpconv_pack_weights_x3 into d3f_kpconv_packed_x3_bytes(K, N) = 6 K N bytes (the B fragments of
+ * v_mfma_f32_16x16x32_bf16; K % 32 == 0, N % 16 == 0), six exact products per fp32 product, fp32 accumulation: fp32 in, fp32 out,
+ * 2.5 x less matrix-pipe time than v_mfma_f32_16x16x4_f32.  Arguments as d3f_kpconv_fused, W_packed = the planes. */
+size_t d3f_kpconv_packed_x3_bytes(int K, int N);
+int d3f_kpconv_pack_weights_x3(const float* W, int K, int N, void* W_planes, void* stream);
+int d3f_kpconv_fused_x3(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                        const void* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                        float KP_extent, int influence, int aggregation, const float* W_planes, int Cout,
+                        const float* col_scale, const float* col_shift, const float* residual, int ldr, int leaky,
+                        float alpha, void* out, int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order,
+                        int feat_bf16, void* stream);
 int d3f_kpconv_fused(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                      const void* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
                      float KP_extent, int influence, int aggregation, const float* W_packed, int Cout,

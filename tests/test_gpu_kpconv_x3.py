@@ -1,0 +1,103 @@
+"""The fused KPConv kernels' contraction in the operand-split form (csrc/kpconv.hip, round 5; the scheme of csrc/gemm_x3.h inside
+kpconv_fused_kernel): fp32 in, fp32 out -- measured against a float64 evaluation of kernels/convolution_ops.py:161-255 next to the
+v_mfma_f32_16x16x4_f32 form on the same operands, and through exactness cases (operands whose products and sums are exact in
+either form)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _kpconv64(pts, nb, f, kp, W, extent):
+    """float64 KPConv_ops (linear influence, sum aggregation) + neighbour-count division, on the device."""
+    n = pts.shape[0]
+    P = torch.cat([pts.double(), torch.full((1, 3), 1e6, dtype=torch.float64, device=pts.device)])
+    F = torch.cat([f.double(), torch.zeros((1, f.shape[1]), dtype=torch.float64, device=f.device)])
+    idx = nb.long()
+    rel = P[idx] - pts.double()[:, None, :]                                    # [n, K, 3]
+    d = (rel[:, :, None, :] - kp.double()[None, None]).pow(2).sum(-1).add(1e-10).sqrt()      # [n, K, 15]
+    w = (1.0 - d / extent).clamp(min=0.0)
+    wf = torch.einsum("nkp,nkc->npc", w, F[idx])                               # [n, 15, Cin]
+    out = torch.einsum("npc,pco->no", wf, W.double())
+    cnt = (F[idx].sum(-1) > 0).sum(-1).clamp(min=1).double()
+    return out / cnt[:, None]
+
+
+def _operands(cin, device, seed, n_raw=30000):
+    from d3feat_amd import ops
+    rng = np.random.default_rng(seed)
+    s0 = surface_cloud(seed, n_raw=n_raw)
+    pts = torch.from_numpy(s0).to(device)
+    lens = [len(s0)]
+    nb = ops.batch_radius_neighbors(pts, pts, lens, lens, 0.075, 42)[0]
+    f = torch.from_numpy(rng.standard_normal((len(s0), cin)).astype(np.float32)).to(device)
+    W = torch.from_numpy((rng.standard_normal((15, cin, cin)) * np.sqrt(2.0 / (15 * cin))).astype(np.float32)).to(device)
+    kp = (rng.standard_normal((15, 3)) * 0.025).astype(np.float32)
+    kp[0] = 0
+    return pts, nb, f, W, kp
+
+
+def _both(ops, *a, **k):
+    keep = ops.KP_X3
+    try:
+        ops.KP_X3 = True
+        x3 = ops.kpconv_fused(*a, **k)
+        ops.KP_X3 = False
+        f32 = ops.kpconv_fused(*a, **k)
+    finally:
+        ops.KP_X3 = keep
+    torch.cuda.synchronize()
+    return x3, f32
+
+
+@pytest.mark.parametrize("cin", [64, 128, 256])
+def test_split_contraction_error_against_float64(device, cin):
+    from d3feat_amd import ops
+    pts, nb, f, W, kp = _operands(cin, device, 640 + cin)
+    x3, f32 = _both(ops, pts, pts, nb, f, kp, W, 0.03)
+    ref = _kpconv64(pts, nb, f, torch.from_numpy(kp).to(device), W, 0.03)
+    scale = ref.abs().max().item()
+    e3, e32 = (x3.double() - ref).abs().max().item() / scale, (f32.double() - ref).abs().max().item() / scale
+    print("Cin %d: split form %.2e, fp32 MFMA form %.2e of max |out| = %.3g" % (cin, e3, e32, scale))
+    # both carry the influences' v_sqrt / fp32 aggregation error (~1e-6); the split contraction must not add to it
+    assert e3 <= 5e-6 and e32 <= 5e-6 and e3 <= 1.5 * e32 + 2e-7
+    assert (x3 - f32).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("cin", [64, 128])
+def test_split_contraction_exactness_cases(device, cin):
+    """K_values = a selection: output column o of kernel point p copies weighted-feature channel (o + p) % Cin -- one nonzero
+    product per (k, column), weights 1.0: every plane product is exact and the sum over the 15 kernel points is the same fp32
+    sum in both forms up to order; with ONE kernel point selected the output IS the weighted feature, bit for bit."""
+    from d3feat_amd import ops
+    pts, nb, f, _, kp = _operands(cin, device, 77 + cin, n_raw=15000)
+    W1 = torch.zeros((15, cin, cin), dtype=torch.float32, device=device)
+    W1[3] = torch.eye(cin, device=device)                      # out[:, o] = wf[:, 3, o] / count
+    x3, f32 = _both(ops, pts, pts, nb, f, kp, W1, 0.03)
+    assert torch.equal(x3, f32)                                 # one exact product per output: both forms copy the same float
+    wf, inv = ops.kpconv_aggregate(pts, pts, nb, f, kp, 0.03)
+    want = wf.view(-1, 15, cin)[:, 3, :] * inv[:, None]
+    assert (x3 - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())   # (aggregation order differs: vec4 kernel)
+    # integer-valued operands: every product and partial sum is an integer below 2^24 -> exact in any order, in both forms
+    fi = torch.randint(-3, 4, f.shape, device=device).float()
+    Wi = torch.randint(-2, 3, (15, cin, cin), device=device).float()
+    kp0 = np.zeros((15, 3), np.float32)
+    kp0[1:] = 10.0                                              # only the centre kernel point has influence ...
+    x3, f32 = _both(ops, pts, pts, nb, fi, kp0, Wi, 1e3)        # ... and a huge extent makes it ~1 - d/1000: not an integer:
+    assert (x3 - f32).abs().max().item() <= 2e-6 * max(1.0, f32.abs().max().item())
+
+
+def test_split_contraction_epilogue_and_capacity_rows(device):
+    """Epilogue operands (batch-norm scale / shift, residual, LeakyReLU) and a capacity-mode call (device-resident row count
+    smaller than the grid): the two forms agree to fp32 rounding; rows beyond the real count are not written."""
+    from d3feat_amd import ops
+    pts, nb, f, W, kp = _operands(64, device, 5, n_raw=20000)
+    rng = np.random.default_rng(9)
+    cs = torch.from_numpy((rng.random(64) + 0.5).astype(np.float32)).to(device)
+    ch = torch.from_numpy(rng.standard_normal(64).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.standard_normal((pts.shape[0], 64)).astype(np.float32)).to(device)
+    x3, f32 = _both(ops, pts, pts, nb, f, kp, W, 0.03, col_scale=cs, col_shift=ch, residual=res, leaky=True)
+    assert (x3 - f32).abs().max().item() <= 2e-6 * max(1.0, f32.abs().max().item())
