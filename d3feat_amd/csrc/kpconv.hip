@@ -208,60 +208,6 @@ __device__ __forceinline__ void kp_count_positive(bool positive, int ql, int cl,
     }
 }
 
-// ---- sparse phase B (round 5) --------------------------------------------------------------------------------------------------
-// With the shipped geometry (15 kernel points on a shell of 1.5 extents, linear influence of radius one extent, neighbours within
-// 2.5 extents) a neighbour lies inside the influence ball of 1.15 kernel points on average: 93 % of the 15 x K influences of a query
-// are EXACT zeros, and adding 0 * f changes nothing.  The lanes of a wavefront belong to 64 / LQ different queries whose k-th
-// neighbours are unrelated points, so the skip has to be wavefront-uniform to save issue slots: phase A publishes, per neighbour slot
-// of the chunk, the 15-bit pattern "some query of this wavefront has a non-zero influence of kernel point p here" (one LDS word per
-// slot and wavefront, OR-ed by the lanes that hold the pairs); phase B reads the pattern of a slot into a scalar register and
-// branches around the weight loads and the FMAs of the kernel points nobody needs: ~41 % of the (slot, kernel point) blocks remain at
-// 8 queries per wavefront, 23 % at 4, 12 % at 2 (profiles/r05_experiments.txt s1).  Results are those of the dense loop exactly
-// wherever the features are finite (a skipped term is 0 * f, and x + 0 = x); a NON-FINITE feature row that every kernel point of its
-// query ignores no longer turns the output into NaN -- the dense form's 0 * Inf.  (The reference's own gather + matmul would; no
-// finite activation reaches that case, tests/test_gpu_network.py keeps the planted-NaN rows' REAL neighbours non-finite.)
-__device__ __forceinline__ unsigned kp_nonzero_bits(const float* w) {
-    unsigned z = 0u;
-#pragma unroll
-    for (int p = 0; p < KP_MAXP - 1; ++p) z |= min(__float_as_uint(w[p]) & 0x7fffffffu, 1u) << p;
-    return z;
-}
-// one neighbour slot: ws = the slot's 16 influences in LDS (kp_store_w layout, rotation r = slot >> 1), m = its pattern (scalar)
-__device__ __forceinline__ void kp_sparse_slot(float (&acc)[KP_MAXP - 1][4], unsigned m, const float* __restrict__ ws, int r,
-                                               const float4& fv) {
-    // (the influences are separate scalars on purpose: as an array with conditional element stores the optimiser turns them into
-    // ONE 16-wide vector value and copies all of it at every branch -- 500 spilled registers)
-#define KP_SP_LOAD2(P_)                                                                                      \
-    float w##P_##a, w##P_##b;                                                                                \
-    if (m & (3u << (P_))) {                                                                                  \
-        const float2 t_ = *(const float2*)&ws[((((P_) >> 2) + r) & 3) * 4 + ((P_) & 3)];                      \
-        w##P_##a = t_.x;                                                                                     \
-        w##P_##b = t_.y;                                                                                     \
-    }
-    KP_SP_LOAD2(0) KP_SP_LOAD2(2) KP_SP_LOAD2(4) KP_SP_LOAD2(6) KP_SP_LOAD2(8) KP_SP_LOAD2(10) KP_SP_LOAD2(12)
-    float w14a;
-    if (m & (1u << 14)) w14a = ws[((3 + r) & 3) * 4 + 2];
-#undef KP_SP_LOAD2
-#define KP_SP_FMA(P_, W_)                                                                                    \
-    if (m & (1u << (P_))) {                                                                                  \
-        asm volatile("");      /* keeps the block a branch: if-converted it is the dense loop again */        \
-        acc[P_][0] = fmaf(W_, fv.x, acc[P_][0]);                                                             \
-        acc[P_][1] = fmaf(W_, fv.y, acc[P_][1]);                                                             \
-        acc[P_][2] = fmaf(W_, fv.z, acc[P_][2]);                                                             \
-        acc[P_][3] = fmaf(W_, fv.w, acc[P_][3]);                                                             \
-    }
-    KP_SP_FMA(0, w0a) KP_SP_FMA(1, w0b) KP_SP_FMA(2, w2a) KP_SP_FMA(3, w2b) KP_SP_FMA(4, w4a) KP_SP_FMA(5, w4b) KP_SP_FMA(6, w6a)
-    KP_SP_FMA(7, w6b) KP_SP_FMA(8, w8a) KP_SP_FMA(9, w8b) KP_SP_FMA(10, w10a) KP_SP_FMA(11, w10b) KP_SP_FMA(12, w12a)
-    KP_SP_FMA(13, w12b) KP_SP_FMA(14, w14a)
-#undef KP_SP_FMA
-    static_assert(KP_MAXP == 16, "the slot code is written out for 15 kernel points");
-}
-// D3F_KP_SPARSE=0 keeps the dense loops (A/B measurements)
-static inline bool kp_sparse_enabled() {
-    static const bool on = []() { const char* e = getenv("D3F_KP_SPARSE"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 // row_pos[s] = (sum_c f[s,c] > 0) ? 1 : 0  -- the reference's neighbour-count test (:250-251) depends only on
 // the support row, so it is evaluated once per support instead of once per (query, neighbour).
 // The test is discontinuous: a row whose fp32 sum lies within rounding of 0 flips with the summation order, and the
@@ -301,8 +247,8 @@ __global__ void __launch_bounds__(256) kp_rowpos_vec_kernel(const FT* __restrict
     if (in && l == 0) pos[row] = s > 0.0 ? 1 : 0;
 }
 
-template <int LQ, bool FAST, class FT = float, bool SP = false>  // lanes per query = Cin / 4; FAST: linear / sum / 15 kernel points (kp_influences_t)
-__global__ void __launch_bounds__(256)                            // SP (LQ <= 64: a query's lanes share a wavefront): sparse phase B
+template <int LQ, bool FAST, class FT = float>  // lanes per query = Cin / 4; FAST: linear / sum / 15 kernel points (kp_influences_t)
+__global__ void __launch_bounds__(256)
 kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                 int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                 KpParams P, float* __restrict__ wf, float* __restrict__ inv_cnt, const int* __restrict__ Nq_dev,
@@ -318,9 +264,6 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
     __shared__ __attribute__((aligned(16))) float lw[TQ * WS];
     __shared__ int lidx[TQ * KC];
     __shared__ int lcnt[TQ];
-    static_assert(!SP || LQ <= 64, "the sparse form wants a query's lanes in one wavefront");
-    constexpr int MKC = KC < 64 ? KC : 64;                             // pattern words per wavefront (slots of the chunk its lanes hold)
-    __shared__ unsigned lmask[SP ? 4 * MKC : 1];
     const int tid = threadIdx.x;
     const int ql = tid / LQ, cl = tid % LQ;  // query-in-block, channel group
     // q_order: a spatially coherent visiting order (cell-sorted): the TQ queries of a workgroup then share most of their
@@ -340,46 +283,30 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
     for (int k0 = 0; k0 < K; k0 += KC) {
         const int id_next = kp_pair_index(idrow, qg < Nq, k0 + KC + cl, K, Ns);              // in flight during phase A
         // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
-        unsigned* wmask = lmask + (SP ? (tid >> 6) * MKC : 0);
-        if (SP && (tid & 63) < MKC) wmask[tid & 63] = 0u;               // (this wave's words: LDS operations of one wave keep their order)
         {
             float w[KP_MAXP];
             const bool positive = kp_pair_influences<FAST>(P, pr, qx, qy, qz, w);
             kp_count_positive<LQ>(positive, ql, cl, lcnt);
             lidx[ql * KC + cl] = pr.id;
             kp_store_w(&lw[ql * WS + cl * 16], cl, w);
-            if (SP) {
-                const unsigned z = kp_nonzero_bits(w);
-                if (z) atomicOr(&wmask[cl & (MKC - 1)], z);
-            }
         }
         __syncthreads();
         pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                          // in flight during phase B
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
         const int kend = min(KC, K - k0);
-        const unsigned zall = SP ? wmask[tid & (MKC - 1)] : 0u;          // lane l holds the pattern of slot l % KC
         // feature rows are requested in groups of up to eight before any is consumed: the gathers are independent, so their
         // latencies overlap instead of adding up (the kernel is bound by these round trips, not by the FMAs)
         constexpr int PF = KC < 8 ? KC : 8;
         for (int kg = 0; kg < kend; kg += PF) {
             float4 fv[PF];
             int ids[PF];
-            unsigned ms[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                if (SP) {
-                    ms[u] = (unsigned)__builtin_amdgcn_readlane((int)zall, (kg + u) & (MKC - 1));
-                    if (!ms[u]) ids[u] = -1;         // nobody in the wave needs this row
-                }
                 fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (SP) {
-                    if (ms[u]) kp_sparse_slot(acc, ms[u], &lw[ql * WS + (kg + u) * 16], (kg + u) >> 1, fv[u]);
-                    continue;
-                }
                 if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
                 kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
@@ -727,8 +654,8 @@ __device__ __forceinline__ void kf32_contract_epilogue(TileWriter write_tile, in
     }
 }
 
-template <bool FAST, int PF = 8, class FT = float, bool SP = false>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
-__global__ void __launch_bounds__(256, PF == 4 ? 4 : 3)                  // SP: sparse phase B (kp_sparse_slot)
+template <bool FAST, int PF = 8, class FT = float>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
+__global__ void __launch_bounds__(256, PF == 4 ? 4 : 3)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                       int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                       KpParams P, const float* __restrict__ W, KpEpi E, FT* __restrict__ out, int ldo,
@@ -747,7 +674,6 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     int* lidx = (int*)(kf_smem + KF_TQ * KF_TS);            // [32][8]
     int* lcnt = lidx + KF_TQ * KF_LQ;                       // [32]
     int* lq = lcnt + KF_TQ;                                 // [32] global query index of each tile row
-    unsigned* lmask = (unsigned*)(lq + KF_TQ);              // [4 waves][8 slots] patterns of the chunk (SP)
     const int tid = threadIdx.x;
     const int ql = tid / KF_LQ, cl = tid % KF_LQ;
     const int qslot = tile * KF_TQ + ql;
@@ -764,45 +690,29 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += KF_LQ) {
         const int id_next = kp_pair_index(idrow, qslot < Nq, k0 + KF_LQ + cl, K, Ns);       // in flight during phase A
-        unsigned* wmask = lmask + (tid >> 6) * KF_LQ;
-        if (SP && (tid & 63) < KF_LQ) wmask[tid & 63] = 0u;       // (this wave's words: LDS operations of one wave keep their order)
         {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
             float w[KP_MAXP];
             const bool positive = kp_pair_influences<FAST>(P, pr, qx, qy, qz, w);
             kp_count_positive<KF_LQ>(positive, ql, cl, lcnt);
             lidx[ql * KF_LQ + cl] = pr.id;
             kp_store_w(&lw[ql * KF_WS + cl * 16], cl, w);
-            if (SP) {
-                const unsigned z = kp_nonzero_bits(w);
-                if (z) atomicOr(&wmask[cl], z);
-            }
         }
         __syncthreads();
         pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                         // in flight during phase B
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3) ----
         // all eight feature rows of the chunk are requested before any is consumed: the gathers are independent, so their
         // latencies overlap instead of adding up (the kernel is bound by these round trips, not by the FMAs)
-        const unsigned zall = SP ? wmask[tid & (KF_LQ - 1)] : 0u;   // lane l holds the pattern of slot l % 8
 #pragma unroll
         for (int k1 = 0; k1 < KF_LQ; k1 += PF) {
             float4 fv[PF];
             int ids[PF];
-            unsigned ms[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = lidx[ql * KF_LQ + k1 + u];
-                if (SP) {
-                    ms[u] = (unsigned)__builtin_amdgcn_readlane((int)zall, k1 + u);
-                    if (!ms[u]) ids[u] = -1;         // nobody in the wave needs this row
-                }
                 fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (SP) {
-                    if (ms[u]) kp_sparse_slot(acc, ms[u], &lw[ql * KF_WS + (k1 + u) * 16], (k1 + u) >> 1, fv[u]);
-                    continue;
-                }
                 if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
                 kp_load_w(&lw[ql * KF_WS + (k1 + u) * 16], k1 + u, w);
@@ -848,7 +758,7 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;     // (16.7 M rows per call: use d3f_kpconv_aggregate + d3f_gemm_f32)
     const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
-    const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ + 4 * KF_LQ) * sizeof(int);
+    const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
     static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static std::atomic<unsigned long long> lds_done{0};
     // feature rows requested before any is consumed: 4 -> 126 / 123 registers = four workgroups per CU.  (Round 1 measured the
@@ -856,28 +766,20 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     // 1542 / 1535 against 1521 / 1529 fragments/s, profiles/r03_experiments.txt x16.)
 #define D3F_KP_PF 4
 #define D3F_KP_PF_H 4          // the same for bf16 feature rows (120 registers): 202 -> 178 us and 112 -> 99 us per launch (x24)
-    const void* const fns[3] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF>, (const void*)kpconv_fused32_kernel<false, 8>,
-                                (const void*)kpconv_fused32_kernel<true, D3F_KP_PF, float, true>};
+    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF>, (const void*)kpconv_fused32_kernel<false, 8>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-    const bool sp = kp_sparse_enabled();
-#define D3F_KF(FAST_, PF_, SP_)                                                                                              \
-    kpconv_fused32_kernel<FAST_, PF_, float, SP_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, \
-                                                                                             P, W, E, out, ldo, Nq_dev, Ns_dev, q_order)
+#define D3F_KF(FAST_, PF_)                                                                                                   \
+    kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
+                                                                                 out, ldo, Nq_dev, Ns_dev, q_order)
     if (feat_bf16) {      // bf16 feature storage (in and out); the shipped configuration only; no residual operand
         if (!kp_fast_config(num_kp, influence, aggregation) || residual) return D3F_ERR_ARG;
         static std::atomic<unsigned long long> lds_done_h{0};
-        const void* const fnh[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short>,
-                                    (const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, true>};
+        const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short>};
         if (d3f_opt_in_lds(lds_done_h, fnh, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-        if (sp)
-            kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, true><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
-                q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
-        else
-            kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
-                q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
-    } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8, false);
-    else if (sp) D3F_KF(true, D3F_KP_PF, true);
-    else D3F_KF(true, D3F_KP_PF, false);
+        kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
+            q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
+    } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
+    else D3F_KF(true, D3F_KP_PF);
 #undef D3F_KF
     D3F_LAUNCH_CHECK();
     return D3F_OK;
@@ -947,8 +849,8 @@ __device__ __forceinline__ void kx_split4(float x0, float x1, float x2, float x3
 // Registers: 60 accumulators + the gather prefetch decide the occupancy.  512-thread workgroups (Cin = 128) are two waves
 // per SIMD each: at more than 128 registers only ONE workgroup fits a CU and its gather and matrix phases cannot overlap with
 // anybody's, so that variant prefetches four rows instead of eight and is held to 128 registers (two workgroups per CU).
-template <int LQ, int PF = (LQ >= 32 ? 4 : 8), class FT = float, bool X3 = false, bool SP = false>   // lanes per query = Cin / 4 (16, 32 or 64); Cout == Cin; waves = LQ / 4 = Cout / 16
-__global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)                      // X3: Wp = the pre-split planes (d3f_kpconv_pack_weights_x3); SP: sparse phase B
+template <int LQ, int PF = (LQ >= 32 ? 4 : 8), class FT = float, bool X3 = false>   // lanes per query = Cin / 4 (16, 32 or 64); Cout == Cin; waves = LQ / 4 = Cout / 16
+__global__ void __launch_bounds__(KG_TQ * LQ, PF == 4 ? 4 : 3)                      // X3: Wp = the pre-split planes (d3f_kpconv_pack_weights_x3)
 kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                     int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
                     KpParams P, const float* __restrict__ Wp, KpEpi E, FT* __restrict__ out, int ldo,
@@ -968,7 +870,6 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     __shared__ int lidx[KG_TQ * KC];
     __shared__ int lcnt[KG_TQ];
     __shared__ int lq[KG_TQ];
-    __shared__ unsigned lmask[SP ? (LQ / 4) * KC : 1];                     // [wave][slot] patterns of the chunk (kp_sparse_slot)
     float* lw = region;
     float* wft = region;
     const int tid = threadIdx.x;
@@ -988,8 +889,6 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += KC) {
         const int id_next = kp_pair_index(idrow, pair_lane, k0 + KC + cl, K, Ns);           // in flight during phase A
-        unsigned* wmask = lmask + (SP ? (tid >> 6) * KC : 0);
-        if (SP && (tid & 63) < KC) wmask[tid & 63] = 0u;            // (this wave's words: LDS operations of one wave keep their order)
         {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
             float w[KP_MAXP];
             const bool positive = kp_pair_influences<true>(P, pr, qx, qy, qz, w);
@@ -997,36 +896,22 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             if (cl < KC) {
                 lidx[ql * KC + cl] = pr.id;
                 kp_store_w(&lw[ql * WS + cl * 16], cl, w);
-                if (SP) {
-                    const unsigned z = kp_nonzero_bits(w);
-                    if (z) atomicOr(&wmask[cl], z);                 // (a query's lanes share a wavefront: LQ <= 64)
-                }
             }
         }
         __syncthreads();
         pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                         // in flight during phase B
         // ---- phase B: thread = (query ql, channels 4*cl .. 4*cl+3); PF feature rows requested before any is consumed ----
         const int kend = min(KC, K - k0);
-        const unsigned zall = SP ? wmask[tid & (KC - 1)] : 0u;       // lane l holds the pattern of slot l % KC
         for (int kg = 0; kg < kend; kg += PF) {
             float4 fv[PF];
             int ids[PF];
-            unsigned ms[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ids[u] = (kg + u < kend) ? lidx[ql * KC + kg + u] : -1;
-                if (SP) {
-                    ms[u] = (unsigned)__builtin_amdgcn_readlane((int)zall, (kg + u) & (KC - 1));
-                    if (!ms[u]) ids[u] = -1;         // nobody in the wave needs this row (slots beyond kend are shadows: pattern 0)
-                }
                 fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (SP) {
-                    if (ms[u]) kp_sparse_slot(acc, ms[u], &lw[ql * WS + (kg + u) * 16], (kg + u) >> 1, fv[u]);
-                    continue;
-                }
                 if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
                 kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
@@ -1264,23 +1149,24 @@ static int kp_fused_launch(const float* q, int Nq, const float* s, int Ns, const
     const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
     const int blocks = d3f_cdiv(Nq, KG_TQ);
-    const bool sp = kp_sparse_enabled();
-#define D3F_KG(LQ_, PF_, FT_, F_, O_)                                                                                                      \
-    do {                                                                                                                               \
-        if (sp) kpconv_fused_kernel<LQ_, PF_, FT_, X3, true><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, F_, ldf, rowpos, \
-                                                                                            P, W_packed, E, O_, ldo, Nq_dev, Ns_dev, q_order); \
-        else kpconv_fused_kernel<LQ_, PF_, FT_, X3, false><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, F_, ldf, rowpos,  \
-                                                                                          P, W_packed, E, O_, ldo, Nq_dev, Ns_dev, q_order);  \
-    } while (0)
+#define D3F_KG(LQ_, PF_)                                                                                                    \
+    kpconv_fused_kernel<LQ_, PF_, float, X3><<<blocks, KG_TQ * LQ_, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W_packed, \
+                                                                                 E, out, ldo, Nq_dev, Ns_dev, q_order)
     if (feat_bf16) {
         const unsigned short* fh = (const unsigned short*)f_;
         unsigned short* oh = (unsigned short*)out_;
-        if (Cin == 64) D3F_KG(16, D3F_KP_PF_H, unsigned short, fh, oh);
-        else if (Cin == 256) D3F_KG(64, 4, unsigned short, fh, oh);
-        else D3F_KG(32, 4, unsigned short, fh, oh);
-    } else if (Cin == 64) D3F_KG(16, D3F_KP_PF, float, f, out);
-    else if (Cin == 256) D3F_KG(64, 4, float, f, out);
-    else D3F_KG(32, 4, float, f, out);
+        if (Cin == 64)
+            kpconv_fused_kernel<16, D3F_KP_PF_H, unsigned short, X3><<<blocks, KG_TQ * 16, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+                                                                                         W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
+        else if (Cin == 256)
+            kpconv_fused_kernel<64, 4, unsigned short, X3><<<blocks, KG_TQ * 64, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+                                                                                         W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
+        else
+            kpconv_fused_kernel<32, 4, unsigned short, X3><<<blocks, KG_TQ * 32, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P,
+                                                                                         W_packed, E, oh, ldo, Nq_dev, Ns_dev, q_order);
+    } else if (Cin == 64) D3F_KG(16, D3F_KP_PF);
+    else if (Cin == 256) D3F_KG(64, 4);
+    else D3F_KG(32, 4);
 #undef D3F_KG
     D3F_LAUNCH_CHECK();
     return D3F_OK;
@@ -1358,10 +1244,7 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
         if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;     // bf16 feature rows in, fp32 weighted features out; the deep layers of the shipped configuration
         const unsigned short* fh = (const unsigned short*)f_;
         if (!fast || (ldf % 4) || ((uintptr_t)f_ & 7) || ((uintptr_t)wf & 15) || !(Cin == 256 || Cin == 512)) return D3F_ERR_ARG;
-        if (Cin == 256 && kp_sparse_enabled())
-            kpconv_agg_vec4<64, true, unsigned short, true><<<d3f_cdiv(Nq, 4), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P, wf,
-                                                                                               inv_cnt, Nq_dev, Ns_dev, q_order);
-        else if (Cin == 256)
+        if (Cin == 256)
             kpconv_agg_vec4<64, true, unsigned short><<<d3f_cdiv(Nq, 4), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, fh, ldf, rowpos, P, wf,
                                                                                          inv_cnt, Nq_dev, Ns_dev, q_order);
         else
@@ -1383,9 +1266,6 @@ extern "C" int d3f_kpconv_aggregate(const float* q, int Nq, const float* s, int 
     else if (vec && Cin == 32) D3F_AGG(8);
     else if (vec && Cin == 64) D3F_AGG(16);
     else if (vec && Cin == 128) D3F_AGG(32);
-    else if (vec && Cin == 256 && fast && kp_sparse_enabled())     // one query per wavefront: 6 % of the (slot, kernel point) blocks remain
-        kpconv_agg_vec4<64, true, float, true><<<d3f_cdiv(Nq, 4), 256, 0, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, wf,
-                                                                                    inv_cnt, Nq_dev, Ns_dev, q_order);
     else if (vec && Cin == 256) D3F_AGG(64);
     else if (vec && Cin == 512) D3F_AGG(128);
     else if (vec && Cin == 1024) D3F_AGG(256);
