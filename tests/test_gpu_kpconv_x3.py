@@ -19,7 +19,7 @@ def _kpconv64(pts, nb, f, kp, W, extent):
     idx = nb.long()
     rel = P[idx] - pts.double()[:, None, :]                                    # [n, K, 3]
     d = (rel[:, :, None, :] - kp.double()[None, None]).pow(2).sum(-1).add(1e-10).sqrt()      # [n, K, 15]
-    w = (1.0 - d / extent).clamp(min=0.0)
+    w = (1.0 - d / (2.0 * extent)).clamp(min=0.0)                              # (the reference's linear influence: :215)
     wf = torch.einsum("nkp,nkc->npc", w, F[idx])                               # [n, 15, Cin]
     out = torch.einsum("npc,pco->no", wf, W.double())
     cnt = (F[idx].sum(-1) > 0).sum(-1).clamp(min=1).double()
