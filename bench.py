@@ -118,6 +118,9 @@ def parse():
     ap.add_argument("--gather-chunk", type=int, default=8,
                     help="N > 1: fragments per asynchronous shard-exchange chunk (parallel.ShardCollector overlapped mode: the "
                          "shards cross xGMI while the next fragments are computed); 0 = one all_gather of the whole shard at the end")
+    ap.add_argument("--schedule", default="", help="comma list of replay sizes for ONE window (sum = --steps), submitted round-robin over "
+                    "the slots: a short job has no steady state, so an uneven split (a small first replay reaches the network phase "
+                    "while the others are still in the latency-bound geometry chain) changes its wall time; engine batch = the largest")
     ap.add_argument("--seed-rank", type=int, default=-1, help="generate the synthetic pool of THIS rank of a larger job (default: the "
                     "process's own rank): a single process reproduces what rank r of an N-rank run computed (tests/test_gpu_multi.py)")
     ap.add_argument("--limits", default="", help="comma list: neighbourhood limits to use instead of calibrating (to repeat a multi-rank "
@@ -276,6 +279,12 @@ def main():
         args.pool = max(args.pool if args.config4 else 2, 2)
         if args.demo:
             args.pool, args.cpu_fragments = 2, min(args.cpu_fragments, 2)
+    schedule = [int(x) for x in args.schedule.split(",")] if args.schedule else None
+    if schedule:
+        assert sum(schedule) == args.steps and min(schedule) >= 1, "--schedule must sum to --steps"
+        args.batch = max(schedule)
+        if args.slots <= 0:
+            args.slots = min(len(schedule), 4)
     if args.slots <= 0:
         # a job of one round of replays (the driver's 20 fragments): three replays of 7 beat four of 5 since the contractions moved
         # to the operand-split form (1469 against 1437 fragments/s, three alternating pairs in one visit: r04_experiments.txt x9)
@@ -403,11 +412,12 @@ def main():
                     collect.add(wl.kept(rec))
             busy[sl] = False
         i = k = 0
+        sizes = schedule if (schedule and nsteps == args.steps and engine.F >= max(schedule)) else None
         while i < nsteps:                        # replays of up to F steps each, round-robin over the slots
             sl = k % S
             if busy[sl]:
                 drain(sl)
-            nb = min(F, nsteps - i)
+            nb = min(F, nsteps - i) if sizes is None else sizes[k]
             engine.submit(sl, [pool[(i + j) % len(pool)] for j in range(nb)])
             busy[sl] = True
             i += nb
@@ -628,7 +638,7 @@ def main():
                                      "HIP-graph replay of %d stacked step(s), device-resident sizes, %d replays in flight%s"
                                      % (engine.F, len(engine.slots),
                                         "; self-pair computed once and mirrored" if args.mirror else "")),
-                       "fragments_per_replay": (engine.F if engine is not None else 1),
+                       "fragments_per_replay": (engine.F if engine is not None else 1), "schedule": schedule,
                        "capacities": (None if engine is None else
                                       {"raw_points_per_fragment": engine.raw_cap, "voxels_per_cloud": engine.n0_cap,
                                        "rows_per_level": [int(c) for c in engine.caps]}),
@@ -694,7 +704,7 @@ def compact_line(res, detail_path=None):
     out["dtype"] = "f32" if dt == "f32" else ("bf16" if dt.startswith("bf16") else _short(dt, 40))
     cfg = res.get("config") or {}
     c = {"workload": _short(cfg.get("workload"), 240)}
-    c.update(_pick(cfg, ["points_per_cloud", "neighborhood_limits", "fragments_per_gpu", "parallelism", "fragments_per_replay",
+    c.update(_pick(cfg, ["points_per_cloud", "neighborhood_limits", "fragments_per_gpu", "parallelism", "fragments_per_replay", "schedule",
                          "engine_fallbacks", "engine_isolated_replays", "rccl"]))
     c["contraction"] = _short(cfg.get("contraction"), 110)
     c["execution"] = _short(cfg.get("execution"), 120)
@@ -833,9 +843,9 @@ def install_ablation(families):
     skip = set()
     for f in families:
         skip |= {"gemm": {"d3f_gemm_f32", "d3f_gemm_upsample_cat_f32", "d3f_gemm_f32t", "d3f_gemm_x3"},
-                 "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused", "d3f_kpconv_fused_x3"},
+                 "kpconv": {"d3f_kpconv_aggregate", "d3f_kpconv_fused_c1", "d3f_kpconv_fused32", "d3f_kpconv_fused32_x3", "d3f_kpconv_fused", "d3f_kpconv_fused_x3"},
                  "kpconv_deep": {"d3f_kpconv_fused", "d3f_kpconv_fused_x3", "d3f_kpconv_aggregate"},
-                 "kpconv32": {"d3f_kpconv_fused32"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
+                 "kpconv32": {"d3f_kpconv_fused32", "d3f_kpconv_fused32_x3"}, "kpconv_c1": {"d3f_kpconv_fused_c1"},
                  "rowpos": {"d3f_row_positive"}, "maxpool": {"d3f_ind_max_pool"}, "head": {"d3f_detect_head"},
                  "pack": {"d3f_pack_descriptors"},
                  # geometry: only meaningful together with the whole network ablated (nothing consumes the index matrices then)

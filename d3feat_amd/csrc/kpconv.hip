@@ -581,6 +581,44 @@ extern "C" int d3f_kpconv_fused_c1(const float* q, int Nq, const float* s, int N
 // split the 240 k-steps and their partial tiles are summed through LDS), followed by the neighbour-count division,
 // batch norm and LeakyReLU.  Only out [Nq, 32] reaches HBM.
 // ------------------------------------------------------------------------------------------------
+// ---- the contraction of the fused kernels by EXACT operand splitting (round 5; the scheme of gemm_x3.h) ------------------------
+// Levels 1 and 2 spend more matrix-pipe time in the 15*Cin-deep contraction than vector time in the aggregation (Cin = 64:
+// 240 v_mfma_f32_16x16x4_f32 of 32 cycles per wave and tile against ~5000 cycles of FMAs; Cin = 128: 480).  An fp32 value is three
+// bfloat16 planes exactly (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)), a product of two planes is exact in fp32, and
+// six of the nine plane products carry everything above 2^-23 of the product: 6 v_mfma_f32_16x16x32_bf16 (32 k, ~17 cycles each)
+// do the work of 8 v_mfma_f32_16x16x4_f32 (4 k, 32 cycles each): 2.5x less matrix-pipe time, fp32 in / fp32 out, error of the
+// order of the fp32 kernel's (tests/test_gpu_kpconv_x3.py).  The weighted features are split ONCE, when the accumulators are
+// written to the LDS tile (three planes [16][256 + 8] bf16, 528-byte rows: the 16 lanes of a fragment read hit 16 distinct 4-bank
+// groups); K_values is pre-split once per tensor in the B-fragment order (d3f_kpconv_pack_weights_x3): one coalesced 1 KB
+// load per wave, plane and 32-deep k-step.  Non-finite weighted features: Inf - Inf = NaN in the second plane -- non-finite in,
+// non-finite out, like the fp32 form (which yields +-Inf where this one yields NaN).
+typedef __bf16 kp_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned kx_cvt_pk(float lo, float hi) {     // two fp32 -> two bf16 (RNE), lo in bits 0..15
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// four consecutive-k floats -> the three operand planes (four bf16 = one uint2 each)
+__device__ __forceinline__ void kx_split4(float x0, float x1, float x2, float x3, uint2 (&pl)[3]) {
+    float v[4] = {x0, x1, x2, x3};
+    unsigned p[3][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float a = v[2 * i], b = v[2 * i + 1];
+        p[0][i] = kx_cvt_pk(a, b);
+        a -= __uint_as_float(p[0][i] << 16);
+        b -= __uint_as_float(p[0][i] & 0xffff0000u);
+        p[1][i] = kx_cvt_pk(a, b);
+        a -= __uint_as_float(p[1][i] << 16);
+        b -= __uint_as_float(p[1][i] & 0xffff0000u);
+        p[2][i] = kx_cvt_pk(a, b);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) pl[s] = make_uint2(p[s][0], p[s][1]);
+}
+#define KX_KT 256                       // k-values per contraction pass of the split form
+#define KX_TS (KX_KT + 8)               // bf16 per tile row (528 bytes)
+
 typedef float kp_f32x16 __attribute__((ext_vector_type(16)));
 typedef float kp_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -654,7 +692,101 @@ __device__ __forceinline__ void kf32_contract_epilogue(TileWriter write_tile, in
     }
 }
 
-template <bool FAST, int PF = 8, class FT = float>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
+// The same contraction + epilogue in the operand-split form (see the block comment above KX_KT; round 5): the tile goes through
+// LDS as three bf16 planes [32][160 + 8] in THREE passes of five kernel points (32 KB, the region's size: 336-byte rows put the 16
+// lanes of a fragment read on 16 distinct 4-bank groups), the four wavefronts split a pass's ten 16-deep k-steps (3 + 3 + 2 + 2,
+// rotated from pass to pass: 8 + 8 + 7 + 7 over the tile), v_mfma_f32_32x32x16_bf16, six products per step; W = the pre-split
+// planes in fragment order (d3f_kpconv_pack_weights_x3 with N = 32: Wx[(step * 3 + plane) * 64 + lane][8]).  48 MFMAs of 32 cycles
+// per wave and tile instead of 60 of 64.
+#define KF3_HP 5
+#define KF3_TS (KF3_HP * 32 + 8)      // bf16 per plane row
+template <class Acc, class FT>
+__device__ __forceinline__ void kf32_contract_epilogue_x3(Acc& acc, int tid, int ql, int cl, float* kf_smem, const int* lcnt,
+                                                          const int* lq, const KpParams& P, const unsigned short* __restrict__ Wx,
+                                                          const KpEpi& E, FT* __restrict__ out, int ldo) {
+    constexpr int PL = KF_TQ * KF3_TS;                       // bf16 per plane
+    static_assert(3 * PL * 2 <= KF_TQ * KF_TS * 4, "the plane tile must fit the region");
+    unsigned short* tile3 = (unsigned short*)kf_smem;
+    const int lane = tid & 63, wave = tid >> 6;
+    kp_f32x16 c0, c1;                                        // two accumulator chains, alternating (the products of a step are independent)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    const uint4* bw = (const uint4*)Wx + lane;               // + (step * 3 + plane) * 64
+    const unsigned short* ap = tile3 + (lane & 31) * KF3_TS + 8 * (lane >> 5);
+    const int npass = (P.num_kp + KF3_HP - 1) / KF3_HP;
+#define KF3_BLOAD(B_, ST_)                                                                                          \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) B_[pl] = bw[(size_t)((ST_) * 3 + pl) * 64];                \
+    } while (0)
+#define KF3_STEP(B_, LS_)                                                                                                      \
+    do {                                                                                                                       \
+        uint4 a_[3];                                                                                                           \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) a_[pl] = *(const uint4*)(ap + pl * PL + 16 * (LS_));                  \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[2]), __builtin_bit_cast(kp_bf16x8, B_[0]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[1]), __builtin_bit_cast(kp_bf16x8, B_[0]), c1, 0, 0, 0); \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[1]), __builtin_bit_cast(kp_bf16x8, B_[1]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[2]), c1, 0, 0, 0); \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[1]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[0]), c1, 0, 0, 0); \
+    } while (0)
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass >= npass) break;                             // (workgroup-uniform)
+        const int p0 = pass * KF3_HP;
+        const int np = min(P.num_kp - p0, KF3_HP);
+        const int S = 2 * np;                                 // 16-deep steps of the pass
+        const int s0 = (wave + 2 * pass) & 3;                 // this wave's steps: s0, s0 + 4, s0 + 8
+        uint4 b0[3], b1[3];
+        // the W fragments of the wave's first two steps are requested before the tile is written (clamped addresses: a wave with
+        // fewer steps multiplies nothing with them), the third while the second is multiplied
+        KF3_BLOAD(b0, p0 * 2 + min(s0, S - 1));
+        KF3_BLOAD(b1, p0 * 2 + min(s0 + 4, S - 1));
+        if (pass) __syncthreads();                            // the previous pass's planes have been consumed
+#pragma unroll
+        for (int p = 0; p < KP_MAXP - 1; ++p) {
+            const int pp = p - p0;
+            if (pp >= 0 && pp < KF3_HP && p < P.num_kp) {
+                uint2 pl[3];
+                kx_split4(acc[p][0], acc[p][1], acc[p][2], acc[p][3], pl);
+                unsigned short* d = tile3 + ql * KF3_TS + pp * 32 + 4 * cl;
+                *(uint2*)d = pl[0];
+                *(uint2*)(d + PL) = pl[1];
+                *(uint2*)(d + 2 * PL) = pl[2];
+            }
+        }
+        __syncthreads();
+        if (s0 < S) KF3_STEP(b0, s0);
+        if (s0 + 8 < S) KF3_BLOAD(b0, p0 * 2 + s0 + 8);
+        if (s0 + 4 < S) KF3_STEP(b1, s0 + 4);
+        if (s0 + 8 < S) KF3_STEP(b0, s0 + 8);
+    }
+#undef KF3_STEP
+#undef KF3_BLOAD
+    __syncthreads();
+    // partial tiles -> LDS (the tile region is free now), sum of the four in wave order, epilogue (as the fp32 form)
+    float* red = kf_smem;                                   // [4][32*32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[wave * 1024 + row * 32 + (lane & 31)] = c0[r] + c1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, row = e >> 5, o = e & 31;
+        const int gq = lq[row];
+        if (gq < 0) continue;
+        float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+        v *= 1.0f / fmaxf((float)lcnt[row], 1.0f);
+        if (E.col_scale) v *= E.col_scale[o];
+        if (E.col_shift) v += E.col_shift[o];
+        if (E.residual) v += E.residual[(size_t)gq * E.ldr + o];
+        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+        D3fFeat<FT>::st1(&out[(size_t)gq * ldo + o], v);
+    }
+}
+
+template <bool FAST, int PF = 8, class FT = float, bool X3 = false>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
 __global__ void __launch_bounds__(256, PF == 4 ? 4 : 3)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                       int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
@@ -737,15 +869,17 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
             }
         }
     };
-    kf32_contract_epilogue(write_tile, tid, kf_smem, lcnt, lq, P, W, E, out, ldo);
+    if constexpr (X3) kf32_contract_epilogue_x3(acc, tid, ql, cl, kf_smem, lcnt, lq, P, (const unsigned short*)W, E, out, ldo);
+    else kf32_contract_epilogue(write_tile, tid, kf_smem, lcnt, lq, P, W, E, out, ldo);
 }
 
-extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
-                                  const void* f_, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
-                                  float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
-                                  const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* out_,
-                                  int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16,
-                                  void* stream_) {
+template <bool X3>
+static int kp_fused32_launch(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                             const void* f_, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                             float KP_extent, int influence, int aggregation, const float* W, const float* col_scale,
+                             const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* out_,
+                             int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16,
+                             void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const float* f = (const float*)f_;
     float* out = (float*)out_;
@@ -766,17 +900,18 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     // 1542 / 1535 against 1521 / 1529 fragments/s, profiles/r03_experiments.txt x16.)
 #define D3F_KP_PF 4
 #define D3F_KP_PF_H 4          // the same for bf16 feature rows (120 registers): 202 -> 178 us and 112 -> 99 us per launch (x24)
-    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF>, (const void*)kpconv_fused32_kernel<false, 8>};
+    const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF, float, X3>,
+                                (const void*)kpconv_fused32_kernel<false, 8, float, X3>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_KF(FAST_, PF_)                                                                                                   \
-    kpconv_fused32_kernel<FAST_, PF_><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, W, E, \
-                                                                                 out, ldo, Nq_dev, Ns_dev, q_order)
+    kpconv_fused32_kernel<FAST_, PF_, float, X3><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, \
+                                                                                            W, E, out, ldo, Nq_dev, Ns_dev, q_order)
     if (feat_bf16) {      // bf16 feature storage (in and out); the shipped configuration only; no residual operand
         if (!kp_fast_config(num_kp, influence, aggregation) || residual) return D3F_ERR_ARG;
         static std::atomic<unsigned long long> lds_done_h{0};
-        const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short>};
+        const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, X3>};
         if (d3f_opt_in_lds(lds_done_h, fnh, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-        kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
+        kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, X3><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
             q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
     } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
     else D3F_KF(true, D3F_KP_PF);
@@ -784,6 +919,19 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
+#define KP_F32_ARGS                                                                                                               \
+    const float *q, int Nq, const float *s, int Ns, const int *idx, int ld_idx, int K, const void *f_, int ldf,                   \
+        const unsigned char *rowpos, const float *kp_host, int num_kp, float KP_extent, int influence, int aggregation,           \
+        const float *W, const float *col_scale, const float *col_shift, const float *residual, int ldr, int leaky, float alpha,   \
+        void *out_, int ldo, const int *Nq_dev, const int *Ns_dev, const int *q_order, int feat_bf16, void *stream_
+#define KP_F32_PASS                                                                                                               \
+    q, Nq, s, Ns, idx, ld_idx, K, f_, ldf, rowpos, kp_host, num_kp, KP_extent, influence, aggregation, W, col_scale, col_shift,   \
+        residual, ldr, leaky, alpha, out_, ldo, Nq_dev, Ns_dev, q_order, feat_bf16, stream_
+extern "C" int d3f_kpconv_fused32(KP_F32_ARGS) { return kp_fused32_launch<false>(KP_F32_PASS); }
+// the same operator with the contraction in the operand-split form; W = d3f_kpconv_pack_weights_x3(K_values [480, 32])'s planes
+extern "C" int d3f_kpconv_fused32_x3(KP_F32_ARGS) { return kp_fused32_launch<true>(KP_F32_PASS); }
+#undef KP_F32_ARGS
+#undef KP_F32_PASS
 
 // ------------------------------------------------------------------------------------------------
 // Whole KPConv_ops (kernels/convolution_ops.py:161-255) + inference epilogue for Cin = 64 / 128 -- levels 1 and 2, whose
@@ -804,44 +952,6 @@ extern "C" int d3f_kpconv_fused32(const float* q, int Nq, const float* s, int Ns
 //     reaches memory.
 // VALU (aggregation) and matrix (contraction) phases of different workgroups on a CU overlap: the two pipes are separate.
 // ------------------------------------------------------------------------------------------------
-// ---- the contraction of the fused kernels by EXACT operand splitting (round 5; the scheme of gemm_x3.h) ------------------------
-// Levels 1 and 2 spend more matrix-pipe time in the 15*Cin-deep contraction than vector time in the aggregation (Cin = 64:
-// 240 v_mfma_f32_16x16x4_f32 of 32 cycles per wave and tile against ~5000 cycles of FMAs; Cin = 128: 480).  An fp32 value is three
-// bfloat16 planes exactly (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)), a product of two planes is exact in fp32, and
-// six of the nine plane products carry everything above 2^-23 of the product: 6 v_mfma_f32_16x16x32_bf16 (32 k, ~17 cycles each)
-// do the work of 8 v_mfma_f32_16x16x4_f32 (4 k, 32 cycles each): 2.5x less matrix-pipe time, fp32 in / fp32 out, error of the
-// order of the fp32 kernel's (tests/test_gpu_kpconv_x3.py).  The weighted features are split ONCE, when the accumulators are
-// written to the LDS tile (three planes [16][256 + 8] bf16, 528-byte rows: the 16 lanes of a fragment read hit 16 distinct 4-bank
-// groups); K_values is pre-split once per tensor in the B-fragment order (d3f_kpconv_pack_weights_x3): one coalesced 1 KB
-// load per wave, plane and 32-deep k-step.  Non-finite weighted features: Inf - Inf = NaN in the second plane -- non-finite in,
-// non-finite out, like the fp32 form (which yields +-Inf where this one yields NaN).
-typedef __bf16 kp_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned kx_cvt_pk(float lo, float hi) {     // two fp32 -> two bf16 (RNE), lo in bits 0..15
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// four consecutive-k floats -> the three operand planes (four bf16 = one uint2 each)
-__device__ __forceinline__ void kx_split4(float x0, float x1, float x2, float x3, uint2 (&pl)[3]) {
-    float v[4] = {x0, x1, x2, x3};
-    unsigned p[3][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float a = v[2 * i], b = v[2 * i + 1];
-        p[0][i] = kx_cvt_pk(a, b);
-        a -= __uint_as_float(p[0][i] << 16);
-        b -= __uint_as_float(p[0][i] & 0xffff0000u);
-        p[1][i] = kx_cvt_pk(a, b);
-        a -= __uint_as_float(p[1][i] << 16);
-        b -= __uint_as_float(p[1][i] & 0xffff0000u);
-        p[2][i] = kx_cvt_pk(a, b);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) pl[s] = make_uint2(p[s][0], p[s][1]);
-}
-#define KX_KT 256                       // k-values per contraction pass of the split form
-#define KX_TS (KX_KT + 8)               // bf16 per tile row (528 bytes)
-
 #define KG_TQ 16                        // queries per workgroup = rows of one 16x16x4 tile
 #define KG_KT 512                       // k-values per contraction pass
 #define KG_TS (KG_KT + 4)               // LDS row stride of the wf tile (floats): 16-byte aligned rows, TS/4 odd
@@ -1106,11 +1216,31 @@ __global__ void __launch_bounds__(256) kp_pack_weights_x3_kernel(const float* __
     Wx[t] = (unsigned short)h;
 }
 
+// N = 32 (kpconv_fused32_kernel, v_mfma_f32_32x32x16_bf16): Wx[(step * 3 + plane) * 64 + lane][j] =
+// plane(W[16 step + 8 (lane >> 5) + j][lane & 31])   (K % 16 == 0)
+__global__ void __launch_bounds__(256) kp_pack_weights_x3_n32_kernel(const float* __restrict__ W, int K, unsigned short* __restrict__ Wx) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3ll * K * 32) return;
+    const int j = (int)(t & 7);
+    long long u = t >> 3;
+    const int lane = (int)(u & 63); u >>= 6;
+    const int pl = (int)(u % 3);
+    const int step = (int)(u / 3);
+    float x = W[(size_t)(16 * step + 8 * (lane >> 5) + j) * 32 + (lane & 31)];
+    unsigned h = d3f_bf16_rne(x);
+    if (pl > 0) { x -= __uint_as_float(h << 16); h = d3f_bf16_rne(x); }
+    if (pl > 1) { x -= __uint_as_float(h << 16); h = d3f_bf16_rne(x); }
+    Wx[t] = (unsigned short)h;
+}
+
 extern "C" size_t d3f_kpconv_packed_x3_bytes(int K, int N) { return (K > 0 && N > 0) ? (size_t)K * (size_t)N * 6u : 0; }
 
 extern "C" int d3f_kpconv_pack_weights_x3(const float* W, int K, int N, void* Wx, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (K < 32 || (K % 32) || N < 16 || (N % 16) || !W || !Wx) return D3F_ERR_ARG;
+    if (N == 32)        // the level-0 kernel multiplies 32 x 32 tiles: its own fragment order
+        kp_pack_weights_x3_n32_kernel<<<d3f_cdiv(3ll * K * 32, 256), 256, 0, stream>>>(W, K, (unsigned short*)Wx);
+    else
     kp_pack_weights_x3_kernel<<<d3f_cdiv(3ll * K * N, 256), 256, 0, stream>>>(W, K, N, (unsigned short*)Wx);
     D3F_LAUNCH_CHECK();
     return D3F_OK;

@@ -744,7 +744,8 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     num_kp, cin, cout = K_values.shape
     if cin != 32 or cout != 32 or f.shape[1] != 32:
         raise ValueError("kpconv_fused32 needs Cin == Cout == 32")
-    W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
+    x3 = KP_X3 and (num_kp * cin) % 32 == 0
+    W = packed_kpconv_weights_x3(K_values) if x3 else _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
     Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
     dev = q.device
     out = torch.empty((Nq, cout), dtype=f.dtype, device=dev)
@@ -758,7 +759,7 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
         ns_dev = _nd(features)
     _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, 32, row_pos.data_ptr(), ns_dev, _h(f), st), "row_positive")
     with _timed("kpconv_fused32", dict(Nq=Nq, Ns=Ns, K=K, Cin=32, Cout=32), dev):
-        rc = lib.d3f_kpconv_fused32(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
+        rc = (lib.d3f_kpconv_fused32_x3 if x3 else lib.d3f_kpconv_fused32)(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
                                     row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
                                     _AGGREGATION[aggregation_mode], W.data_ptr(),
                                     col_scale.data_ptr() if col_scale is not None else None,

@@ -222,8 +222,16 @@ int d3f_kpconv_pack_weights(const float* W, int K, int N, float* W_packed, void*
  * tensor by d3f_kpconv_pack_weights_x3 into d3f_kpconv_packed_x3_bytes(K, N) = 6 K N bytes (the B fragments of
  * v_mfma_f32_16x16x32_bf16; K % 32 == 0, N % 16 == 0), six exact products per fp32 product, fp32 accumulation: fp32 in, fp32 out,
  * 2.5 x less matrix-pipe time than v_mfma_f32_16x16x4_f32.  Arguments as d3f_kpconv_fused, W_packed = the planes. */
+/* (N = 32: the fragment order of d3f_kpconv_fused32_x3, v_mfma_f32_32x32x16_bf16; any other N: d3f_kpconv_fused_x3's.) */
 size_t d3f_kpconv_packed_x3_bytes(int K, int N);
 int d3f_kpconv_pack_weights_x3(const float* W, int K, int N, void* W_planes, void* stream);
+/* d3f_kpconv_fused32 (Cin = Cout = 32, the level-0 convolutions) with the split contraction; W_planes =
+ * d3f_kpconv_pack_weights_x3(K_values [15*32, 32]).  Arguments as d3f_kpconv_fused32. */
+int d3f_kpconv_fused32_x3(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                          const void* f, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                          float KP_extent, int influence, int aggregation, const float* W_planes, const float* col_scale,
+                          const float* col_shift, const float* residual, int ldr, int leaky, float alpha, void* out,
+                          int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, int feat_bf16, void* stream);
 int d3f_kpconv_fused_x3(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
                         const void* f, int ldf, int Cin, const unsigned char* rowpos, const float* kp_host, int num_kp,
                         float KP_extent, int influence, int aggregation, const float* W_planes, int Cout,

@@ -42,18 +42,19 @@ def _operands(cin, device, seed, n_raw=30000):
 
 def _both(ops, *a, **k):
     keep = ops.KP_X3
+    fn = ops.kpconv_fused32 if a[3].shape[1] == 32 else ops.kpconv_fused       # (Cin = 32: the level-0 kernel)
     try:
         ops.KP_X3 = True
-        x3 = ops.kpconv_fused(*a, **k)
+        x3 = fn(*a, **k)
         ops.KP_X3 = False
-        f32 = ops.kpconv_fused(*a, **k)
+        f32 = fn(*a, **k)
     finally:
         ops.KP_X3 = keep
     torch.cuda.synchronize()
     return x3, f32
 
 
-@pytest.mark.parametrize("cin", [64, 128, 256])
+@pytest.mark.parametrize("cin", [32, 64, 128, 256])
 def test_split_contraction_error_against_float64(device, cin):
     from d3feat_amd import ops
     pts, nb, f, W, kp = _operands(cin, device, 640 + cin)
@@ -67,7 +68,7 @@ def test_split_contraction_error_against_float64(device, cin):
     assert (x3 - f32).abs().max().item() <= 2e-6 * scale
 
 
-@pytest.mark.parametrize("cin", [64, 128])
+@pytest.mark.parametrize("cin", [32, 64, 128])
 def test_split_contraction_exactness_cases(device, cin):
     """K_values = a selection: output column o of kernel point p copies weighted-feature channel (o + p) % Cin -- one nonzero
     product per (k, column), weights 1.0: every plane product is exact and the sum over the 15 kernel points is the same fp32
