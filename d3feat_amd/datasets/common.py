@@ -117,7 +117,15 @@ class Dataset:
         layer_blocks = []
         input_points, input_neighbors, input_pools, input_upsamples, input_batches_len = [], [], [], [], []
         pending = []
-        status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)   # one fill: the searches do not reset theirs
+        if caps is not None:
+            # capacity mode (a replayed launch sequence): ONE persistent block of sticky status words per dataset object, zero when
+            # the sequence starts; the caller that reads `static_status` clears it again (ops.pack_status at the end of the engine's
+            # replay) -- no fill node per replay
+            status_all = getattr(self, "_status_all", None)
+            if status_all is None or status_all.device != dev:
+                status_all = self._status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+        else:
+            status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)   # one fill: the searches do not reset theirs
         arch = config.architecture
         cap = getattr(self, '_neighbor_cap', 192)
         grids = {}
@@ -357,8 +365,15 @@ class FragmentDataset(Dataset):
         def tf_map(anc_points, anc_keypts, pos_keypts, obj_inds, stack_lengths, ply_id, backup_points):
             batch_inds = None if self.fast else self.tf_get_batch_inds(stack_lengths)
             # stacked_features = ones([N, 1])  (demo_registration.py:102): a device-side fill
-            stacked_features = ops._tag(torch.ones((anc_points.shape[0], 1), dtype=torch.float32, device=anc_points.device),
-                                        anc_points)
+            if self.fast and self.caps is not None:
+                # capacity mode: the all-ones column is a constant of the launch sequence -- filled once, not once per replay
+                key = (int(anc_points.shape[0]), anc_points.device)
+                if getattr(self, "_ones_key", None) != key:
+                    self._ones_key, self._ones = key, torch.ones((key[0], 1), dtype=torch.float32, device=key[1])
+                ones = self._ones
+            else:
+                ones = torch.ones((anc_points.shape[0], 1), dtype=torch.float32, device=anc_points.device)
+            stacked_features = ops._tag(ones, anc_points)
             li = self.tf_descriptor_input(config, anc_points, stacked_features, stack_lengths, batch_inds,
                                           exact_shapes=not self.fast, up_first_column_only=self.fast, caps=self.caps)
             return li + [stack_lengths, anc_keypts, pos_keypts, ply_id, backup_points]

@@ -173,6 +173,7 @@ class FragmentEngine:
             sl.raw_len.fill_(per)
             with ops.private_workspace():
                 _, _, _, w_status, w_lens = self._sequence(sl)
+            w_status.zero_()              # the searches' status words are sticky: the replay's last node clears them (pack_status)
         sl.stream.synchronize()
         # one packed read-back per replay: [n_total, status0(2), status(k,2)..., lens(nb)]; the packing copies are nodes of
         # the graph (no host calls per replay), only the copy to the host follows the replay
@@ -184,10 +185,8 @@ class FragmentEngine:
         with ops.private_workspace() as pw:
             with torch.cuda.graph(sl.graph, stream=sl.stream):
                 sl.pts, sl.desc, sl.score, sl.status, sl.lens = self._sequence(sl)
-                sl.dev_stat[0:1].copy_(sl.pts.n_dev)
-                sl.dev_stat[1:3].copy_(sl.status0)
-                sl.dev_stat[3:sl.nstat].copy_(sl.status.reshape(-1))
-                sl.dev_stat[sl.nstat:].copy_(sl.lens)
+                # [n_total | status0 | statuses | lens] in one launch, the sticky status words cleared for the next replay
+                ops.pack_status(sl.dev_stat, [sl.pts.n_dev, sl.status0, sl.status, sl.lens], clear=sl.status)
         sl.keep = pw.kept          # scratch buffers referenced by the graph
         assert sl.lens.numel() == sl.nl and 1 + 2 + 2 * sl.status.shape[0] == sl.nstat
         sl.done = torch.cuda.Event()

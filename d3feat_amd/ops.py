@@ -231,6 +231,23 @@ def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0, e
     return sub_p, sub_l, status
 
 
+def pack_status(dst, blocks, clear=None):
+    """dst i32[>= sum of the blocks' sizes] <- the (up to four) device int32 blocks one after the other, then `clear` (a device
+    int32 tensor, may be one of the blocks) zeroed: one launch (d3f_pack_status) instead of a copy node per block and a fill."""
+    lib = _lib.load()
+    blocks = [b.reshape(-1) for b in blocks]
+    assert 1 <= len(blocks) <= 4 and all(b.dtype == torch.int32 and b.is_contiguous() for b in blocks) and dst.dtype == torch.int32
+    assert dst.numel() >= sum(b.numel() for b in blocks)
+    args = []
+    for i in range(4):
+        args += [blocks[i].data_ptr(), blocks[i].numel()] if i < len(blocks) else [None, 0]
+    if clear is not None:
+        assert clear.dtype == torch.int32 and clear.is_contiguous()
+    _lib.check(lib.d3f_pack_status(dst.data_ptr(), *args, clear.data_ptr() if clear is not None else None,
+                                   clear.numel() if clear is not None else 0, _stream(dst.device)), "pack_status")
+    return dst
+
+
 def stack_self_pair(pts, lens=None):
     """np.concatenate([c, c]) for every cloud c of a stack whose row counts live on the device:
     pts f32[cap,3] holding B clouds (lens i32[B] on the device; default: one cloud of pts.n_dev rows)
