@@ -1007,10 +1007,17 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                 ("gemm_dma_kernel", "gemm_fast_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
             ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
                    and "traffic_bytes_per_launch" in v]
-            m = re.match(r"kpconv_fused_kernel<Cin=(\d+)>", name)     # template argument = lanes per query = Cin / 4
+            # families that are ONE template instance take that instance's counters, not the launch-weighted mean of all
+            # instances of the base name (r04: both nb_search variants and both kpconv_agg_vec4 widths reported one number)
+            m = re.match(r"(kpconv_fused_kernel|kpconv_agg_vec4)<Cin=(\d+)>", name)     # template argument = lanes per query = Cin / 4
+            prefix = None
             if m:
-                ent = [v for k, v in traffic.items() if isinstance(v, dict) and "traffic_bytes_per_launch" in v
-                       and k.startswith("kpconv_fused_kernel<%d," % (int(m.group(1)) // 4))]
+                prefix = "%s<%d," % (m.group(1), int(m.group(2)) // 4)
+            m = re.match(r"nb_search_kernel<first_only=(\d)>", name)
+            if m:
+                prefix = "nb_search_kernel<%s," % ("true" if m.group(1) == "1" else "false")
+            if prefix:
+                ent = [v for k, v in traffic.items() if isinstance(v, dict) and "traffic_bytes_per_launch" in v and k.startswith(prefix)]
             nl = sum(e["launches"] for e in ent)
             if nl:
                 # the counter run's launches held F_pmc fragments each, this pass's hold Fp: traffic scales with the rows

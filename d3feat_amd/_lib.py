@@ -23,7 +23,7 @@ _vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
 SIGNATURES = {
     "d3f_version": (_i, []),
     "d3f_trace_marker": (_i, [_i, _vp]),
-    "d3f_pack_status": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "d3f_pack_status": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "d3f_grid_subsample_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_batch_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_batch_grid_subsample_async": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -204,24 +204,26 @@ int d3f_bbox_launch(const float* pts, const int* offs, int B, int N, unsigned* b
 // two ends of its timed region, tools/rocpd_summary.py --timed-region keeps the launches between the first two of them (the
 // capture warm-ups, the calibration prologue and the untimed legs of a run stay out of the per-kernel table).
 // One launch at the end of a replay: the device-resident sizes and status words of the whole launch sequence packed into ONE
-// block (read back by one copy), and the sticky status words cleared for the next replay -- instead of four copy nodes and a fill
+// block (read back by one copy), and the sticky FLAG words (clear[clear_first + i * clear_step]; the size words beside them stay
+// readable after the replay) cleared for the next replay -- instead of four copy nodes and a fill
 // node per replay (r04: runtime copies and torch fills cost more kernel time than max pooling).
 __global__ void __launch_bounds__(256) d3f_pack_status_kernel(int* __restrict__ dst, const int* __restrict__ a, int na,
                                                               const int* __restrict__ b, int nb, const int* __restrict__ c, int nc,
-                                                              const int* __restrict__ d, int nd, int* __restrict__ clear, int nclear) {
+                                                              const int* __restrict__ d, int nd, int* __restrict__ clear, int nclear,
+                                                              int clear_first, int clear_step) {
     for (int i = threadIdx.x; i < na; i += blockDim.x) dst[i] = a[i];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) dst[na + i] = b[i];
     for (int i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c[i];
     for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[na + nb + nc + i] = d[i];
     __syncthreads();                    // (`clear` may be one of the sources)
-    for (int i = threadIdx.x; i < nclear; i += blockDim.x) clear[i] = 0;
+    for (int i = threadIdx.x; i < nclear; i += blockDim.x) clear[clear_first + i * clear_step] = 0;
 }
 extern "C" int d3f_pack_status(int* dst, const int* a, int na, const int* b, int nb, const int* c, int nc, const int* d, int nd,
-                               int* clear, int nclear, void* stream) {
+                               int* clear, int nclear, int clear_first, int clear_step, void* stream) {
     if (!dst || na < 0 || nb < 0 || nc < 0 || nd < 0 || nclear < 0 || (na && !a) || (nb && !b) || (nc && !c) || (nd && !d) ||
-        (nclear && !clear))
+        (nclear && (!clear || clear_first < 0 || clear_step < 1)))
         return D3F_ERR_ARG;
-    d3f_pack_status_kernel<<<1, 256, 0, (hipStream_t)stream>>>(dst, a, na, b, nb, c, nc, d, nd, clear, nclear);
+    d3f_pack_status_kernel<<<1, 256, 0, (hipStream_t)stream>>>(dst, a, na, b, nb, c, nc, d, nd, clear, nclear, clear_first, clear_step);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

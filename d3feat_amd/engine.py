@@ -173,7 +173,7 @@ class FragmentEngine:
             sl.raw_len.fill_(per)
             with ops.private_workspace():
                 _, _, _, w_status, w_lens = self._sequence(sl)
-            w_status.zero_()              # the searches' status words are sticky: the replay's last node clears them (pack_status)
+            w_status[:, 1].zero_()        # the searches' flag words are sticky: the replay's last node clears them (pack_status)
         sl.stream.synchronize()
         # one packed read-back per replay: [n_total, status0(2), status(k,2)..., lens(nb)]; the packing copies are nodes of
         # the graph (no host calls per replay), only the copy to the host follows the replay

@@ -232,8 +232,9 @@ def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0, e
 
 
 def pack_status(dst, blocks, clear=None):
-    """dst i32[>= sum of the blocks' sizes] <- the (up to four) device int32 blocks one after the other, then `clear` (a device
-    int32 tensor, may be one of the blocks) zeroed: one launch (d3f_pack_status) instead of a copy node per block and a fill."""
+    """dst i32[>= sum of the blocks' sizes] <- the (up to four) device int32 blocks one after the other, then the FLAG column of
+    `clear` (a device int32 [k, 2] tensor of [kmax-or-size | flags] pairs, may be one of the blocks) zeroed -- the size words stay
+    readable after the replay: one launch (d3f_pack_status) instead of a copy node per block and a fill."""
     lib = _lib.load()
     blocks = [b.reshape(-1) for b in blocks]
     assert 1 <= len(blocks) <= 4 and all(b.dtype == torch.int32 and b.is_contiguous() for b in blocks) and dst.dtype == torch.int32
@@ -242,9 +243,9 @@ def pack_status(dst, blocks, clear=None):
     for i in range(4):
         args += [blocks[i].data_ptr(), blocks[i].numel()] if i < len(blocks) else [None, 0]
     if clear is not None:
-        assert clear.dtype == torch.int32 and clear.is_contiguous()
+        assert clear.dtype == torch.int32 and clear.is_contiguous() and clear.dim() == 2 and clear.shape[1] == 2
     _lib.check(lib.d3f_pack_status(dst.data_ptr(), *args, clear.data_ptr() if clear is not None else None,
-                                   clear.numel() if clear is not None else 0, _stream(dst.device)), "pack_status")
+                                   clear.shape[0] if clear is not None else 0, 1, 2, _stream(dst.device)), "pack_status")
     return dst
 
 

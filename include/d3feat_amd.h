@@ -50,10 +50,11 @@ int d3f_version(void);
  * a kernel trace of a run can be cut at the ends of a timed region (bench.py; tools/rocpd_summary.py --timed-region). */
 int d3f_trace_marker(int id, void* stream);
 /* Capacity mode (no reference counterpart: the reference's ops return their sizes to the host one by one): packs up to four device
- * int blocks (sizes, status words, lens) into dst[0 .. na+nb+nc+nd) in ONE launch, then zeroes clear[0 .. nclear) -- the sticky status
- * words of the searches, ready for the next replay (`clear` may alias a source).  Any pointer whose count is 0 may be NULL. */
+ * int blocks (sizes, status words, lens) into dst[0 .. na+nb+nc+nd) in ONE launch, then zeroes the nclear words
+ * clear[clear_first + i * clear_step] -- the sticky flag words of the searches ([kmax | flags] pairs: first 1, step 2), ready for the
+ * next replay (`clear` may alias a source).  Any pointer whose count is 0 may be NULL. */
 int d3f_pack_status(int* dst, const int* a, int na, const int* b, int nb, const int* c, int nc, const int* d, int nd,
-                    int* clear, int nclear, void* stream);
+                    int* clear, int nclear, int clear_first, int clear_step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident sizes ("capacity mode").  The reference's ops have data-dependent output sizes, which costs a host
