@@ -17,7 +17,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 
 class GoldenNetwork:
     def __init__(self, name):
-        """name: '3dmatch' or 'kitti'."""
+        """name: '3dmatch', 'kitti', or '3dmatch_4k' (a 4000-point crop: row sums of EVERY row of every block, two blocks whole)."""
         self.name = name
         self.z = np.load(os.path.join(GOLDEN, "network_%s.npz" % name))
         ext = ()
@@ -41,6 +41,16 @@ class GoldenNetwork:
     def block(self, scope):
         """-> (rows, values[rows]) of the block's output as the reference computed it."""
         return self.z["rows/block/" + scope], self.z["block/" + scope]
+
+    def rowsum(self, scope):
+        """(the '3dmatch_4k' fixture) float64 [rows, 2]: per row of the block's output, (sum over channels, sum of magnitudes)."""
+        return self.z["rowsum/" + scope]
+
+    def whole_scopes(self):
+        return [k[len("whole/"):] for k in self.z.files if k.startswith("whole/")]
+
+    def whole(self, scope):
+        return self.z["whole/" + scope]
 
     def kpconv(self, scope):
         return self.z["rows/kpconv/" + scope], self.z["kpconv/" + scope]

@@ -80,6 +80,44 @@ def test_forward_equals_the_reference_python(device, name):
     assert checked >= 15
 
 
+def test_every_row_of_every_block_on_a_larger_crop(device):
+    """tests/golden/network_3dmatch_4k.npz (round 5): a 4000-point crop as a self-pair -- 8000 stacked rows, sixteen 256-thread
+    tiles per level-0 kernel instead of four -- with, for EVERY row of every block output, the reference's (sum over channels, sum
+    of magnitudes): an error that depends on the row (a tile edge, a shadow slot, the last workgroup) cannot hide behind the
+    sampled rows of the small fixtures.  Two blocks are kept whole, descriptors and scores too."""
+    from d3feat_amd.models.KPFCNN_model import KernelPointFCNN
+    g = GoldenNetwork("3dmatch_4k")
+    cfg = g.config()
+    got, restore = _record_blocks()
+    try:
+        model = KernelPointFCNN(_flat(g, device), cfg, weights=dict(g.W))
+    finally:
+        restore()
+    d, s = model.out_features.cpu().numpy(), model.out_scores.cpu().numpy()
+    assert d.shape == g.descriptors.shape == (8000, 32)
+    ed, es = np.abs(d - g.descriptors).max(), np.abs(s - g.scores).max()
+    assert ed <= TOL and es <= TOL, (ed, es)
+    checked = 0
+    for scope in g.block_order:
+        if scope not in got:
+            continue
+        have = got[scope].cpu().numpy().astype(np.float64)
+        want = g.rowsum(scope)
+        assert have.shape[0] == want.shape[0], scope
+        scale = max(1.0, float(want[:, 1].max()) / have.shape[1])          # the block's typical magnitude
+        # a row sum of C terms, each within 1e-4 of the block's scale in the worst case and ~1e-6 in practice
+        err = np.abs(have.sum(1) - want[:, 0]).max()
+        assert err <= TOL * scale * np.sqrt(have.shape[1]), (scope, err, scale)
+        assert np.abs(np.abs(have).sum(1) - want[:, 1]).max() <= TOL * scale * np.sqrt(have.shape[1]), scope
+        checked += 1
+    assert checked >= 15
+    for scope in g.whole_scopes():
+        want = g.whole(scope)
+        have = got[scope].cpu().numpy()
+        assert have.shape == want.shape and np.abs(have - want).max() <= TOL * max(1.0, float(np.abs(want).max())), scope
+    assert len(g.whole_scopes()) == 2
+
+
 @pytest.mark.parametrize("name", ["3dmatch", "kitti"])
 def test_every_kpconv_layer_equals_the_reference_python(device, name):
     """The 10 KPConv_ops calls of the reference's run, one by one through kernels.convolution_ops.KPConv_ops (every kernel form:

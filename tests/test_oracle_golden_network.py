@@ -39,6 +39,24 @@ def test_network_restatement_equals_the_reference_python(name):
     assert np.abs(score - g.scores).max() <= 1e-5 and np.abs(desc - g.descriptors).max() <= 1e-5
 
 
+def test_network_restatement_on_the_larger_crop_every_row():
+    """network_3dmatch_4k.npz: 8000 stacked rows, the row sums of EVERY row of every block, two blocks whole (round 5)."""
+    g = GoldenNetwork("3dmatch_4k")
+    trace = {}
+    desc, score = onp.forward(g.config(), g.W, g.inputs, trace=trace)
+    assert list(trace.keys()) == g.block_order
+    for scope in g.block_order:
+        have = trace[scope].numpy().astype(np.float64)
+        want = g.rowsum(scope)
+        scale = max(1.0, float(want[:, 1].max()) / have.shape[1])
+        assert np.abs(have.sum(1) - want[:, 0]).max() <= 2e-5 * scale * np.sqrt(have.shape[1]), scope
+        rows, w = g.block(scope)
+        _close(have[rows], w, scope)
+    for scope in g.whole_scopes():
+        _close(trace[scope].numpy(), g.whole(scope), scope)
+    assert np.abs(score - g.scores).max() <= 1e-5 and np.abs(desc - g.descriptors).max() <= 1e-5
+
+
 @pytest.mark.parametrize("name", ["3dmatch", "kitti"])
 def test_every_kpconv_layer_equals_the_reference_python(name):
     """Each of the 10 KPConv ops alone, fed the reference's own block inputs is not possible (inputs are not in the fixture), so

@@ -102,8 +102,10 @@ class Recorder:
                                 setattr(conv_ops, "KPConv_ops", orig_kp))
 
 
-def run_case(tf, mods, config, clouds, limits, external=None, tag=""):
-    """clouds: list of stage-0 clouds forming ONE stack (self-pair: [c, c])."""
+def run_case(tf, mods, config, clouds, limits, external=None, tag="", whole=(), rowsums=False, sample_rows=None):
+    """clouds: list of stage-0 clouds forming ONE stack (self-pair: [c, c]).  rowsums: additionally keep, for EVERY row of every block
+    output, (sum over channels, sum of magnitudes) in float64 -- 16 bytes per row instead of the row: a row-dependent error cannot hide
+    behind the sampled rows; whole: scopes whose output is kept whole."""
     from oracle import seeded_variables as sv
     conv_ops, network_blocks, d3feat, common = mods
     L = config.num_layers
@@ -171,9 +173,15 @@ def run_case(tf, mods, config, clouds, limits, external=None, tag=""):
     rrng = np.random.default_rng(SEED + 7)
     for pre, d in (("block/", rec.blocks), ("kpconv/", rec.kpconv)):
         for k, v in d.items():
-            rows = np.sort(rrng.choice(v.shape[0], size=min(v.shape[0], ROWS), replace=False)).astype(np.int32)
+            rows = np.sort(rrng.choice(v.shape[0], size=min(v.shape[0], sample_rows or ROWS), replace=False)).astype(np.int32)
             out[pre + k] = np.ascontiguousarray(v[rows])
             out["rows/" + pre + k] = rows
+    if rowsums:
+        for k, v in rec.blocks.items():
+            v64 = v.astype(np.float64)
+            out["rowsum/" + k] = np.stack([v64.sum(1), np.abs(v64).sum(1)], 1)
+    for k in whole:
+        out["whole/" + k] = np.ascontiguousarray(rec.blocks[k])
     out["block_order"] = np.asarray(json.dumps(list(rec.blocks.keys())))
     out["descriptors"] = np.asarray(desc, np.float32)
     out["scores"] = np.asarray(score, np.float32)
@@ -291,9 +299,16 @@ def main():
     o = run_ops(tf, mods, a)
     np.savez_compressed(os.path.join(OUT, "network_ops.npz"), **o)
 
+    # a larger crop (4000 points, 8000 stacked rows): every row of every block through its row sums, two blocks whole (round 5)
+    c4 = crop(bin0, 7000, 4000)
+    order = json.loads(str(a["block_order"]))
+    big = run_case(tf, mods, cfg, [c4, c4], [37, 35, 36, 38, 38], tag="3dmatch_4k", rowsums=True, whole=(order[3], order[7]),
+                   sample_rows=48)
+    np.savez_compressed(os.path.join(OUT, "network_3dmatch_4k.npz"), **big)
+
     man_p = os.path.join(OUT, "MANIFEST.json")
     man = json.load(open(man_p))
-    for fn in ("network_3dmatch.npz", "network_kitti.npz", "network_ops.npz"):
+    for fn in ("network_3dmatch.npz", "network_kitti.npz", "network_ops.npz", "network_3dmatch_4k.npz"):
         man["files"][fn] = hashlib.sha256(open(os.path.join(OUT, fn), "rb").read()).hexdigest()
         man.setdefault("generated_by_also", {})[fn] = "tools/make_golden_network.py"
         print("%-22s %.2f MB" % (fn, os.path.getsize(os.path.join(OUT, fn)) / 1e6))
