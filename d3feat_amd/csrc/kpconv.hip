@@ -467,7 +467,8 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
     const bool kp_lane = p < P.num_kp;
     const float qx = q[3 * (size_t)qi], qy = q[3 * (size_t)qi + 1], qz = q[3 * (size_t)qi + 2];
     const int* row = idx + (size_t)qi * ld_idx;
-    float acc = 0.f;       // lanes 0..14: sum_k h_p * f;  lane 15: number of neighbours with f > 0
+    float acc = 0.f;       // lanes 0..14: sum_k h_p * f  (lane 15 walks along with a kernel point of zeros; its sum is dropped)
+    float cnt = 0.f;       // number of neighbours with f > 0 (the same number in the 16 lanes of a query)
     const float sig = P.extent * 0.3f, gden = 2.0f * sig * sig + 1e-9f;
     // The 16 lanes of a query first act as LOADERS: lane p fetches neighbours p, p + 16, p + 32, p + 48 of the pass (index,
     // then position and feature, all four in flight) and parks (s - q, f) as one 16-byte record in LDS; then every lane walks
@@ -492,19 +493,19 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             px[j] = s[o3]; py[j] = s[o3 + 1]; pz[j] = s[o3 + 2];
             fv[j] = ok[j] ? f[(size_t)id[j] * ldf] : 0.f;
         }
-        unsigned long long valid = 0ull;                               // bit u: neighbour k0 + u of THIS query is real
+        // (round 5) the walk below has no branches: a slot that holds no neighbour carries f = 0 (its influence, computed from
+        // support 0's position, is finite in every mode and multiplies nothing), and the positive neighbours are counted HERE, by
+        // one ballot per loaded group, instead of by a sixteenth lane that took its own path through every iteration
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mynb[p + 16 * j] = make_float4(px[j] - qx, py[j] - qy, pz[j] - qz, fv[j]);
-            valid |= ((__ballot(ok[j]) >> gshift) & 0xFFFFull) << (16 * j);
+            cnt += (float)__popcll((__ballot(ok[j] && fv[j] > 0.f) >> gshift) & 0xFFFFull);
         }
         __syncthreads();
         const int kn = min(C1_SC, K - k0);
-#pragma unroll 4
+#pragma unroll 6
         for (int u = 0; u < kn; ++u) {
-            if (!((valid >> u) & 1ull)) continue;
             const float4 v = mynb[u];
-            if (p == 15) { acc += (v.w > 0.f) ? 1.f : 0.f; continue; }
             const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
             const float d2 = dx * dx + dy * dy + dz * dz;
             float h;
@@ -514,7 +515,7 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             acc = fmaf(h, v.w, acc);
         }
     }
-    sacc[ql][p] = (kp_lane || p == 15) ? acc : 0.f;
+    sacc[ql][p] = p == 15 ? cnt : (kp_lane ? acc : 0.f);
     __syncthreads();
     // contraction + epilogue: thread -> output channel o = tid % 64 (+64 per pass), queries tid/64 + 4*i
     for (int o0 = 0; o0 < Cout; o0 += 64) {
