@@ -1003,7 +1003,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
         # collected for different kernel sources than the ones running now.
         if traffic is not None:
             base = name.split("<")[0].split(" ")[0]
-            names = ("gemm_x3_kernel",) if name.startswith("gemm_x3") else \
+            names = ("gemm_x3_kernel", "gemm_x3r_kernel") if name.startswith("gemm_x3") else \
                 ("gemm_dma_kernel", "gemm_fast_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
             ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
                    and "traffic_bytes_per_launch" in v]

@@ -21,6 +21,8 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -937,6 +939,17 @@ static GemmX3Plan gemm_x3_plan(int M, int N, int K, int M_hint) {
     if (M_hint > 0 && M_hint < M) M = M_hint;
     const int nt = K / GX_BK;
     GemmX3Plan p;
+    // measurement aid: D3F_X3_PLAN="tn,waves,S" forces the workgroup shape (1,4 / 2,4 / 4,8) and the K slice count of EVERY call
+    static const char* forced = getenv("D3F_X3_PLAN");
+    if (forced) {
+        int tn = 0, wv = 0, S = 0;
+        if (sscanf(forced, "%d,%d,%d", &tn, &wv, &S) == 3 && ((tn == 1 && wv == 4) || (tn == 2 && wv == 4) || (tn == 4 && wv == 8)) && S >= 1) {
+            p.tn = tn; p.waves = wv; p.S = S < nt ? S : nt;
+            p.tps = d3f_cdiv(nt, p.S);
+            p.S = d3f_cdiv(nt, p.tps);
+            return p;
+        }
+    }
     p.tn = N <= 32 ? 1 : 2;
     p.waves = 4;
     const long long c_small = gemm_x3_cost((long long)d3f_cdiv(M, 128) * d3f_cdiv(N, 32 * p.tn), 512, nt, 100, p.S);
@@ -998,6 +1011,34 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
     if (!A || !Wx || !C || (C2 > 0 && !skip) ||
         (((uintptr_t)A | (uintptr_t)Wx | (uintptr_t)C | (uintptr_t)skip | (uintptr_t)residual | (uintptr_t)col_scale | (uintptr_t)col_shift) & 15))
         return D3F_ERR_ARG;
+    GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
+    GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
+    const int nkt = K / GX_BK, NG = d3f_cdiv(N, 32);
+    {   // ---- the resident-W persistent form: tall contractions whose whole pre-split W fits the LDS of a CU (gemm_x3.h) ----
+        static const bool on = []() { const char* e = getenv("D3F_GEMM_X3R"); return !(e && e[0] == '0'); }();
+        const int m_eff = (M_hint > 0 && M_hint < M) ? M_hint : M;
+        const size_t wbytes = (size_t)nkt * NG * GX_CHUNK * sizeof(unsigned short);
+        if (on && (NG == 1 || NG == 2 || NG == 4) && wbytes <= 128 * 1024 && m_eff >= 65536) {
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                hipDeviceProp_t pr;
+                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return D3F_ERR_HIP;
+                cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+            }
+            static std::atomic<unsigned long long> lds_done{0};
+            const void* const fns[3] = {(const void*)gemm_x3r_kernel<1>, (const void*)gemm_x3r_kernel<2>, (const void*)gemm_x3r_kernel<4>};
+            if (d3f_opt_in_lds(lds_done, fns, 128 * 1024) != D3F_OK) return D3F_ERR_HIP;
+            const int grid = std::min(cus, d3f_cdiv(d3f_cdiv(M, 32), 8));
+#define D3F_GXR(TN_) gemm_x3r_kernel<TN_><<<grid, 512, wbytes, stream>>>(A, lda, (const unsigned short*)Wx, nkt, C, ldc, M, N, E, M_dev, G)
+            if (NG == 4) D3F_GXR(4);
+            else if (NG == 2) D3F_GXR(2);
+            else D3F_GXR(1);
+#undef D3F_GXR
+            D3F_LAUNCH_CHECK();
+            return D3F_OK;
+        }
+    }
     const GemmX3Plan pl = gemm_x3_plan(M, N, K, M_hint);
     const int S = pl.S, tps = pl.tps, bm = 32 * pl.waves;
     float* slab = nullptr;
@@ -1006,9 +1047,6 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
         slab = (float*)workspace;
     }
     if (d3f_cdiv(M, bm) > 65535) return D3F_ERR_ARG;
-    GemmEpi E{row_scale, col_scale, col_shift, residual, ldr, leaky, alpha};
-    GemmGather G{idx, ld_idx, N1, N1_dev, C2 > 0 ? skip : nullptr, lds, C1};
-    const int nkt = K / GX_BK, NG = d3f_cdiv(N, 32);
     dim3 grid(d3f_cdiv(N, 32 * pl.tn), S, d3f_cdiv(M, bm));
 #define D3F_GX(TN_, WV_) gemm_x3_kernel<TN_, WV_><<<grid, 64 * WV_, 0, stream>>>(A, lda, (const unsigned short*)Wx, nkt, NG, C, ldc, M, N, tps, slab, E, M_dev, G)
     if (pl.waves == 8) D3F_GX(4, 8);

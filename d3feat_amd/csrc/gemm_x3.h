@@ -346,3 +346,203 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
         }
     }
 }
+
+// =====================================================================================================================
+// Resident-W, persistent form (round 5) for the tall contractions of the fine levels: M of 10^5 .. 10^6 rows, K <= 256, N <= 128.
+// There the tile kernel above is all fixed cost: a 256 x 128 workgroup lives for 3 - 8 k-tiles, and with NO memory traffic at all
+// (A rows aliased to the zero line, no stores) M = 707592, K = 96, N = 128 still takes 118 us of the 238 -- 2764 workgroups, one at
+// a time per CU, each launching, staging its W slices through the ring, synchronising per k-tile and draining
+// (profiles/r05_experiments.txt g1).  Here the whole pre-split W ([k-tile][column group][plane][32][40] bf16, <= 120 KB) is staged
+// in LDS ONCE per CU and read in place; one 8-wave workgroup per CU; every WAVEFRONT walks its own sequence of 32-row tiles
+// (tile = wave * gridDim.x + block, stride 8 gridDim.x: the chip's waves share the rows evenly at any M) with the same register
+// pipeline as above (A floats straight from global memory in operand layout, three register sets, the splitting of k-tile t + 1 in
+// the shadow of the MFMAs of k-tile t) -- and NO barrier after the staging: waves run out of phase and cover each other's
+// latencies.  Per tile one full drain (the tile's first floats and the previous tile's stores together), counted waits inside.
+template <int TN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wx, int nkt, float* __restrict__ C, int ldc,
+                int M, int N, GemmEpi E, const int* __restrict__ M_dev, GemmGather G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gxr_w[];      // [nkt][TN] chunks of GX_CHUNK bf16
+    static_assert(TN == 1 || TN == 2 || TN == 4, "column groups per row tile");
+    M = d3f_dyn(M, M_dev);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // ---- W: chunk (column group j, k-tile kt) of the packed copy -> chunk (kt, j) of the LDS image ----
+        const int total = nkt * TN * 480;
+        const uint4* src = (const uint4*)Wx;
+        uint4* dst = (uint4*)gxr_w;
+        for (int e = tid; e < total; e += 512) {
+            const int c = e / 480, o = e - 480 * c;
+            const int kt = c / TN, j = c - kt * TN;
+            dst[e] = src[(size_t)(j * nkt + kt) * 480 + o];
+        }
+    }
+    __syncthreads();
+    const int ntiles = (M + 31) >> 5;
+    const int kofs = (lane >> 5) << 3;
+    const int K1 = G.K1;
+    const int n1 = G.gidx ? d3f_dyn(G.N1, G.N1_dev) : 0;
+    const int tstride = 8 * (int)gridDim.x;
+    const int rt0 = wave * (int)gridDim.x + (int)blockIdx.x;       // this wave's tiles: rt0, rt0 + tstride, ...
+    if (rt0 >= ntiles) return;                                      // (after the workgroup's only barrier)
+    const int ntl = (ntiles - rt0 + tstride - 1) / tstride;
+    const int total = ntl * nkt;                                    // (tile, k-tile) pairs of this wave, walked as ONE stream
+    // ---- request side: the rows of the tile whose floats are requested next (up to three k-tiles ahead of the multiplies, across
+    // tile boundaries: a wave always has its next 12 KB on the way); a row that does not exist (beyond M, shadow / out-of-range
+    // index) is the zero line, read at offset 0 whatever the k-tile ----
+    int rq_tile = rt0, rq_kt = 0;
+    const float* arow;
+    const float* a2row;
+    unsigned amask, a2mask;
+    const float* pa;
+    unsigned astep;
+    auto a_rebase = [&](int t) {
+        const bool first = t * GX_BK < K1;                 // (wave-uniform)
+        const unsigned msk = first ? amask : a2mask;
+        pa = (first ? arow : a2row) + ((unsigned)((first ? t * GX_BK : t * GX_BK - K1) + kofs) & msk);
+        astep = (unsigned)GX_BK & msk;
+    };
+    auto rq_rows = [&](int rt) {
+        const int gm = rt * 32 + (lane & 31);
+        arow = gd_zero_line; a2row = gd_zero_line; amask = 0u; a2mask = 0u;
+        if (rt < ntiles && gm < M) {
+            int sr = gm;
+            if (G.gidx) {
+                sr = G.gidx[(size_t)gm * G.ld_gidx];
+                if (sr < 0 || sr >= n1) sr = -1;
+            }
+            if (sr >= 0) { arow = A + (size_t)sr * lda; amask = 0xffffffffu; }
+            if (G.A2) { a2row = G.A2 + (size_t)gm * G.lda2; a2mask = 0xffffffffu; }
+        }
+        a_rebase(0);
+    };
+    rq_rows(rq_tile);
+    gx_f4 rA0, rA1, rA2, rA3, rB0, rB1, rB2, rB3, rC0, rC1, rC2, rC3;
+    uint4 ap0[2][3], ap1[2][3];
+    auto request_a = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
+        gx_ld16(r0, pa);
+        gx_ld16o<16>(r1, pa);
+        gx_ld16o<64>(r2, pa);
+        gx_ld16o<80>(r3, pa);
+        // advance to the next (tile, k-tile) pair; past this wave's last tile: the zero line (rq_rows), nobody consumes it
+        if (++rq_kt == nkt) {                                  // (wave-uniform)
+            rq_kt = 0;
+            rq_tile += tstride;
+            rq_rows(rq_tile);
+        } else if (rq_kt * GX_BK == K1) a_rebase(rq_kt);
+        else pa += astep;
+    };
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // one k-tile: the 12 TN MFMAs of k-tile kt on planes `cur`, the splitting of the NEXT pair's floats in their shadow (the
+    // micro-operation list of gemm_x3_kernel::tile), W fragments read from the resident image
+    auto tile = [&](int kt, const uint4 (&cur)[2][3], uint4 (&nxt)[2][3], const gx_f4& r0, const gx_f4& r1, const gx_f4& r2,
+                    const gx_f4& r3) {
+        const unsigned short* bp = (const unsigned short*)gxr_w + (size_t)kt * (TN * GX_CHUNK) + (lane & 31) * GX_LS + kofs;
+        constexpr int NM = 12 * TN, NOPS = 88;
+        constexpr int PA[2][6] = {{2, 1, 0, 1, 0, 0}, {0, 1, 0, 2, 1, 0}}, PB[2][6] = {{0, 1, 2, 0, 1, 0}, {2, 1, 1, 0, 0, 0}};
+        uint4 b[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[j][p] = *(const uint4*)(bp + j * GX_CHUNK + p * (32 * GX_LS));
+        float x[16] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], r2[0], r2[1], r2[2], r2[3], r3[0], r3[1], r3[2], r3[3]};
+        float hl[16];
+        unsigned P[3][8];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int s = m / (6 * TN), prod = (m % (6 * TN)) / TN, j = m % TN;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, b[j][PB[s][prod]]),
+                                                             __builtin_bit_cast(gb_bf16x8, cur[s][PA[s][prod]]), acc[j], 0, 0, 0);
+            if (s == 0 && (prod == 2 || prod >= 4)) {
+                const int p = prod == 2 ? 2 : prod == 4 ? 1 : 0;
+                b[j][p] = *(const uint4*)(bp + j * GX_CHUNK + p * (32 * GX_LS) + 16);
+            }
+#pragma unroll
+            for (int k = m * NOPS / NM; k < (m + 1) * NOPS / NM; ++k) {
+                const int lvl = k < 8 ? 0 : k < 24 ? 1 : k < 40 ? 2 : k < 48 ? 3 : k < 64 ? 4 : k < 80 ? 5 : 6;
+                if (lvl == 0) P[0][k] = gx_cvt_pk(x[2 * k], x[2 * k + 1]);
+                else if (lvl == 3) P[1][k - 40] = gx_cvt_pk(x[2 * (k - 40)], x[2 * (k - 40) + 1]);
+                else if (lvl == 6) P[2][k - 80] = gx_cvt_pk(x[2 * (k - 80)], x[2 * (k - 80) + 1]);
+                else if (lvl == 1 || lvl == 4) {
+                    const int e = k - (lvl == 1 ? 8 : 48);
+                    const unsigned pk = P[lvl == 1 ? 0 : 1][e >> 1];
+                    hl[e] = __uint_as_float((e & 1) ? (pk & 0xffff0000u) : (pk << 16));
+                } else {
+                    const int e = k - (lvl == 2 ? 24 : 64);
+                    x[e] = gx_sub(x[e], hl[e]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) nxt[s][p] = make_uint4(P[p][4 * s], P[p][4 * s + 1], P[p][4 * s + 2], P[p][4 * s + 3]);
+    };
+    // ---- the finished tile of the compute side: epilogue and stores (D[i][jm] as in gemm_x3_kernel), accumulators cleared ----
+    int c_tile = rt0, c_kt = 0;
+    auto finish_tile = [&]() {
+        const int gm_a = c_tile * 32 + (lane & 31);
+        const bool mok = gm_a < M;
+        float rs = 1.f;
+        if (E.row_scale && mok) rs = E.row_scale[gm_a];
+        float* dst = C + (size_t)(mok ? gm_a : 0) * ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = 32 * j + 8 * q + 4 * (lane >> 5);
+                if (mok && gn < N) {
+                    float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                    const float4 c4 = E.col_scale ? *(const float4*)&E.col_scale[gn] : make_float4(1.f, 1.f, 1.f, 1.f);
+                    const float4 h4 = E.col_shift ? *(const float4*)&E.col_shift[gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 r4 = E.residual ? *(const float4*)&E.residual[(size_t)gm_a * E.ldr + gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float c[4] = {c4.x, c4.y, c4.z, c4.w}, h[4] = {h4.x, h4.y, h4.z, h4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float tt = (v[e] * rs) * c[e] + h[e];
+                        tt += rr[e];
+                        v[e] = (E.leaky && !(tt > 0.f)) ? tt * E.alpha : tt;
+                    }
+                    *(float4*)&dst[gn] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                acc[j][4 * q] = acc[j][4 * q + 1] = acc[j][4 * q + 2] = acc[j][4 * q + 3] = 0.f;
+            }
+        }
+        c_tile += tstride;
+    };
+    // everything but the newest request (four loads) has retired.  Loads retire in order among themselves, so "at most four
+    // operations outstanding" means every load older than the newest four has landed whatever stores are in flight beside them (a
+    // store still in flight only makes the wait longer: the tile's first wait after its epilogue also waits for those stores).
+    auto landed = [&](gx_f4& r0, gx_f4& r1, gx_f4& r2, gx_f4& r3) {
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+    };
+    request_a(rA0, rA1, rA2, rA3);
+    request_a(rB0, rB1, rB2, rB3);
+    request_a(rC0, rC1, rC2, rC3);
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(rA0), "+v"(rA1), "+v"(rA2), "+v"(rA3) : : "memory");
+    gx_split8(rA0, rA1, ap0[0]);
+    gx_split8(rA2, rA3, ap0[1]);
+#define GXR_STEP(I_, CUR_, NXT_, C0_, C1_, C2_, C3_, Q0_, Q1_, Q2_, Q3_)                                                         \
+    if (it + I_ < total) {                                                                                                     \
+        landed(C0_, C1_, C2_, C3_);                                                                                            \
+        request_a(Q0_, Q1_, Q2_, Q3_);                                                                                         \
+        tile(c_kt, CUR_, NXT_, C0_, C1_, C2_, C3_);                                                                            \
+        if (++c_kt == nkt) { c_kt = 0; finish_tile(); }                                                                        \
+    }
+    for (int it = 0; it < total; it += 6) {
+        GXR_STEP(0, ap0, ap1, rB0, rB1, rB2, rB3, rA0, rA1, rA2, rA3)
+        GXR_STEP(1, ap1, ap0, rC0, rC1, rC2, rC3, rB0, rB1, rB2, rB3)
+        GXR_STEP(2, ap0, ap1, rA0, rA1, rA2, rA3, rC0, rC1, rC2, rC3)
+        GXR_STEP(3, ap1, ap0, rB0, rB1, rB2, rB3, rA0, rA1, rA2, rA3)
+        GXR_STEP(4, ap0, ap1, rC0, rC1, rC2, rC3, rB0, rB1, rB2, rB3)
+        GXR_STEP(5, ap1, ap0, rA0, rA1, rA2, rA3, rC0, rC1, rC2, rC3)
+    }
+#undef GXR_STEP
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rA0), "+v"(rA1), "+v"(rA2), "+v"(rA3), "+v"(rB0), "+v"(rB1), "+v"(rB2), "+v"(rB3), "+v"(rC0),
+                 "+v"(rC1), "+v"(rC2), "+v"(rC3) : : "memory");
+}

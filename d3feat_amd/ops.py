@@ -494,10 +494,17 @@ def packed_x3_weights(W):
     return _packed_on_tensor(W, "_d3f_x3", make)
 
 
-def _x3_ok(C1, C2, N):
-    """d3f_gemm_x3 can address the call (K and a concatenation's first part multiples of 32) and is the faster kernel for it: the
-    32-column layers (level-0 unary blocks, memory bound) stay on the fp32 MFMA kernel (70.9 against 83.6 us at M = 707592, K = 64)."""
-    return GEMM_X3 and N > 32 and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0)
+X3R_MIN_ROWS = 65536     # d3f_gemm_x3 takes its resident-W persistent form from this many (expected) rows on (csrc/gemm_f32.hip)
+X3_N32 = os.environ.get("D3F_X3_N32", "1") != "0"      # the 32-column layers on that form too (D3F_X3_N32=0: the fp32 MFMA kernel)
+
+
+def _x3_ok(C1, C2, N, rows=0):
+    """d3f_gemm_x3 can address the call (K and a concatenation's first part multiples of 32) and is the faster kernel for it.  The
+    32-column layers (level-0 unary blocks, memory bound) are slower on its tile form than on the fp32 MFMA kernel (70.9 against
+    83.6 us at M = 707592, K = 64: r04 x6) but faster on the resident-W persistent form of round 5, which the library takes for
+    `rows` >= X3R_MIN_ROWS (70.6 / 105.8 us against 72-82 / 118.6 at M = 707592, 23 / 31 against 28 / 39 at M = 235864: r05 g3)."""
+    wide = N > 32 or (X3_N32 and rows >= X3R_MIN_ROWS and os.environ.get("D3F_GEMM_X3R", "1") != "0")
+    return GEMM_X3 and wide and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0)
 
 
 X3_MAX_ROWS = 65535 * 128      # d3f_gemm_x3's grid holds 65535 row tiles of (at least) 128 rows; beyond: the fp32 kernel
@@ -520,7 +527,7 @@ def _f32t_ok(N, ldc, out, residual, ldr, vectors, *operands):
 def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, row_scale, col_scale, col_shift, residual, ldr, leaky,
                alpha, m_dev, n1_dev, hint, dev):
     lib = _lib.load()
-    if _x3_ok(C1, C2, N) and M <= X3_MAX_ROWS:
+    if _x3_ok(C1, C2, N, hint if 0 < hint < M else M) and M <= X3_MAX_ROWS:
         Wx = packed_x3_weights(W)
         ws = workspace(lib.d3f_gemm_x3_workspace_bytes(M, N, C1 + C2, hint), dev)
         with _timed("gemm_x3", dict(M=M, N=N, K=C1 + C2), dev):

@@ -42,7 +42,8 @@ def test_x3_is_the_default_contraction(monkeypatch):
     monkeypatch.undo()
     from d3feat_amd import ops
     assert ops.GEMM_X3 and ops._x3_ok(64, 0, 64) and ops._x3_ok(128, 64, 128) and not ops._x3_ok(48, 0, 64) and not ops._x3_ok(16, 48, 64)
-    assert not ops._x3_ok(64, 0, 32)        # 32-column layers: the fp32 MFMA kernel is the faster one
+    assert not ops._x3_ok(64, 0, 32)        # 32-column layers: the fp32 MFMA kernel is the faster one ...
+    assert ops._x3_ok(64, 0, 32, 100000)    # ... below the row count of the resident-W persistent form
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 64), (333, 96, 32), (4100, 128, 100), (130, 2048, 36)])
@@ -131,6 +132,7 @@ def test_error_against_float64_beside_the_fp32_mfma_kernel(device, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N,real", [(777, 64, 36, 0), (4097, 128, 100, 0), (260, 4096, 128, 0), (70001, 96, 128, 0),
+                                        (140000, 256, 64, 0), (100003, 64, 32, 0), (131072, 32, 128, 66000), (90000, 128, 20, 0),
                                         (9000, 512, 128, 6100), (1580, 7680, 512, 1200), (5, 32, 4, 0), (20001, 1024, 200, 0),
                                         (33000, 512, 256, 24000)])
 def test_same_operator_every_epilogue_ragged_shapes_row_counts(device, M, K, N, real):
@@ -167,10 +169,12 @@ def test_same_operator_every_epilogue_ragged_shapes_row_counts(device, M, K, N, 
 
 
 @pytest.mark.parametrize("C1,C2,N,m", [(128, 64, 64, 2500), (1024, 2048, 512, 2500), (64, 0, 32, 2500), (32, 32, 128, 2500),
-                                       (128, 128, 256, 30000)])
+                                       (128, 128, 256, 30000), (32, 64, 128, 70001), (128, 0, 64, 66000), (64, 0, 32, 90003),
+                                       (32, 32, 32, 70000)])
 def test_gathered_and_concatenated_operands(device, C1, C2, N, m):
     """[ x'[idx[m, 0]] | skip[m] ] @ W: shadow / out-of-range indices read the zero row; the same bits as the materialised operand.
-    (The last case runs as 256 x 128 workgroups.)"""
+    (The fifth case runs as 256 x 128 workgroups; the cases of >= 65536 rows take the resident-W persistent form of round 5 --
+    gathered rows, a concatenation boundary inside the walk, 128 / 64 / 32 columns, a ragged last tile.)"""
     from d3feat_amd import ops
     rng = np.random.default_rng(C1 + C2 + N)
     n1 = 700

@@ -68,7 +68,14 @@ def main():
         B = torch.randn(K, N, device=dev)
         fl = 2.0 * M * K * N
         us = time_one(A, B)
-        line = "M=%6d K=%5d N=%5d  plan %7.1f us %6.1f TF" % (M, K, N, us, fl / us / 1e6)
+        import ctypes
+        from d3feat_amd import _lib
+        r, c, sl = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        plan = ""
+        if K % 32 == 0 and N > 32 and _lib.load().d3f_gemm_x3_plan(M, N, K, 0, ctypes.byref(r), ctypes.byref(c), ctypes.byref(sl)) == 0:
+            plan = "x3 %dx%d S=%d" % (r.value, c.value, sl.value)
+        gb = 4.0 * M * (K + N) / us / 1e3
+        line = "M=%6d K=%5d N=%5d  %-14s %7.1f us %6.1f TF %6.0f GB/s(A+C)" % (M, K, N, plan, us, fl / us / 1e6, gb)
         print(line, flush=True)
         tot_us += us
         tot_fl += fl
