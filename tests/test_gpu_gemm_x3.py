@@ -35,7 +35,7 @@ class _fp32_mfma:
 def _x3_for_every_width(monkeypatch):
     """The host keeps 32-column layers on the fp32 MFMA kernel (faster there); this module exercises d3f_gemm_x3 at every width."""
     from d3feat_amd import ops
-    monkeypatch.setattr(ops, "_x3_ok", lambda C1, C2, N: ops.GEMM_X3 and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0))
+    monkeypatch.setattr(ops, "_x3_ok", lambda C1, C2, N, rows=0: ops.GEMM_X3 and (C1 + C2) % 32 == 0 and (C2 == 0 or C1 % 32 == 0))
 
 
 def test_x3_is_the_default_contraction(monkeypatch):
