@@ -358,6 +358,8 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
 // pipeline as above (A floats straight from global memory in operand layout, three register sets, the splitting of k-tile t + 1 in
 // the shadow of the MFMAs of k-tile t) -- and NO barrier after the staging: waves run out of phase and cover each other's
 // latencies.  Per tile one full drain (the tile's first floats and the previous tile's stores together), counted waits inside.
+#define GXR_PS 36                       // floats per row of a wave's output patch (32 + 4: the b128 accesses of a row group on distinct banks)
+#define GXR_PATCH_BYTES (8 * 32 * GXR_PS * 4)
 template <int TN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wx, int nkt, float* __restrict__ C, int ldc,
@@ -485,19 +487,24 @@ gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __re
     };
     // ---- the finished tile of the compute side: epilogue and stores (D[i][jm] as in gemm_x3_kernel), accumulators cleared ----
     int c_tile = rt0, c_kt = 0;
+    // Stores: in the accumulator layout a lane holds four consecutive columns of ITS row -- 16 bytes into each of 64 different
+    // places per wave instruction, 22 M sixteen-byte write requests for the 362 MB of a level-0 layer (the stores alone cost 68 of
+    // that layer's 238 us: g1).  The finished values of one 32-column group therefore go through a 32 x 36-float patch of LDS that
+    // belongs to the wave (no barrier: a wave's LDS operations keep their order) and leave as FULL 128-byte lines: lane l writes
+    // 16 bytes of row l / 8 + 8 i, eight lanes per row.
+    float* patch = (float*)(gxr_w + (size_t)nkt * TN * (GX_CHUNK * 2)) + wave * (32 * GXR_PS);
     auto finish_tile = [&]() {
         const int gm_a = c_tile * 32 + (lane & 31);
         const bool mok = gm_a < M;
         float rs = 1.f;
         if (E.row_scale && mok) rs = E.row_scale[gm_a];
-        float* dst = C + (size_t)(mok ? gm_a : 0) * ldc;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gn = 32 * j + 8 * q + 4 * (lane >> 5);
+                float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
                 if (mok && gn < N) {
-                    float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
                     const float4 c4 = E.col_scale ? *(const float4*)&E.col_scale[gn] : make_float4(1.f, 1.f, 1.f, 1.f);
                     const float4 h4 = E.col_shift ? *(const float4*)&E.col_shift[gn] : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float4 r4 = E.residual ? *(const float4*)&E.residual[(size_t)gm_a * E.ldr + gn] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -508,10 +515,22 @@ gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __re
                         tt += rr[e];
                         v[e] = (E.leaky && !(tt > 0.f)) ? tt * E.alpha : tt;
                     }
-                    *(float4*)&dst[gn] = make_float4(v[0], v[1], v[2], v[3]);
                 }
+                *(float4*)&patch[(lane & 31) * GXR_PS + 8 * q + 4 * (lane >> 5)] = make_float4(v[0], v[1], v[2], v[3]);
                 acc[j][4 * q] = acc[j][4 * q + 1] = acc[j][4 * q + 2] = acc[j][4 * q + 3] = 0.f;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cc = 32 * j + 4 * (lane & 7);                  // this lane's four columns of the group
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (lane >> 3) + 8 * i;
+                const float4 o = *(const float4*)&patch[r * GXR_PS + 4 * (lane & 7)];
+                const int gm = c_tile * 32 + r;
+                if (gm < M && cc < N) *(float4*)&C[(size_t)gm * ldc + cc] = o;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                         // (the patch is rewritten by the next column group)
         }
         c_tile += tstride;
     };
