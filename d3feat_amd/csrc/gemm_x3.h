@@ -323,8 +323,46 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
     float rs = 1.f;
     if (!slab && E.row_scale && mok) rs = E.row_scale[gm_a];
     float* dst = slab ? slab + ((size_t)by * Mcap + (mok ? gm_a : 0)) * N : C + (size_t)(mok ? gm_a : 0) * ldc;
+    // (round 5) final results leave as full 128-byte lines through a 32 x 36-float patch of the (now free) ring that belongs to the
+    // wave, as in gemm_x3r_kernel::finish_tile: sixteen bytes per lane into 64 different places per store instruction were a
+    // request-rate problem next to the loads (r05 g1); K slices still go to their slab directly
+    static_assert(3 * SB >= WAVES * 32 * 36 * 4, "the output patches must fit the ring");
+    float* patch = (float*)Bs + wave * (32 * 36);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+        if (!slab) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + 32 * j + 8 * q + 4 * (lane >> 5);
+                float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                if (mok && gn < N) {
+                    const float4 c4 = E.col_scale ? *(const float4*)&E.col_scale[gn] : make_float4(1.f, 1.f, 1.f, 1.f);
+                    const float4 h4 = E.col_shift ? *(const float4*)&E.col_shift[gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 r4 = E.residual ? *(const float4*)&E.residual[(size_t)gm_a * E.ldr + gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float c[4] = {c4.x, c4.y, c4.z, c4.w}, h[4] = {h4.x, h4.y, h4.z, h4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = (v[e] * rs) * c[e] + h[e];
+                        t += rr[e];
+                        v[e] = (E.leaky && !(t > 0.f)) ? t * E.alpha : t;
+                    }
+                }
+                *(float4*)&patch[(lane & 31) * 36 + 8 * q + 4 * (lane >> 5)] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cc = n0 + 32 * j + 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (lane >> 3) + 8 * i;
+                const float4 o = *(const float4*)&patch[r * 36 + 4 * (lane & 7)];
+                const int gm = m0 + 32 * wave + r;
+                if (gm < M && cc < N) *(float4*)&C[(size_t)gm * ldc + cc] = o;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int gn = n0 + 32 * j + 8 * q + 4 * (lane >> 5);
