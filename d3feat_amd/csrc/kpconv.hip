@@ -787,11 +787,7 @@ __device__ __forceinline__ void kf32_contract_epilogue_x3(Acc& acc, int tid, int
     }
 }
 
-// DB (round 5): the influences of chunk j + 1 are computed (phase A) in the SAME barrier interval as the gathers and FMAs of chunk j
-// (phase B), into the other of two LDS buffers: one barrier per chunk instead of two, and a wave's influence arithmetic fills the
-// time its own feature gathers are in flight.
-#define KF_REGION (2 * KF_TQ * KF_WS > KF_TQ * KF_TS ? 2 * KF_TQ * KF_WS : KF_TQ * KF_TS)   // floats: two influence buffers / the tile
-template <bool FAST, int PF = 8, class FT = float, bool X3 = false, bool DB = false>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
+template <bool FAST, int PF = 8, class FT = float, bool X3 = false>   // PF: feature rows requested before any is consumed (4: 128 registers, four workgroups per CU)
 __global__ void __launch_bounds__(256, PF == 4 ? 4 : 3)
 kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
                       int ld_idx, int K, const FT* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
@@ -808,8 +804,8 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     extern __shared__ __attribute__((aligned(16))) float kf_smem[];
     float* wft = kf_smem;
     float* lw = kf_smem;
-    int* lidx = (int*)(kf_smem + KF_REGION);                // [2][32][8]
-    int* lcnt = lidx + 2 * KF_TQ * KF_LQ;                   // [32]
+    int* lidx = (int*)(kf_smem + KF_TQ * KF_TS);            // [32][8]
+    int* lcnt = lidx + KF_TQ * KF_LQ;                       // [32]
     int* lq = lcnt + KF_TQ;                                 // [32] global query index of each tile row
     const int tid = threadIdx.x;
     const int ql = tid / KF_LQ, cl = tid % KF_LQ;
@@ -825,55 +821,6 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
     const int* idrow = idx + (qslot < Nq ? __umul24((unsigned)qg, (unsigned)ld_idx) : 0u);   // (rows, leading dimensions < 2^24)
     KpPair pr = kp_pair_fetch(kp_pair_index(idrow, qslot < Nq, cl, K, Ns), Ns, s, rowpos);  // chunk 0's pair
     __syncthreads();
-    if constexpr (DB) {
-        // phase A of one chunk: thread = (query ql, neighbour cl of the chunk) -> influences and index into buffer b
-        auto phase_a = [&](const KpPair& pp, int b) {
-            float w[KP_MAXP];
-            const bool positive = kp_pair_influences<FAST>(P, pp, qx, qy, qz, w);
-            kp_count_positive<KF_LQ>(positive, ql, cl, lcnt);
-            lidx[b * (KF_TQ * KF_LQ) + ql * KF_LQ + cl] = pp.id;
-            kp_store_w(&lw[b * (KF_TQ * KF_WS) + ql * KF_WS + cl * 16], cl, w);
-        };
-        const int id1 = kp_pair_index(idrow, qslot < Nq, KF_LQ + cl, K, Ns);
-        phase_a(pr, 0);                                                       // chunk 0
-        pr = kp_pair_fetch(id1, Ns, s, rowpos);                               // chunk 1's pair
-        __syncthreads();
-        int b = 0;
-        for (int k0 = 0; k0 < K; k0 += KF_LQ, b ^= 1) {
-            const int id_next = kp_pair_index(idrow, qslot < Nq, k0 + 2 * KF_LQ + cl, K, Ns);   // chunk j + 2's index
-            const float* lwb = lw + b * (KF_TQ * KF_WS) + ql * KF_WS;
-            const int* lib = lidx + b * (KF_TQ * KF_LQ) + ql * KF_LQ;
-            // ---- phase B of chunk j (gathers first), phase A of chunk j + 1 while they are in flight ----
-#pragma unroll
-            for (int k1 = 0; k1 < KF_LQ; k1 += PF) {
-                float4 fv[PF];
-                int ids[PF];
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    ids[u] = lib[k1 + u];
-                    fv[u] = kp_gather4(fbuf, ids[u], ldf, 4 * cl);
-                }
-                if (k1 == 0) {
-                    if (k0 + KF_LQ < K) phase_a(pr, b ^ 1);                   // (workgroup-uniform)
-                    pr = kp_pair_fetch(id_next, Ns, s, rowpos);               // chunk j + 2's pair, in flight during the FMAs
-                }
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront
-                    float w[16];
-                    kp_load_w(&lwb[(k1 + u) * 16], k1 + u, w);
-#pragma unroll
-                    for (int p = 0; p < KP_MAXP - 1; ++p) {
-                        acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
-                        acc[p][1] = fmaf(w[p], fv[u].y, acc[p][1]);
-                        acc[p][2] = fmaf(w[p], fv[u].z, acc[p][2]);
-                        acc[p][3] = fmaf(w[p], fv[u].w, acc[p][3]);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    } else
     for (int k0 = 0; k0 < K; k0 += KF_LQ) {
         const int id_next = kp_pair_index(idrow, qslot < Nq, k0 + KF_LQ + cl, K, Ns);       // in flight during phase A
         {   // ---- phase A: thread = (query ql, neighbour k0 + cl) ----
@@ -946,8 +893,8 @@ static int kp_fused32_launch(const float* q, int Nq, const float* s, int Ns, con
     if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;     // (16.7 M rows per call: use d3f_kpconv_aggregate + d3f_gemm_f32)
     const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
     KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
-    const size_t lds = (size_t)KF_REGION * sizeof(float) + (size_t)(2 * KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
-    static_assert(KF_REGION >= KF_TQ * KF_TS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
+    const size_t lds = (size_t)(KF_TQ * KF_TS) * sizeof(float) + (size_t)(KF_TQ * KF_LQ + 2 * KF_TQ) * sizeof(int);
+    static_assert(KF_TQ * KF_TS >= KF_TQ * KF_WS && KF_TQ * KF_TS >= 4096, "LDS region must hold every life");
     static std::atomic<unsigned long long> lds_done{0};
     // feature rows requested before any is consumed: 4 -> 126 / 123 registers = four workgroups per CU.  (Round 1 measured the
     // deeper prefetch faster -- then 4 spilled; since the packed influences and 24-bit addressing of round 3 it fits and wins:
@@ -957,11 +904,6 @@ static int kp_fused32_launch(const float* q, int Nq, const float* s, int Ns, con
     const void* const fns[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF, float, X3>,
                                 (const void*)kpconv_fused32_kernel<false, 8, float, X3>};
     if (d3f_opt_in_lds(lds_done, fns, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-    static const bool db = []() { const char* e = getenv("D3F_KP_DB"); return !(e && e[0] == '0'); }();   // D3F_KP_DB=0: two barriers per chunk
-    const void* const fnd[2] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF, float, X3, true>,
-                                (const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, X3, true>};
-    static std::atomic<unsigned long long> lds_done_d{0};
-    if (d3f_opt_in_lds(lds_done_d, fnd, (int)lds) != D3F_OK) return D3F_ERR_HIP;
 #define D3F_KF(FAST_, PF_)                                                                                                   \
     kpconv_fused32_kernel<FAST_, PF_, float, X3><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P, \
                                                                                             W, E, out, ldo, Nq_dev, Ns_dev, q_order)
@@ -970,16 +912,9 @@ static int kp_fused32_launch(const float* q, int Nq, const float* s, int Ns, con
         static std::atomic<unsigned long long> lds_done_h{0};
         const void* const fnh[1] = {(const void*)kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, X3>};
         if (d3f_opt_in_lds(lds_done_h, fnh, (int)lds) != D3F_OK) return D3F_ERR_HIP;
-        if (db)
-            kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, X3, true><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
-                q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
-        else
         kpconv_fused32_kernel<true, D3F_KP_PF_H, unsigned short, X3><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(
             q, Nq, s, Ns, idx, ld_idx, K, (const unsigned short*)f_, ldf, rowpos, P, W, E, (unsigned short*)out_, ldo, Nq_dev, Ns_dev, q_order);
     } else if (!kp_fast_config(num_kp, influence, aggregation)) D3F_KF(false, 8);
-    else if (db)
-        kpconv_fused32_kernel<true, D3F_KP_PF, float, X3, true><<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P,
-                                                                                                       W, E, out, ldo, Nq_dev, Ns_dev, q_order);
     else D3F_KF(true, D3F_KP_PF);
 #undef D3F_KF
     D3F_LAUNCH_CHECK();
