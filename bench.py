@@ -876,10 +876,11 @@ def classify_record(cfg, name, info):
             name, "kpconv_fused_kernel<Cin=%d>" % cin)
         nbytes = kpconv_alg_bytes(info["Nq"], info["Ns"], info["K"], cin, cout)
         flops = sum(kpconv_flops(info["Nq"], info["K"], cin, cout))
-    elif name in ("gemm_f32", "gemm_x3"):
-        # the contraction families (+ their split-K reduce kernel): operand-split form on the bf16 matrix cores (every layer wider
-        # than 32 columns), LDS-DMA fp32 MFMA tile kernel (the 32-column layers and whatever d3f_gemm_x3 cannot address)
-        key = "gemm_x3_kernel" if name == "gemm_x3" else "gemm_dma_kernel"
+    elif name in ("gemm_f32", "gemm_x3", "gemm_x3r"):
+        # the contraction families (+ their split-K reduce kernel): operand-split form on the bf16 matrix cores -- its tile kernel
+        # (gemm_x3_kernel) and, since round 5, its resident-W persistent form for the tall layers of the fine levels
+        # (gemm_x3r_kernel: a streaming kernel, HBM-bound) --, LDS-DMA fp32 MFMA tile kernel (whatever d3f_gemm_x3 cannot address)
+        key = {"gemm_x3": "gemm_x3_kernel", "gemm_x3r": "gemm_x3r_kernel"}.get(name, "gemm_dma_kernel")
         nbytes = 4.0 * (info["M"] * info["K"] + info["K"] * info["N"] + info["M"] * info["N"])
         flops = 2.0 * info["M"] * info["N"] * info["K"]
     elif name == "nb_search":  # SURVEY §8(d) bytes_alg = 12*(Nq+Ns) + 4*Nq*K_out
@@ -956,8 +957,8 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
             per_step_agg[-1].append((info, ms))
         elif name in ("kpconv_fused_c1", "kpconv_fused32", "kpconv_fused"):
             per_step_agg[-1].append((dict(info, fused=True), ms))
-        elif name in ("gemm_f32", "gemm_x3"):
-            per_step_gemm[-1].append((dict(info, kernel="gemm_x3_kernel" if name == "gemm_x3" else "gemm_dma_kernel"), ms))
+        elif name in ("gemm_f32", "gemm_x3", "gemm_x3r"):
+            per_step_gemm[-1].append((dict(info, kernel={"gemm_x3": "gemm_x3_kernel", "gemm_x3r": "gemm_x3r_kernel"}.get(name, "gemm_dma_kernel")), ms))
     fam = accumulate_families(cfg, timed)
 
     traffic, traffic_src, traffic_stale = load_traffic()
@@ -1003,7 +1004,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
         # collected for different kernel sources than the ones running now.
         if traffic is not None:
             base = name.split("<")[0].split(" ")[0]
-            names = ("gemm_x3_kernel", "gemm_x3r_kernel") if name.startswith("gemm_x3") else \
+            names = ("gemm_x3r_kernel",) if name.startswith("gemm_x3r") else ("gemm_x3_kernel",) if name.startswith("gemm_x3") else \
                 ("gemm_dma_kernel", "gemm_fast_kernel", "gemm_f32_kernel") if name.startswith("gemm") else (base,)
             ent = [v for k, v in traffic.items() if isinstance(v, dict) and k.split("<")[0] in names
                    and "traffic_bytes_per_launch" in v]

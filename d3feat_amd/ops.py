@@ -530,7 +530,12 @@ def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, ro
     if _x3_ok(C1, C2, N, hint if 0 < hint < M else M) and M <= X3_MAX_ROWS:
         Wx = packed_x3_weights(W)
         ws = workspace(lib.d3f_gemm_x3_workspace_bytes(M, N, C1 + C2, hint), dev)
-        with _timed("gemm_x3", dict(M=M, N=N, K=C1 + C2), dev):
+        # (record name only: which form the library takes -- the predicate of csrc/gemm_f32.hip d3f_gemm_x3, mirrored for the
+        # per-family tables of bench.py: the resident-W persistent form is a streaming kernel, bound by HBM, not by the matrix pipe)
+        ng, rows = (N + 31) // 32, (hint if 0 < hint < M else M)
+        resident = (os.environ.get("D3F_GEMM_X3R", "1") != "0" and ng in (1, 2, 4) and rows >= X3R_MIN_ROWS and
+                    ((C1 + C2) // 32) * ng * 7680 + 36864 <= 160 * 1024)
+        with _timed("gemm_x3r" if resident else "gemm_x3", dict(M=M, N=N, K=C1 + C2), dev):
             rc = lib.d3f_gemm_x3(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
                                  skip.data_ptr() if skip is not None else None, lds, C2, Wx.data_ptr(), out.data_ptr(), ldc, M, N,
                                  row_scale.data_ptr() if row_scale is not None else None,
