@@ -814,9 +814,10 @@ def marginal_costs(args, cfg, W, limits, engine, run, shard, device, nsteps, flo
                 x3 = fam == "gemm" and _ops.GEMM_X3
                 pk = MFMA_X3_PEAK_TF if x3 else MFMA_F32_PEAK_TF
                 e.update(alg_flops_per_fragment=int(flops[fam]), tflops=round(tf, 2), peak=round(pk, 1), frac=round(tf / pk, 4),
-                         bound=("mfma (six bf16 products per fp32 product: dense bf16 peak / 6; the 32-column layers run on the fp32 "
-                                "pipe)" if x3 else "mfma") if fam == "gemm"
-                         else "valu (aggregation: 157.3 TF/s of packed fp32 FMAs) + contraction (since round 5 on the bf16 matrix cores in the operand-split form); priced against 157.3")
+                         bound=("mfma (six bf16 products per fp32 product: dense bf16 peak / 6; the tall layers of the fine levels are "
+                                "HBM-bound: rooflines[gemm_x3r_kernel])" if x3 else "mfma") if fam == "gemm"
+                         else "valu (aggregation: 157.3 TF/s of packed fp32 FMAs) + contraction (since round 5 on the bf16 matrix "
+                              "cores in the operand-split form); priced against 157.3")
                 if x3:
                     e["over_fp32_mfma_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
             out[fam] = e
