@@ -1018,7 +1018,7 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
         static const bool on = []() { const char* e = getenv("D3F_GEMM_X3R"); return !(e && e[0] == '0'); }();
         const int m_eff = (M_hint > 0 && M_hint < M) ? M_hint : M;
         const size_t wbytes = (size_t)nkt * NG * GX_CHUNK * sizeof(unsigned short);
-        if (on && (NG == 1 || NG == 2 || NG == 4) && wbytes + GXR_PATCH_BYTES <= 160 * 1024 && m_eff >= 65536) {
+        if (on && (NG == 1 || NG == 2 || NG == 4) && wbytes + GXR_PATCH_BYTES + GXR_EPI_BYTES <= 160 * 1024 && m_eff >= 65536) {
             static int cus = 0;
             if (!cus) {
                 int dev = 0;
@@ -1030,7 +1030,7 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
             const void* const fns[3] = {(const void*)gemm_x3r_kernel<1>, (const void*)gemm_x3r_kernel<2>, (const void*)gemm_x3r_kernel<4>};
             if (d3f_opt_in_lds(lds_done, fns, 160 * 1024) != D3F_OK) return D3F_ERR_HIP;
             const int grid = std::min(cus, d3f_cdiv(d3f_cdiv(M, 32), 8));
-#define D3F_GXR(TN_) gemm_x3r_kernel<TN_><<<grid, 512, wbytes + GXR_PATCH_BYTES, stream>>>(A, lda, (const unsigned short*)Wx, nkt, C, ldc, M, N, E, M_dev, G)
+#define D3F_GXR(TN_) gemm_x3r_kernel<TN_><<<grid, 512, wbytes + GXR_PATCH_BYTES + GXR_EPI_BYTES, stream>>>(A, lda, (const unsigned short*)Wx, nkt, C, ldc, M, N, E, M_dev, G)
             if (NG == 4) D3F_GXR(4);
             else if (NG == 2) D3F_GXR(2);
             else D3F_GXR(1);

@@ -398,6 +398,7 @@ gemm_x3_kernel(const float* __restrict__ A, int lda, const unsigned short* __res
 // latencies.  Per tile one full drain (the tile's first floats and the previous tile's stores together), counted waits inside.
 #define GXR_PS 36                       // floats per row of a wave's output patch (32 + 4: the b128 accesses of a row group on distinct banks)
 #define GXR_PATCH_BYTES (8 * 32 * GXR_PS * 4)
+#define GXR_EPI_BYTES (2 * 128 * 4)          // per-column scale / shift of up to 128 columns, staged once
 template <int TN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wx, int nkt, float* __restrict__ C, int ldc,
@@ -415,10 +416,26 @@ gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __re
             const int kt = c / TN, j = c - kt * TN;
             dst[e] = src[(size_t)(j * nkt + kt) * 480 + o];
         }
+        // the per-column epilogue operands too (identity where absent): read from LDS in the epilogue -- a global load there is
+        // waited for with vmcnt(0) by the compiler and drains the wave's prefetched operand loads once per tile
+        float* ep = (float*)(gxr_w + (size_t)nkt * TN * (GX_CHUNK * 2) + GXR_PATCH_BYTES);
+        for (int c = tid; c < 32 * TN; c += 512) {
+            ep[c] = (E.col_scale && c < N) ? E.col_scale[c] : 1.f;
+            ep[32 * TN + c] = (E.col_shift && c < N) ? E.col_shift[c] : 0.f;
+        }
     }
     __syncthreads();
+    const float* ep_scale = (const float*)(gxr_w + (size_t)nkt * TN * (GX_CHUNK * 2) + GXR_PATCH_BYTES);
+    const float* ep_shift = ep_scale + 32 * TN;
     const int ntiles = (M + 31) >> 5;
-    const int kofs = (lane >> 5) << 3;
+    // 8 (lane >> 5), RECOMPUTED where it is used (two instructions, volatile: not kept live): at 256 registers the allocator spilled
+    // this one value, and its reload -- a scratch load the compiler waits for with vmcnt(0) -- drained the wave's prefetched
+    // operand loads at every tile boundary
+    auto kofs_now = [&]() -> int {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (int)((l >> 5) << 3);
+    };
     const int K1 = G.K1;
     const int n1 = G.gidx ? d3f_dyn(G.N1, G.N1_dev) : 0;
     const int tstride = 8 * (int)gridDim.x;
@@ -438,7 +455,7 @@ gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __re
     auto a_rebase = [&](int t) {
         const bool first = t * GX_BK < K1;                 // (wave-uniform)
         const unsigned msk = first ? amask : a2mask;
-        pa = (first ? arow : a2row) + ((unsigned)((first ? t * GX_BK : t * GX_BK - K1) + kofs) & msk);
+        pa = (first ? arow : a2row) + ((unsigned)((first ? t * GX_BK : t * GX_BK - K1) + kofs_now()) & msk);
         astep = (unsigned)GX_BK & msk;
     };
     auto rq_rows = [&](int rt) {
@@ -480,7 +497,7 @@ gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __re
     // micro-operation list of gemm_x3_kernel::tile), W fragments read from the resident image
     auto tile = [&](int kt, const uint4 (&cur)[2][3], uint4 (&nxt)[2][3], const gx_f4& r0, const gx_f4& r1, const gx_f4& r2,
                     const gx_f4& r3) {
-        const unsigned short* bp = (const unsigned short*)gxr_w + (size_t)kt * (TN * GX_CHUNK) + (lane & 31) * GX_LS + kofs;
+        const unsigned short* bp = (const unsigned short*)gxr_w + (size_t)kt * (TN * GX_CHUNK) + (lane & 31) * GX_LS + kofs_now();
         constexpr int NM = 12 * TN, NOPS = 88;
         constexpr int PA[2][6] = {{2, 1, 0, 1, 0, 0}, {0, 1, 0, 2, 1, 0}}, PB[2][6] = {{0, 1, 2, 0, 1, 0}, {2, 1, 1, 0, 0, 0}};
         uint4 b[TN][3];
@@ -543,8 +560,8 @@ gemm_x3r_kernel(const float* __restrict__ A, int lda, const unsigned short* __re
                 const int gn = 32 * j + 8 * q + 4 * (lane >> 5);
                 float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
                 if (mok && gn < N) {
-                    const float4 c4 = E.col_scale ? *(const float4*)&E.col_scale[gn] : make_float4(1.f, 1.f, 1.f, 1.f);
-                    const float4 h4 = E.col_shift ? *(const float4*)&E.col_shift[gn] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 c4 = *(const float4*)&ep_scale[gn];
+                    const float4 h4 = *(const float4*)&ep_shift[gn];
                     const float4 r4 = E.residual ? *(const float4*)&E.residual[(size_t)gm_a * E.ldr + gn] : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float c[4] = {c4.x, c4.y, c4.z, c4.w}, h[4] = {h4.x, h4.y, h4.z, h4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll

@@ -534,7 +534,7 @@ def _gemm_f32t(A, N1, lda, C1, idx, ld_idx, skip, lds, C2, W, out, ldc, M, N, ro
         # per-family tables of bench.py: the resident-W persistent form is a streaming kernel, bound by HBM, not by the matrix pipe)
         ng, rows = (N + 31) // 32, (hint if 0 < hint < M else M)
         resident = (os.environ.get("D3F_GEMM_X3R", "1") != "0" and ng in (1, 2, 4) and rows >= X3R_MIN_ROWS and
-                    ((C1 + C2) // 32) * ng * 7680 + 36864 <= 160 * 1024)
+                    ((C1 + C2) // 32) * ng * 7680 + 36864 + 1024 <= 160 * 1024)
         with _timed("gemm_x3r" if resident else "gemm_x3", dict(M=M, N=N, K=C1 + C2), dev):
             rc = lib.d3f_gemm_x3(A.data_ptr(), N1, lda, C1, idx.data_ptr() if idx is not None else None, ld_idx,
                                  skip.data_ptr() if skip is not None else None, lds, C2, Wx.data_ptr(), out.data_ptr(), ldc, M, N,
