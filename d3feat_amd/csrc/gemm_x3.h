@@ -9,6 +9,16 @@
 // instead of one rounded product on v_mfma_f32_32x32x2_f32 (2 k per instruction, 64 cycles): 2.67x the matrix-pipe rate and a
 // sixth of the k-steps a wavefront has to issue instructions around.  What is dropped is below the rounding of the fp32
 // accumulation itself; tests/test_gpu_gemm_x3.py measures the result against float64 next to the fp32 MFMA kernel's.
+// Edges of the format (tests: the e^+-20 exactness cases, test_the_small_edge_of_the_format): an operand that is +-Inf, or finite
+// within 2^-8 of FLT_MAX (its first plane rounds to Inf), yields NaN (Inf - Inf in the second plane) where the fp32 pipe yields
+// +-Inf -- non-finite either way; planes that are bfloat16 SUBNORMALS (the third plane of operands below ~2^-110, the second below
+// ~2^-118) are flushed by the matrix pipe: measured max abs error 4.6e-41 = 2^-134 on operands of 2^-126 .. 2^-90, nothing flushed
+// to zero, operands of 2^-100 and above bit for bit.
+// Toolchain contract: the A loads and the LDS-DMA are inline asm whose outputs land after the statement; nothing may
+// copy or spill those registers between request and wait, and the hand-counted vmcnt assumes no compiler-issued VMEM inside the
+// k-loop.  Checked after every change of this file: -Rpass-analysis=kernel-resource-usage reports 0 spilled VGPRs for every
+// gemm_x3 / gemm_x3r instance (a spill did appear in round 5 -- of a lane constant, not of a request register -- and cost a
+// vmcnt(0) per tile: see gemm_x3r_kernel), and the exact-plane tests are part of the GPU suite.
 //
 // Layout.  Workgroup = 4 wavefronts stacked along M: 128 rows x 32 TN columns; wave w owns rows 32 w .. 32 w + 31 and ALL the
 // workgroup's columns (TN accumulator tiles), so no A element is loaded or split twice inside a workgroup.

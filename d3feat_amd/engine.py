@@ -73,7 +73,12 @@ class FragmentEngine:
         features with MFMA contraction"; arithmetic inside every kernel stays fp32.
         stage0=False: the submitted clouds are ALREADY at the first subsampling resolution (the reference's scripts subsample
         before the dataset sees a cloud: demo_registration.py:24, datasets/ThreeDMatch.py:349) -- no stage-0 voxelisation, the
-        cloud is stacked with itself as it is; raw_cap is then the voxel capacity n0_cap."""
+        cloud is stacked with itself as it is; raw_cap is then the voxel capacity n0_cap.
+    Weights are captured BY ADDRESS: a replayed graph reads the model's tensors and their packed copies (transposed / pre-split planes,
+    made once per tensor: ops._packed_on_tensor) through raw pointers.  After an in-place update of a weight tensor the packed copies
+    are re-made at the next eager call -- at NEW addresses -- and `.data =` / `set_()` updates are not seen at all: build a new engine
+    after changing weights.
+    """
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.device = config, device
