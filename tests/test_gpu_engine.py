@@ -301,3 +301,30 @@ def test_packed_weight_copies_outlive_any_cache_traffic(device):
     assert torch.equal(o1, o2) and hasattr(K_values, "_d3f_f32t") and len(K_values._d3f_f32t) == 1
     assert (o1.double() - A2.double() @ K_values.reshape(120, 16).double()).abs().max().item() <= 1e-3
     del keep
+
+
+def test_pack_status_packs_in_one_launch_and_clears_the_flag_words_only(device, setup):
+    """d3f_pack_status (round 5): the replay's last node packs [n_total | status0 | statuses | lens] into one block and zeroes the
+    sticky FLAG column of the searches' status words -- the size / kmax column stays readable after the replay -- and a flagged
+    replay does not poison the next one (the flags of replay n are gone when replay n + 1 reads its own)."""
+    from d3feat_amd import ops
+    from d3feat_amd.engine import FragmentEngine
+    a = torch.tensor([7], dtype=torch.int32, device=device)
+    b = torch.tensor([1, 2], dtype=torch.int32, device=device)
+    st = torch.tensor([[10, 4], [20, 0], [30, 8]], dtype=torch.int32, device=device)
+    lens = torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=device)
+    dst = torch.full((16,), -1, dtype=torch.int32, device=device)
+    ops.pack_status(dst, [a, b, st, lens], clear=st)
+    torch.cuda.synchronize()
+    assert dst.tolist() == [7, 1, 2, 10, 4, 20, 0, 30, 8, 5, 6, 7, 8, -1, -1, -1]
+    assert st.tolist() == [[10, 0], [20, 0], [30, 0]]
+    # engine level: a replay whose capacity is exceeded raises flags (fallback), the next replay of the same slot with a small cloud
+    # must come back clean, from the graph
+    cfg, W, limits = setup
+    big, small = _frag(3, n_raw=40000), _frag(4, n_raw=6000)
+    eng = FragmentEngine(cfg, W, limits, raw_cap=50000, n0_cap=4096, slots=1, device=device)
+    eng.run(torch.from_numpy(big).to(device))
+    assert eng.fallbacks == 1
+    eng.run(torch.from_numpy(small).to(device))
+    assert eng.fallbacks == 1 and eng.fragments == 2
+    assert int(eng.slots[0].status[:, 1].abs().sum().item()) == 0
