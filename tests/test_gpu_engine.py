@@ -322,7 +322,7 @@ def test_pack_status_packs_in_one_launch_and_clears_the_flag_words_only(device, 
     # must come back clean, from the graph
     cfg, W, limits = setup
     big, small = _frag(3, n_raw=40000), _frag(4, n_raw=6000)
-    eng = FragmentEngine(cfg, W, limits, raw_cap=50000, n0_cap=4096, slots=1, device=device)
+    eng = FragmentEngine(cfg, W, limits, raw_cap=50000, n0_cap=8192, slots=1, device=device)
     eng.run(torch.from_numpy(big).to(device))
     assert eng.fallbacks == 1
     eng.run(torch.from_numpy(small).to(device))
