@@ -51,7 +51,8 @@ MFMA_BF16_PEAK_TF = 2516.6  # v_mfma_f32_32x32x16_bf16 dense peak (16 x the fp32
 X3_PRODUCTS = 6
 MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / X3_PRODUCTS
 PARITY_TOL = 1e-4          # BASELINE.json north_star: descriptors and scores within 1e-4 (absolute), indices bit-exact
-BF16_TOL = 2e-2            # documented tolerance of the bf16-contraction configuration vs the fp32 oracle (tests/test_gpu_bf16.py)
+BF16_TOL = 1.5e-2          # documented tolerance of the bf16 configurations vs the fp32 oracle (tests/test_gpu_bf16.py; measured on this
+                           # sample: descriptors 6.2e-3, scores 1.27e-2)
 
 
 def parse():

@@ -12,10 +12,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DESC_TOL = 1.5e-2     # max |descriptor component| difference vs the fp32 oracle (unit-norm 32-d descriptors); measured 5e-3 .. 6.5e-3
-SCORE_TOL = 2e-2      # max |score| difference; measured 1e-2 .. 1.1e-2
-FEAT_DESC_TOL = 1.5e-2  # bf16 feature STORAGE on top (38 layers of 2^-9 roundings of the activations); measured 4.7e-3
-FEAT_SCORE_TOL = 2e-2   # measured 7.9e-3
+DESC_TOL = 1.0e-2     # max |descriptor component| difference vs the fp32 oracle (unit-norm 32-d descriptors); measured 4.5e-3 .. 6.5e-3
+SCORE_TOL = 1.5e-2    # max |score| difference; measured 8.3e-3 .. 1.1e-2 (round 5: set from the measured values)
+FEAT_DESC_TOL = 1.0e-2  # bf16 feature STORAGE on top (38 layers of 2^-9 roundings of the activations); measured 4.7e-3 .. 6.2e-3
+FEAT_SCORE_TOL = 1.5e-2  # measured 7.9e-3 .. 1.27e-2 (the bench sample of five 30 k-point fragments is the largest)
 
 
 def _bf16_round(a):
