@@ -177,23 +177,17 @@ __device__ __forceinline__ bool kp_pair_influences(const KpParams& P, const KpPa
 // The 16 influences of one (query, neighbour) pair in LDS: four 16-byte quads at base + 16*slot floats.  Eight adjacent
 // lanes store their pairs with ds_write_b128 at a 64-byte stride, i.e. on two bank groups only (4-way conflict: a third of the
 // LDS-active cycles of these kernels); rotating the quad order by slot/2 spreads them over all eight.  Readers undo it.
-// (round 5) Chunks of 16 / 32 neighbours: with the rotation slot / 2 the lanes slot and slot + 8 (+ 16, + 24) of a query landed on
-// the same banks again -- SQ_LDS_BANK_CONFLICT 11 % of the LDS-active cycles at 8 lanes per query, 19 % at 16, 28 % at 32
-// (gpurun_out/r05_sq_counters.txt); the 64-byte records of slots 4 apart share a bank group, so the rotation is slot / 4 there.
-template <int KC> __device__ __forceinline__ int kp_rot(int slot) { return KC > 8 ? (slot >> 2) : (slot >> 1); }
-template <int KC>
 __device__ __forceinline__ void kp_store_w(float* __restrict__ pair_base, int slot, const float* w) {
     float4* dst = (float4*)pair_base;
-    const int r = kp_rot<KC>(slot);
+    const int r = slot >> 1;
     dst[(0 + r) & 3] = make_float4(w[0], w[1], w[2], w[3]);
     dst[(1 + r) & 3] = make_float4(w[4], w[5], w[6], w[7]);
     dst[(2 + r) & 3] = make_float4(w[8], w[9], w[10], w[11]);
     dst[(3 + r) & 3] = make_float4(w[12], w[13], w[14], w[15]);
 }
-template <int KC>
 __device__ __forceinline__ void kp_load_w(const float* __restrict__ pair_base, int slot, float* w) {
     const float4* src = (const float4*)pair_base;
-    const int r = kp_rot<KC>(slot);
+    const int r = slot >> 1;
     const float4 w0 = src[(0 + r) & 3], w1 = src[(1 + r) & 3], w2 = src[(2 + r) & 3], w3 = src[(3 + r) & 3];
     w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
     w[8] = w2.x; w[9] = w2.y; w[10] = w2.z; w[11] = w2.w; w[12] = w3.x; w[13] = w3.y; w[14] = w3.z; w[15] = w3.w;
@@ -294,7 +288,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
             const bool positive = kp_pair_influences<FAST>(P, pr, qx, qy, qz, w);
             kp_count_positive<LQ>(positive, ql, cl, lcnt);
             lidx[ql * KC + cl] = pr.id;
-            kp_store_w<KC>(&lw[ql * WS + cl * 16], cl, w);
+            kp_store_w(&lw[ql * WS + cl * 16], cl, w);
         }
         __syncthreads();
         pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                          // in flight during phase B
@@ -315,7 +309,7 @@ kpconv_agg_vec4(const float* __restrict__ q, int Nq, const float* __restrict__ s
             for (int u = 0; u < PF; ++u) {
                 if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
-                kp_load_w<KC>(&lw[ql * WS + (kg + u) * 16], kg + u, w);
+                kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
 #pragma unroll
                 for (int p = 0; p < KP_MAXP - 1; ++p) {
                     acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
@@ -834,7 +828,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
             const bool positive = kp_pair_influences<FAST>(P, pr, qx, qy, qz, w);
             kp_count_positive<KF_LQ>(positive, ql, cl, lcnt);
             lidx[ql * KF_LQ + cl] = pr.id;
-            kp_store_w<KF_LQ>(&lw[ql * KF_WS + cl * 16], cl, w);
+            kp_store_w(&lw[ql * KF_WS + cl * 16], cl, w);
         }
         __syncthreads();
         pr = kp_pair_fetch(id_next, Ns, s, rowpos);                                         // in flight during phase B
@@ -854,7 +848,7 @@ kpconv_fused32_kernel(const float* __restrict__ q, int Nq, const float* __restri
             for (int u = 0; u < PF; ++u) {
                 if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
-                kp_load_w<KF_LQ>(&lw[ql * KF_WS + (k1 + u) * 16], k1 + u, w);
+                kp_load_w(&lw[ql * KF_WS + (k1 + u) * 16], k1 + u, w);
 #pragma unroll
                 for (int p = 0; p < KP_MAXP - 1; ++p) {
                     acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
@@ -1012,7 +1006,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             kp_count_positive<LQ>(positive, ql, cl, lcnt);
             if (cl < KC) {
                 lidx[ql * KC + cl] = pr.id;
-                kp_store_w<KC>(&lw[ql * WS + cl * 16], cl, w);
+                kp_store_w(&lw[ql * WS + cl * 16], cl, w);
             }
         }
         __syncthreads();
@@ -1031,7 +1025,7 @@ kpconv_fused_kernel(const float* __restrict__ q, int Nq, const float* __restrict
             for (int u = 0; u < PF; ++u) {
                 if (!__any(ids[u] >= 0)) continue;   // (wavefront-uniform) shadow slot for every query of the wavefront: nothing to add
                 float w[16];
-                kp_load_w<KC>(&lw[ql * WS + (kg + u) * 16], kg + u, w);
+                kp_load_w(&lw[ql * WS + (kg + u) * 16], kg + u, w);
 #pragma unroll
                 for (int p = 0; p < KP_MAXP - 1; ++p) {
                     acc[p][0] = fmaf(w[p], fv[u].x, acc[p][0]);
