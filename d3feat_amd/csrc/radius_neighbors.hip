@@ -445,6 +445,8 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
                                           cap, status, want_kmax, nn_hint);
 }
 
+#include "nb_cell_search.h"
+
 // ------------------------------------------------------------------------------------------------
 // cells the grid may use: 4 per support (surface clouds occupy ~0.3 cells per point at cell edge = radius; a sparser cloud gets
 // larger cells).  The budget is what every build has to clear -- in capacity mode whatever the real cloud size -- so it is
@@ -552,6 +554,36 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     if (!g.ok) return D3F_ERR_WORKSPACE;
     const float r2 = radius * radius;
     const int* qorder = queries_are_supports ? g.order : nullptr;
+    // full lists: one wavefront per query, the stencil shared by the queries of a cell (nb_cell_search.h); D3F_NB_CELL=0 keeps the
+    // 16 / 32-lanes-per-query kernel (A/B measurements)
+    const char* cf_env = getenv("D3F_NB_CELL");      // (read per call: a measurement script switches forms in one process)
+    const bool cell_form = !(cf_env && atoi(cf_env) == 0);
+    if (!first_only && cell_form) {
+        cap = (cap + 1) & ~1;
+        // queries per wavefront: consecutive queries share a stencil when they come in cell order, but a wavefront works through
+        // its queries one after the other -- a small launch keeps one query per wavefront (all of them in flight at once)
+        const char* q_env = getenv("D3F_NBC_Q");
+        const int q_forced = q_env ? atoi(q_env) : 0;
+        int Q = q_forced > 0 ? q_forced : Nq / 8192;
+        Q = Q < 1 ? 1 : (Q > 16 ? 16 : Q);
+        if (Q > NBC_QMAX) Q = NBC_QMAX;
+        while (Q > 1 && (size_t)4 * (2 * cap + Q * width + 1) * sizeof(int) > 48 * 1024) Q >>= 1;   // finished rows wait in LDS
+        const char* dbg_env = getenv("D3F_NBC_DBG");       // measurement only: skip phases (results are then wrong)
+        const int dbg = dbg_env ? atoi(dbg_env) : 0;
+        const char* prof_env = getenv("D3F_NBC_PROF");     // measurement only: device address of 16 u64 counters (hex)
+        unsigned long long* prof = prof_env ? (unsigned long long*)strtoull(prof_env, nullptr, 16) : nullptr;
+        const int blocks = d3f_cdiv(d3f_cdiv(Nq, Q), 4);
+        const size_t lds = (size_t)4 * ((2 * cap + Q * width + 1) & ~1) * sizeof(int);
+        if (lds > 64 * 1024) return D3F_ERR_ARG;      // (width > ~3000 columns: not a neighbourhood matrix)
+        if (queries_are_supports)
+            nb_cell_search_kernel<true><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
+                                                                      pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof);
+        else
+            nb_cell_search_kernel<false><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
+                                                                       pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof);
+        D3F_LAUNCH_CHECK();
+        return D3F_OK;
+    }
     // lanes per query: 32 (two queries per wavefront) unless the ordering budget is large (rare, dense clouds)
     cap = (cap + 3) & ~3;   // LDS segments are read four hits at a time
     // lanes per query.  The kernel runs at full occupancy and costs (rounds of resident wavefronts) x (a chain of ~4 dependent

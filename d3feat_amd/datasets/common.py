@@ -124,6 +124,11 @@ class Dataset:
             status_all = getattr(self, "_status_all", None)
             if status_all is None or status_all.device != dev:
                 status_all = self._status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+            elif not torch.cuda.is_current_stream_capturing():
+                # eager use of the capacity mode (a tool, a test, the engine's warm-up): the flag words are sticky and nobody
+                # is guaranteed to have cleared the previous call's -- start clean.  Inside a capture the sequence
+                # relies on its own last node (ops.pack_status clear=...) instead: no fill node per replay
+                status_all[:, 1].zero_()
         else:
             status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)   # one fill: the searches do not reset theirs
         arch = config.architecture

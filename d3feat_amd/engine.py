@@ -75,9 +75,9 @@ class FragmentEngine:
         before the dataset sees a cloud: demo_registration.py:24, datasets/ThreeDMatch.py:349) -- no stage-0 voxelisation, the
         cloud is stacked with itself as it is; raw_cap is then the voxel capacity n0_cap.
     Weights are captured BY ADDRESS: a replayed graph reads the model's tensors and their packed copies (transposed / pre-split planes,
-    made once per tensor: ops._packed_on_tensor) through raw pointers.  After an in-place update of a weight tensor the packed copies
-    are re-made at the next eager call -- at NEW addresses -- and `.data =` / `set_()` updates are not seen at all: build a new engine
-    after changing weights.
+    made once per tensor: ops._packed_on_tensor) through raw pointers.  `refresh_weights(values)` is the supported way to change
+    them under live graphs: device tensors and packed copies are rewritten IN PLACE (same addresses), so the next replay computes
+    with the new weights.  `.data =` / `set_()` re-bindings are not seen by a captured graph at all.
     """
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
@@ -123,6 +123,18 @@ class FragmentEngine:
         self.fragments = 0
         self._hit_overflows = 0
         self._warned = False
+
+    def refresh_weights(self, values):
+        """New values ({checkpoint name: array}) for some of the model's variables while captured graphs are alive: every
+        device tensor (plain copies, folded batch-norm vectors, stacked branch weights) and every packed copy (transposed /
+        pre-split bf16 planes) is rewritten in place -- nothing a captured graph points at is freed or moved -- and the next
+        replay of every slot uses them.  No replay may be in flight (fetch every submitted slot first)."""
+        assert not any(sl.busy for sl in self.slots), "refresh_weights with replays in flight"
+        torch.cuda.synchronize(self.device)
+        touched = self.model.variables.update_in_place(values)
+        n = ops.refresh_packed_weights(touched)
+        torch.cuda.synchronize(self.device)
+        return n
 
     # ---- the fixed launch sequence -------------------------------------------------------------------------------
     def _sequence(self, sl):

@@ -30,6 +30,7 @@ class VariableStore:
         self.create = create
         self._scope = []
         self._dev = {}
+        self._recipes = {}      # derived device tensors -> how to recompute them on the host (update_in_place)
 
     # ---- scopes -------------------------------------------------------------------------------------
     @contextlib.contextmanager
@@ -79,18 +80,28 @@ class VariableStore:
             self._dev[full] = t
         return t
 
+    def _bn_host(self, names, eps):
+        g, b, m, v = (self.values[n].astype(np.float32) for n in names)
+        scale = (g / np.sqrt(v + np.float32(eps))).astype(np.float32)
+        return scale, (b - m * scale).astype(np.float32)
+
     def folded_bn(self, names, eps=1e-6):
         """Inference batch norm (models/network_blocks.py:149-160, epsilon 1e-6) as y = x*scale + shift with
         scale = gamma*rsqrt(var+eps), shift = beta - mean*scale  (tf.nn.batch_normalization's own factoring)."""
         key = ('bn',) + tuple(names)
         t = self._dev.get(key)
         if t is None:
-            g, b, m, v = (self.values[n].astype(np.float32) for n in names)
-            scale = (g / np.sqrt(v + np.float32(eps))).astype(np.float32)
-            shift = (b - m * scale).astype(np.float32)
+            scale, shift = self._bn_host(names, eps)
             t = (torch.from_numpy(scale).to(self.device), torch.from_numpy(shift).to(self.device))
             self._dev[key] = t
+            self._recipes[key] = (lambda: self._bn_host(names, eps))
         return t
+
+    def _stack_host(self, w1, bn1, w2, bn2, eps):
+        s1, t1 = self._bn_host(bn1, eps)
+        s2, t2 = self._bn_host(bn2, eps)
+        W = np.concatenate([self.values[w1] * s1[None, :], self.values[w2] * s2[None, :]], 0).astype(np.float32)
+        return np.ascontiguousarray(W), (t1 + t2).astype(np.float32)
 
     def stacked_branches(self, w1, bn1, w2, bn2, eps=1e-6):
         """The two branches of a resnet block that meet in an add -- leaky(bn(x @ W1) + bn(f @ W2)), models/network_blocks.py:
@@ -99,19 +110,42 @@ class VariableStore:
         key = ('stack', w1, w2)
         t = self._dev.get(key)
         if t is None:
-            def fold(names):
-                g, b, m, v = (self.values[n].astype(np.float32) for n in names)
-                sc = (g / np.sqrt(v + np.float32(eps))).astype(np.float32)
-                return sc, (b - m * sc).astype(np.float32)
-            s1, t1 = fold(bn1)
-            s2, t2 = fold(bn2)
-            W = np.concatenate([self.values[w1] * s1[None, :], self.values[w2] * s2[None, :]], 0).astype(np.float32)
-            t = (torch.from_numpy(np.ascontiguousarray(W)).to(self.device), torch.from_numpy(t1 + t2).to(self.device))
+            W, shift = self._stack_host(w1, bn1, w2, bn2, eps)
+            t = (torch.from_numpy(W).to(self.device), torch.from_numpy(shift).to(self.device))
             self._dev[key] = t
+            self._recipes[key] = (lambda: self._stack_host(w1, bn1, w2, bn2, eps))
         return t
+
+    def update_in_place(self, values):
+        """New values for some variables of a model whose device copies may already be captured BY ADDRESS in HIP graphs
+        (d3feat_amd.engine): the host masters are replaced and every device tensor made from them -- the plain copies, the folded
+        batch-norm vectors, the stacked branch weights -- is rewritten IN PLACE, so a replayed graph reads the new values at the
+        old addresses.  -> the device tensors that were rewritten (ops.refresh_packed_weights re-packs their packed copies, also
+        in place).  Shapes cannot change; kernel points ride in the launch arguments of a captured graph and cannot change."""
+        for name, v in values.items():
+            if name not in self.values:
+                raise KeyError('variable %s is not part of the weight set' % name)
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if v.shape != self.values[name].shape:
+                raise ValueError('variable %s has shape %s, expected %s' % (name, v.shape, self.values[name].shape))
+            if name.endswith('kernel_points') and not np.array_equal(v, self.values[name]):
+                raise ValueError('kernel points are launch arguments of the captured graphs: build a new engine to change %s' % name)
+            self.values[name] = v
+        touched = []
+        for key, t in self._dev.items():
+            if isinstance(key, str):
+                t.copy_(torch.from_numpy(self.values[key]))
+                touched.append(t)
+            else:
+                host = self._recipes[key]()
+                for dst, src in zip(t, host):
+                    dst.copy_(torch.from_numpy(src))
+                    touched.append(dst)
+        return touched
 
     def invalidate_device(self):
         self._dev = {}
+        self._recipes = {}
 
 
 def build_variables(config, seed=42, in_features_dim=None, randomize_bn=False, device=None):

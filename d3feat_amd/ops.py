@@ -236,8 +236,11 @@ def pack_status(dst, blocks, clear=None):
     `clear` (a device int32 [k, 2] tensor of [kmax-or-size | flags] pairs, may be one of the blocks) zeroed -- the size words stay
     readable after the replay: one launch (d3f_pack_status) instead of a copy node per block and a fill."""
     lib = _lib.load()
-    blocks = [b.reshape(-1) for b in blocks]
+    # contiguity is checked on the CALLER's tensors: the launch may be captured in a HIP graph with these addresses, and a silent
+    # copy (reshape of a strided view) would hand the graph a temporary that is freed when this call returns
     assert 1 <= len(blocks) <= 4 and all(b.dtype == torch.int32 and b.is_contiguous() for b in blocks) and dst.dtype == torch.int32
+    assert dst.is_contiguous()
+    blocks = [b.view(-1) for b in blocks]
     assert dst.numel() >= sum(b.numel() for b in blocks)
     args = []
     for i in range(4):
@@ -441,18 +444,49 @@ def _packed_on_tensor(W, slot, make):
         setattr(base, slot, store)
     key = (W.storage_offset(), tuple(W.shape), W.stride(0))
     hit = store.get(key)
-    if hit is None or hit[0] != base._version:
-        hit = store[key] = (base._version, make())
+    if hit is None:
+        hit = store[key] = [base._version, make(None)]
+    elif hit[0] != base._version:
+        # the weight was updated in place: re-pack INTO THE SAME BUFFER.  A captured graph holds the packed copy's address; a fresh
+        # allocation here would free memory that its replays still read (ADVICE r04 / VERDICT r05 item 8a) -- this way the replays
+        # simply see the new values (tests/test_gpu_engine.py::test_in_place_weight_update_reaches_a_captured_engine)
+        make(hit[1])
+        hit[0] = base._version
     return hit[1]
+
+
+def refresh_packed_weights(tensors):
+    """Re-pack (in place, same addresses) every packed copy that rides on one of `tensors` and is older than its tensor.
+    The packed copies are made by the EAGER ops; a caller that updates weights in place and then only REPLAYS captured graphs
+    calls this once after the update (FragmentEngine.refresh_weights does)."""
+    n = 0
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            continue
+        base = t._base if t._base is not None else t
+        for slot, fn in (("_d3f_bf16t", packed_bf16_weights), ("_d3f_f32t", packed_f32t_weights), ("_d3f_x3", packed_x3_weights)):
+            store = getattr(base, slot, None)
+            for key, hit in list((store or {}).items()):
+                if hit[0] != base._version:
+                    off, shape, st0 = key
+                    fn(base.as_strided(shape, (st0, 1), off))
+                    n += 1
+        for slot, fn in (("_d3f_packed", packed_kpconv_weights), ("_d3f_packed_x3", packed_kpconv_weights_x3)):
+            hit = getattr(t, slot, None)
+            if hit is not None and hit[0] != t._version:
+                fn(t)
+                n += 1
+    return n
 
 
 def packed_bf16_weights(W):
     """W f32[K,N] (contiguous rows) -> the bf16 [N][Kp] copy d3f_gemm_bf16 reads; made once per (weight tensor, view, version)."""
-    def make():
+    def make(t):
         lib = _lib.load()
         K, N = W.shape
         Kp = (K + 31) // 32 * 32
-        t = torch.empty((N, Kp), dtype=torch.int16, device=W.device)
+        if t is None:
+            t = torch.empty((N, Kp), dtype=torch.int16, device=W.device)
         _lib.check(lib.d3f_gemm_pack_bf16(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_bf16")
         return t
     return _packed_on_tensor(W, "_d3f_bf16t", make)
@@ -466,11 +500,12 @@ def packed_f32t_weights(W):
     """W f32[K,N] (contiguous rows) -> the transposed, K-padded f32 [N][Kp] copy d3f_gemm_f32t reads (LDS-DMA copies 16
     contiguous bytes per lane: it cannot transpose); made once per (weight tensor, view, version) -- at a model's first eager
     use, i.e. the engine's warm-up, never inside a captured graph."""
-    def make():
+    def make(t):
         lib = _lib.load()
         K, N = W.shape
         Kp = (K + 31) // 32 * 32
-        t = torch.empty((N, Kp), dtype=torch.float32, device=W.device)
+        if t is None:
+            t = torch.empty((N, Kp), dtype=torch.float32, device=W.device)
         _lib.check(lib.d3f_gemm_pack_f32t(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_f32t")
         return t
     return _packed_on_tensor(W, "_d3f_f32t", make)
@@ -485,10 +520,11 @@ GEMM_X3 = os.environ.get("D3F_GEMM_X3", "1") != "0"
 def packed_x3_weights(W):
     """W f32[K,N] (contiguous rows) -> the pre-split bf16 planes d3f_gemm_x3 stages ([column group][k-tile][plane][32][40]); made
     once per (weight tensor, view, version), like the transposed fp32 copy."""
-    def make():
+    def make(t):
         lib = _lib.load()
         K, N = W.shape
-        t = torch.empty((int(lib.d3f_gemm_x3_packed_bytes(K, N)) // 2,), dtype=torch.int16, device=W.device)
+        if t is None:
+            t = torch.empty((int(lib.d3f_gemm_x3_packed_bytes(K, N)) // 2,), dtype=torch.int16, device=W.device)
         _lib.check(lib.d3f_gemm_pack_x3(W.data_ptr(), int(W.stride(0)), K, N, t.data_ptr(), _stream(W.device)), "gemm_pack_x3")
         return t
     return _packed_on_tensor(W, "_d3f_x3", make)
@@ -818,7 +854,8 @@ def packed_kpconv_weights(K_values):
     lib = _lib.load()
     num_kp, cin, cout = K_values.shape
     W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
-    Wp = torch.empty_like(W)
+    # an in-place update of the weights re-packs into the SAME buffer (captured graphs hold its address: _packed_on_tensor)
+    Wp = cached[1] if cached is not None else torch.empty_like(W)
     _lib.check(lib.d3f_kpconv_pack_weights(W.data_ptr(), num_kp * cin, cout, Wp.data_ptr(), _stream(W.device)), "kpconv_pack_weights")
     K_values._d3f_packed = (K_values._version, Wp)
     return Wp
@@ -839,7 +876,8 @@ def packed_kpconv_weights_x3(K_values):
     lib = _lib.load()
     num_kp, cin, cout = K_values.shape
     W = _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
-    Wx = torch.empty((int(lib.d3f_kpconv_packed_x3_bytes(num_kp * cin, cout)) // 2,), dtype=torch.int16, device=W.device)
+    Wx = cached[1] if cached is not None else \
+        torch.empty((int(lib.d3f_kpconv_packed_x3_bytes(num_kp * cin, cout)) // 2,), dtype=torch.int16, device=W.device)
     _lib.check(lib.d3f_kpconv_pack_weights_x3(W.data_ptr(), num_kp * cin, cout, Wx.data_ptr(), _stream(W.device)), "kpconv_pack_weights_x3")
     K_values._d3f_packed_x3 = (K_values._version, Wx)
     return Wx

@@ -328,3 +328,66 @@ def test_pack_status_packs_in_one_launch_and_clears_the_flag_words_only(device, 
     eng.run(torch.from_numpy(small).to(device))
     assert eng.fallbacks == 1 and eng.fragments == 2
     assert int(eng.slots[0].status[:, 1].abs().sum().item()) == 0
+
+
+def test_in_place_weight_update_keeps_the_packed_copy_at_its_address(device):
+    """an in-place update of a weight tensor re-packs INTO THE SAME BUFFER -- a captured graph that holds the
+    packed copy's address then computes with the new weights instead of reading freed memory."""
+    from d3feat_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randn((3000, 128), generator=g).to(device)
+    W = (torch.randn((128, 64), generator=g) * 0.1).to(device)
+    ops.gemm(A, W)                                         # eager warm-up: packs W outside the capture
+    slots = [s for s in ("_d3f_x3", "_d3f_f32t", "_d3f_bf16t") if hasattr(W, s)]
+    assert slots
+    before = {s: [h[1].data_ptr() for h in getattr(W, s).values()] for s in slots}
+    stream = torch.cuda.Stream(device=device)
+    graph = torch.cuda.CUDAGraph()
+    with ops.private_workspace() as pw:
+        with torch.cuda.graph(graph, stream=stream):
+            out = ops.gemm(A, W)
+    keep = pw.kept
+    W.mul_(-0.5).add_(0.01)                                # in place: same storage, new version
+    want = (A.double() @ W.double()).float()
+    assert ops.refresh_packed_weights([W]) == len(slots)
+    after = {s: [h[1].data_ptr() for h in getattr(W, s).values()] for s in slots}
+    assert before == after
+    torch.cuda.synchronize(device)
+    graph.replay()
+    torch.cuda.synchronize(device)
+    assert (out - want).abs().max().item() <= 1e-3
+    # an eager call after a further update takes the same route
+    W.add_(0.02)
+    o2 = ops.gemm(A, W)
+    assert (o2.double() - A.double() @ W.double()).abs().max().item() <= 1e-3
+    assert {s: [h[1].data_ptr() for h in getattr(W, s).values()] for s in slots} == before
+    del keep
+    # a strided status block must be refused, not silently copied (ADVICE r05: the graph would capture a temporary)
+    st = torch.zeros((4, 4), dtype=torch.int32, device=device)
+    dst = torch.zeros((16,), dtype=torch.int32, device=device)
+    with pytest.raises(AssertionError):
+        ops.pack_status(dst, [st[:, :2]])
+
+
+def test_in_place_weight_update_reaches_a_captured_engine(device, setup):
+    """FragmentEngine.refresh_weights: new weight values under live graphs -- every device tensor and packed copy is rewritten in
+    place, the next replay equals an engine built from the new weights (same capacities: same launch plans, bit for bit)."""
+    from d3feat_amd.engine import FragmentEngine
+    cfg, W, limits = setup
+    raw = torch.from_numpy(_frag(11, 30000)).to(device)
+    eng = FragmentEngine(cfg, W, limits, raw_cap=40000, n0_cap=10000, slots=1, device=device)
+    p0, d0, s0 = (t.clone() for t in eng.run(raw))
+    rng = np.random.default_rng(5)
+    W2 = {k: (v * (1.0 + 0.1 * rng.standard_normal(v.shape))).astype(np.float32) if not k.endswith("kernel_points") else v
+          for k, v in W.items()}
+    n = eng.refresh_weights(W2)
+    assert n > 0
+    p1, d1, s1 = (t.clone() for t in eng.run(raw))
+    assert eng.fallbacks == 0
+    ref = FragmentEngine(cfg, W2, limits, raw_cap=40000, n0_cap=10000, slots=1, device=device)
+    p2, d2, s2 = ref.run(raw)
+    assert torch.equal(p1, p2) and torch.equal(d1, d2) and torch.equal(s1, s2)
+    assert (d1 - d0).abs().max().item() > 1e-3            # the update was really seen
+    with pytest.raises(ValueError):
+        k = next(k for k in W if k.endswith("kernel_points"))
+        eng.refresh_weights({k: W[k] + 1.0})

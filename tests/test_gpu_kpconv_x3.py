@@ -102,3 +102,38 @@ def test_split_contraction_epilogue_and_capacity_rows(device):
     res = torch.from_numpy(rng.standard_normal((pts.shape[0], 64)).astype(np.float32)).to(device)
     x3, f32 = _both(ops, pts, pts, nb, f, kp, W, 0.03, col_scale=cs, col_shift=ch, residual=res, leaky=True)
     assert (x3 - f32).abs().max().item() <= 2e-6 * max(1.0, f32.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,num_kp,influence,mode", [
+    (32, 4, "linear", "sum"), (32, 6, "gaussian", "sum"), (32, 13, "linear", "closest"), (32, 15, "constant", "sum"),
+    (32, 15, "gaussian", "closest"), (64, 6, "linear", "sum"), (64, 13, "gaussian", "closest"), (128, 4, "constant", "closest")])
+def test_split_contraction_generic_modes_against_the_oracle(device, coracle, cin, num_kp, influence, mode):
+    """with KP_X3 on, KPConv_ops sends EVERY Cin = Cout = 32 / 64 / 128 call through the operand-split fused kernels --
+    also the generic instances (num_kp != 15: partial passes of the split tile, other influences / aggregations) that the
+    production model never reaches.  Each is checked here against the float64-free CPU oracle (oracle/network_np.KPConv_ops =
+    kernels/convolution_ops.py:161-255) and against the fp32 MFMA form of the same kernel."""
+    from d3feat_amd import ops
+    from d3feat_amd.kernels import convolution_ops as conv_ops
+    from oracle import network_np as onp
+    s0 = surface_cloud(40 + num_kp, n_raw=12000)
+    rng = np.random.default_rng(100 * cin + num_kp)
+    lens = np.asarray([len(s0)], np.int32)
+    nb = coracle.batch_neighbors(s0, s0, lens, lens, np.float32(0.075))[:, :34].astype(np.int32)
+    f = rng.standard_normal((len(s0), cin)).astype(np.float32)
+    W = (rng.standard_normal((num_kp, cin, cin)) * np.sqrt(2.0 / (num_kp * cin))).astype(np.float32)
+    KP = (rng.standard_normal((num_kp, 3)) * 0.03).astype(np.float32)
+    KP[0] = 0
+    want = onp.KPConv_ops(s0, s0, nb, f, KP, W, 0.03, influence, mode).numpy()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    keep = ops.KP_X3
+    try:
+        ops.KP_X3 = True
+        x3 = conv_ops.KPConv_ops(t(s0), t(s0), t(nb), t(f), KP, t(W), 0.03, influence, mode).cpu().numpy()
+        ops.KP_X3 = False
+        f32 = conv_ops.KPConv_ops(t(s0), t(s0), t(nb), t(f), KP, t(W), 0.03, influence, mode).cpu().numpy()
+    finally:
+        ops.KP_X3 = keep
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(x3 - want).max() <= 1e-4 * scale, np.abs(x3 - want).max()
+    assert np.abs(f32 - want).max() <= 1e-4 * scale
+    assert np.abs(x3 - f32).max() <= 5e-6 * scale

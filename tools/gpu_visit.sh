@@ -70,6 +70,15 @@ pmc)
   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json 2> $OUT/pmc_summary.err
   head -c 600 $OUT/hbm_traffic.json
   find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" -size +2M -delete;;
+mfma)   # matrix-pipe counters of the MFMA kernels (ONE --pmc pass with --kernel-trace only; tools/pmc_mfma.py)
+  cd /tmp
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN > /dev/null 2> $OUT/pmc_mfma.err
+  cd $REPO
+  python tools/pmc_mfma.py $OUT/pmc_mfma > $OUT/mfma_counters.json 2> $OUT/pmc_mfma_summary.err
+  head -c 1500 $OUT/mfma_counters.json; tail -3 $OUT/pmc_mfma.err
+  find $OUT/pmc_mfma -name "*.csv" -size +2M -delete;;
+sq:*)   # SQ / cache counters of selected kernels on the graph engine's F = 4 shapes:  sq:<kernel-regex>
+  BENCH_ARGS="--steps 8 --warmup 1 --batch 4 --slots 1 $LEAN" bash tools/pmc_kernel.sh $TAG/sq "${SEC#sq:}" 12 > $OUT/sq_counters.txt 2>&1; cat $OUT/sq_counters.txt | cut -c1-600;;
 proto)
   for f in gemm_bf16x3 mfma_rate; do
     [ -x tools/ubench/$f.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/ubench/$f.hip -o tools/ubench/$f.bin
