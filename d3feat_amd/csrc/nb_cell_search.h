@@ -1,29 +1,35 @@
-// Full-list radius search, round 6: ONE WAVEFRONT PER QUERY, the stencil shared by the queries of a cell, ordering on 32-bit keys.
+// Full-list radius search, round 6: ONE WAVEFRONT PER QUERY for the distance tests, the stencil shared by the queries of a cell,
+// then the rows of SIXTEEN queries ordered at once, four lanes per query, on 32-bit keys held in registers.
 // (included by radius_neighbors.hip; semantics in its header: d2 = (dx*dx + dy*dy) + dz*dz in fp32 without FMA, strict d2 < r2,
 // rows ascending by (d2, index) -- neighbors.cpp:125-208 / :211-332.)
 //
-// Why (profiles/r06_experiments.txt n1): SQ counters of the 16-lanes-per-query kernel at level 0 (235 k queries) show 921 vector
-// + 378 scalar instructions per wavefront of four queries and the vector pipe busy for the whole launch -- the kernel is issue
-// bound, not latency bound: (a) every candidate slot of every query pays the 9-run lane -> run select chain (16 instructions +
-// hazard nops), (b) the 64-key ordering network moves 64-bit (d2, index) keys: two cross-lane moves, a three-part compare and two
-// selects per compare-exchange, four keys per lane.  Here instead:
-//   * a wavefront takes Q consecutive queries; the queries' cells, batch elements and coordinates are computed ONCE for the
-//     wavefront, one query per lane, and then read lane by lane (v_readlane): everything about the current query is scalar;
+// Why (profiles/r06_experiments.txt n1-n6): SQ counters of the 16-lanes-per-query kernel at level 0 (235 k queries) show 1105
+// vector + 443 scalar instructions per wavefront of four queries with the vector pipe busy for the whole launch (a wave64 vector
+// instruction occupies its SIMD for 4 cycles): the kernel is issue bound, not latency bound.  (a) every candidate slot of every query
+// pays the 9-run lane -> run select chain (16 instructions + hazard nops), (b) the 64-key ordering network moves 64-bit
+// (d2, index) keys across lanes: two cross-lane moves, a three-part compare and two selects per compare-exchange.  Here instead:
+//   * a wavefront takes up to 16 consecutive queries; their cells, batch elements and coordinates are computed ONCE, one query per
+//     lane, and then read lane by lane (v_readlane): everything about the current query is scalar;
 //   * queries that ARE the supports come in cell order, so consecutive queries share their 27-cell stencil: its 9 runs are
-//     resolved, mapped lane -> run and loaded into registers (4 candidates per lane: 256 per chunk) once per CELL; a query of the
-//     same cell costs two 64-wide distance tests and nothing else.  (Queries in any other order reload per query.)
-//   * hits are compacted by ballot + mbcnt into one {d2, index} array per wavefront in LDS;
-//   * ordering: key = (d2 bits with the low 6 mantissa bits replaced by the hit's slot): ONE 32-bit key per lane, a 64-lane
-//     bitonic network of v_min_u32 / v_max_u32 (partners through DPP for distances 1, 2, 8, ds_swizzle for 4, 16, ds_bpermute for
-//     32): 3 vector instructions per stage instead of ~36.  The truncation is checked, never trusted: if two hits of a query agree
-//     in the upper 26 bits of d2 (that includes every exact tie) the query is ordered by exact rank counting over the LDS array
-//     instead (about 0.2 % of the queries of a 3DMatch level) -- the result is always the exact (d2, index) order.
-//   * more than 64 hits (dense clouds): the same rank counting, any count up to `cap`.
+//     resolved, mapped lane -> run and loaded into registers (6 candidates per lane: 384 per chunk) once per CELL; a query of the
+//     same cell costs two or three 64-wide distance tests and nothing else.  (Queries in any other order reload per query.)
+//   * hits are compacted by ballot + mbcnt into one {d2, index} array per wavefront in LDS and, when there are at most 64 (all but
+//     ~0.1 % of the queries of a 3DMatch pyramid), copied to the query's own 64-entry list;
+//   * ordering, after the last query: lane = (query, quarter); each lane loads 16 entries of its query's list and builds the keys
+//     (d2 bits with the low 6 mantissa bits replaced by the entry's slot).  The 64 keys of a query are sorted by a bitonic network in
+//     its mirrored form (every comparator puts the smaller key at the lower position: no direction flags): 18 of its 21 stages pair
+//     registers of ONE lane -- v_min_u32 + v_max_u32, two instructions per comparator for sixteen queries at once -- and three
+//     stages pair lanes of a quad through DPP.  27 vector instructions per query instead of ~150.
+//     The truncation is checked, never trusted: if two neighbouring keys of a sorted list agree in the upper 26 bits of d2 (that
+//     includes every exact tie) the query is ordered by exact rank counting over its list instead (~0.3 % of the queries) -- the
+//     result is always the exact (d2, index) order.  Padding entries carry distinct keys above every real one.
+//   * more than 64 hits (dense clouds): a 128-key network over the wavefront (two keys per lane), beyond that the same rank
+//     counting, any count up to `cap`.
 #pragma once
 
-#define NBC_SLOTS 4                      // candidates per lane in registers
+#define NBC_SLOTS 6                      // candidates per lane in registers
 #define NBC_CHUNK (64 * NBC_SLOTS)       // candidates per chunk
-#define NBC_QMAX 32                      // queries per wavefront (one per lane in the prologue)
+#define NBC_QMAX 32                      // queries per wavefront (ordered in batches of eight, eight lanes each)
 
 template <int J>
 __device__ __forceinline__ unsigned nbc_xor_lane(unsigned v, int lane) {
@@ -61,17 +67,6 @@ __device__ __forceinline__ void nbc_stage(unsigned& k, int lane) {
         asm volatile("s_xnor_b64 %0, %1, %2" : "=s"(keep_min) : "s"(nbc_lane_bit(ik)), "s"(nbc_lane_bit(ij)) : "scc");
     k = __builtin_amdgcn_inverse_ballot_w64(keep_min) ? mn : mx;
 }
-// 64 keys, one per lane, ascending over the lanes
-__device__ __forceinline__ void nbc_bitonic64(unsigned& k, int lane) {
-#define NBC_ST(K_, J_) nbc_stage<K_, J_, 0>(k, lane)
-    NBC_ST(2, 1);
-    NBC_ST(4, 2); NBC_ST(4, 1);
-    NBC_ST(8, 4); NBC_ST(8, 2); NBC_ST(8, 1);
-    NBC_ST(16, 8); NBC_ST(16, 4); NBC_ST(16, 2); NBC_ST(16, 1);
-    NBC_ST(32, 16); NBC_ST(32, 8); NBC_ST(32, 4); NBC_ST(32, 2); NBC_ST(32, 1);
-    NBC_ST(64, 32); NBC_ST(64, 16); NBC_ST(64, 8); NBC_ST(64, 4); NBC_ST(64, 2); NBC_ST(64, 1);
-#undef NBC_ST
-}
 // 128 keys, two per lane (element lane + 64 * slot), ascending: k0 ends up holding elements 0..63
 __device__ __forceinline__ void nbc_bitonic128(unsigned& k0, unsigned& k1, int lane) {
 #define NBC_ST(K_, J_) do { nbc_stage<K_, J_, 0>(k0, lane); nbc_stage<K_, J_, 1>(k1, lane); } while (0)
@@ -89,6 +84,59 @@ __device__ __forceinline__ void nbc_bitonic128(unsigned& k0, unsigned& k1, int l
 __device__ __forceinline__ int nbc_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float nbc_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// ---- the 64 keys of a query in the registers of eight lanes: element e = 8 * part + r (part = lane & 7, r = register) --------
+// Mirrored bitonic network: the first step of the merge of block size K pairs e with e ^ (K - 1), the following steps e with e ^ J
+// (J = K / 4 ... 1); every comparator leaves the smaller key at the lower position.  15 of the 21 steps pair registers of one lane
+// (v_min_u32 + v_max_u32 per comparator, eight queries at once), six pair lanes of the group through DPP.
+#define NBC_GROUP 8                      // lanes per query in the ordering phase
+#define NBC_BATCH 8                      // queries ordered at once (64 / NBC_GROUP)
+#define NBC_CE(A_, B_) do { const unsigned lo_ = min(k[A_], k[B_]), hi_ = max(k[A_], k[B_]); k[A_] = lo_; k[B_] = hi_; } while (0)
+template <int K>
+__device__ __forceinline__ void nbc_g_mirror(unsigned (&k)[8]) {            // K <= 8: both elements in this lane
+#pragma unroll
+    for (int base = 0; base < 8; base += K)
+#pragma unroll
+        for (int t = 0; t < K / 2; ++t) NBC_CE(base + t, base + K - 1 - t);
+}
+template <int J>
+__device__ __forceinline__ void nbc_g_clean(unsigned (&k)[8]) {             // J <= 4
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if ((r & J) == 0) NBC_CE(r, r | J);
+}
+// partner in another lane of the group: lane ^ PX, register MIRROR ? 7 - r : r; the lane with the lower part keeps the smaller key
+template <int PX, bool MIRROR>
+__device__ __forceinline__ void nbc_g_cross(unsigned (&k)[8]) {
+    // lane ^ 1: quad_perm [1,0,3,2]; ^ 2: quad_perm [2,3,0,1]; ^ 3: quad_perm [3,2,1,0]; ^ 7: row_half_mirror
+    constexpr int ctrl = PX == 1 ? 0xB1 : PX == 2 ? 0x4E : PX == 3 ? 0x1B : 0x141;
+    // lanes whose part has the highest bit of PX clear
+    constexpr unsigned long long lower = PX == 1 ? 0x5555555555555555ull : (PX == 2 || PX == 3) ? 0x3333333333333333ull : 0x0F0F0F0F0F0F0F0Full;
+    unsigned nk[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned p = (unsigned)__builtin_amdgcn_mov_dpp((int)k[MIRROR ? 7 - r : r], ctrl, 0xF, 0xF, true);
+        const unsigned mn = min(k[r], p), mx = max(k[r], p);
+        nk[r] = __builtin_amdgcn_inverse_ballot_w64(lower) ? mn : mx;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) k[r] = nk[r];
+}
+__device__ __forceinline__ void nbc_group_sort64(unsigned (&k)[8]) {
+    nbc_g_mirror<2>(k);
+    nbc_g_mirror<4>(k); nbc_g_clean<1>(k);
+    nbc_g_mirror<8>(k); nbc_g_clean<2>(k); nbc_g_clean<1>(k);
+    nbc_g_cross<1, true>(k);                                                 // K = 16: e ^ 15
+    nbc_g_clean<4>(k); nbc_g_clean<2>(k); nbc_g_clean<1>(k);
+    nbc_g_cross<3, true>(k);                                                 // K = 32: e ^ 31
+    nbc_g_cross<1, false>(k);                                                // J = 8
+    nbc_g_clean<4>(k); nbc_g_clean<2>(k); nbc_g_clean<1>(k);
+    nbc_g_cross<7, true>(k);                                                 // K = 64: e ^ 63
+    nbc_g_cross<2, false>(k);                                                // J = 16
+    nbc_g_cross<1, false>(k);                                                // J = 8
+    nbc_g_clean<4>(k); nbc_g_clean<2>(k); nbc_g_clean<1>(k);
+}
+#undef NBC_CE
+
 template <bool SORTED_Q>
 __global__ void __launch_bounds__(256)
 nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
@@ -102,12 +150,12 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-    // per wavefront: the hits of the current query {d2 bits, support index} [cap], then the finished rows of its Q queries
-    // [Q][width]: rows are written to memory after the last query -- a store inside the query loop would be waited for by the
-    // next query's `s_waitcnt vmcnt(0)` (loads and stores retire through one counter): a write round trip per query
-    const int wave_words = (2 * cap + Q * width + 1) & ~1;      // (8-byte aligned hit records)
-    uint2* hk = (uint2*)((int*)smem + (size_t)wave * wave_words);
-    int* orow = (int*)(hk + cap);
+    // per wavefront: the hits of the current query {d2 bits, support index} [cap], then one 64-entry list of d2 bits and one of
+    // indices for each query of the batch being collected [8][64]
+    char* wbase = smem + (size_t)wave * ((size_t)cap * 8 + NBC_BATCH * 64 * 8);
+    uint2* hk = (uint2*)wbase;
+    unsigned* ld2 = (unsigned*)(wbase + (size_t)cap * 8);
+    int* lidx = (int*)(ld2 + NBC_BATCH * 64);
     const bool staged = B <= NB_EL_LDS;
     if (staged) {
         constexpr int W = (int)(sizeof(NbElem) / sizeof(int));
@@ -165,8 +213,9 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
     int off0 = 0, off1 = 0, off2 = 0, off3 = 0, off4 = 0, off5 = 0, off6 = 0, off7 = 0, off8 = 0;
     int nmax = 0;
     bool over = false;
+    int vn = -1;                                 // lane i: hits of query i when its row is still to be ordered from its list (<= 64)
 
-    // candidates [c0, c0 + 256) of the current stencil -> cand[]; a lane beyond the list holds a point at 3e38 (its d2 is +inf)
+    // candidates [c0, c0 + NBC_CHUNK) of the current stencil -> cand[]; a lane beyond the list holds a point at 3e38 (d2 = +inf)
 #define NBC_LOAD_CHUNK(C0_)                                                                                    \
     do {                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < NBC_SLOTS; ++u) {                                                \
@@ -182,7 +231,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         }                                                                                                      \
     } while (0)
 
-    // measurement aid (prof != NULL): shader-clock cycles per phase, summed and maximised over the wavefronts
+    // measurement aid (prof != NULL): shader-clock cycles per phase, one record per wavefront
     unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
 #define NBC_T0() do { if (prof) t0 = __builtin_amdgcn_s_memtime(); } while (0)
 #define NBC_T1(P_) do { if (prof) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tp[P_] += t1_ - t0; t0 = t1_; } } while (0)
@@ -239,58 +288,107 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         NBC_T1(2);
         nmax = max(nmax, n);
         over = over || (n > cap);
-        const int m = min(n, cap);
-        int* row = orow + i * width;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        bool need_exact = true;
         if (n <= 64) {
-            // one 32-bit key per lane: upper 26 bits of d2 | slot; padding keys sort last
-            unsigned k = 0xFFFFFFFFu;
-            if (lane < m) k = (hk[lane].x & 0xFFFFFFC0u) | (unsigned)lane;
-            if (!(dbg & 1)) nbc_bitonic64(k, lane);
-            // two hits of the row within 2^-17 of each other (or tied): the exact path decides
-            const unsigned kn = (unsigned)__shfl_down((int)k, 1);
-            const bool clash = (lane + 1 < m) && (lane < width) && ((k >> 6) == (kn >> 6));
-            need_exact = !(dbg & 2) && __ballot(clash) != 0ull;
-            if (!need_exact) {
-                const int mw = min(m, width);
-                if (lane < mw) row[lane] = (int)hk[k & 63u].y;
+            // the query's own list: its hits, then padding entries whose keys are distinct and above every real key (finite
+            // d2 bits are below 0x7F800000); ordered after the last query, sixteen queries at a time
+            uint2 h = make_uint2(0x80000000u | ((unsigned)lane << 6), 0u);
+            if (lane < n) h = hk[lane];
+            ld2[(i & (NBC_BATCH - 1)) * 64 + lane] = h.x;
+            lidx[(i & (NBC_BATCH - 1)) * 64 + lane] = (int)h.y;
+            vn = (lane == i) ? n : vn;
+        } else {
+            // ---- dense neighbourhood (rare): ordered now, by the whole wavefront, from the hit array ----------------------
+            const int m = min(n, cap);
+            int* row = out + (size_t)nbc_rl(vqi, i) * ld;
+            bool need_exact = true;
+            if (n <= 128 && n <= cap && width < 64) {
+                // 128 keys, two per lane (upper 25 bits of d2 | slot); the row is the head of elements 0..63
+                unsigned k0 = (hk[lane].x & 0xFFFFFF80u) | (unsigned)lane, k1 = 0xFFFFFFFFu;
+                if (lane + 64 < m) k1 = (hk[lane + 64].x & 0xFFFFFF80u) | (unsigned)(lane + 64);
+                nbc_bitonic128(k0, k1, lane);
+                const unsigned kn = (unsigned)__shfl_down((int)k0, 1);
+                const bool clash = (lane < width) && ((k0 >> 7) == (kn >> 7));   // (width < 64 <= m: lane + 1 is a real element)
+                need_exact = __ballot(clash) != 0ull;
+                if (!need_exact && lane < width) row[lane] = (int)hk[k0 & 127u].y;
             }
-        } else if (n <= 128 && n <= cap && width < 64) {
-            // dense neighbourhoods: 128 keys, two per lane (upper 25 bits of d2 | slot); the row is the head of elements 0..63
-            unsigned k0 = (hk[lane].x & 0xFFFFFF80u) | (unsigned)lane, k1 = 0xFFFFFFFFu;
-            if (lane + 64 < m) k1 = (hk[lane + 64].x & 0xFFFFFF80u) | (unsigned)(lane + 64);
-            if (!(dbg & 1)) nbc_bitonic128(k0, k1, lane);
-            const unsigned kn = (unsigned)__shfl_down((int)k0, 1);
-            const bool clash = (lane < width) && ((k0 >> 7) == (kn >> 7));       // (width < 64 <= m: lane + 1 is a real element)
-            need_exact = !(dbg & 2) && __ballot(clash) != 0ull;
-            if (!need_exact && lane < width) row[lane] = (int)hk[k0 & 127u].y;
-        }
-        NBC_T1(3);
-        if (need_exact && !(dbg & 4)) {
-            if ((dbg & 32) && lane == 0) { atomicAdd(&status[0], 1); atomicMax(&status[1], m); }
-            // exact rank counting over the LDS array: rank = number of hits with a smaller (d2, index) key (keys are unique)
-            for (int e0 = 0; e0 < m; e0 += 64) {
-                const int ei = e0 + lane;
-                const uint2 mine = hk[ei < m ? ei : 0];
-                int rank = 0;
-                for (int j = 0; j < m; ++j) {
-                    const uint2 o = hk[j];
-                    rank += (o.x < mine.x || (o.x == mine.x && (int)o.y < (int)mine.y)) ? 1 : 0;
+            if (need_exact) {
+                // exact rank counting over the hit array: rank = number of hits with a smaller (d2, index) key (keys are unique)
+                for (int e0 = 0; e0 < m; e0 += 64) {
+                    const int ei = e0 + lane;
+                    const uint2 mine = hk[ei < m ? ei : 0];
+                    int rank = 0;
+                    for (int j = 0; j < m; ++j) {
+                        const uint2 o = hk[j];
+                        rank += (o.x < mine.x || (o.x == mine.x && (int)o.y < (int)mine.y)) ? 1 : 0;
+                    }
+                    if (ei < m && rank < width) row[rank] = (int)mine.y;
                 }
-                if (ei < m && rank < width) row[rank] = (int)mine.y;
             }
+            for (int j = m + lane; j < width; j += 64) row[j] = pad;
         }
-        for (int j = m + lane; j < width; j += 64) row[j] = pad;
         __builtin_amdgcn_wave_barrier();            // the next query's hits overwrite the array
+        NBC_T1(3);
+        if ((i & (NBC_BATCH - 1)) != NBC_BATCH - 1 && i != cnt - 1) continue;
+        // ---- ordering of the batch's rows: lane = (query of the batch, eighth of its list) --------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int i0 = i & ~(NBC_BATCH - 1);         // first query of the batch
+        const int qd = lane >> 3, part = lane & 7;
+        const int nqd = __shfl(vn, i0 + qd), qiq = __shfl(vqi, i0 + qd);    // hits / row of this lane's query (-1: nothing to do)
+        unsigned k[8];
+        {
+            const uint4* src = (const uint4*)(ld2 + qd * 64 + part * 8);
+            const uint4 v0 = src[0], v1 = src[1];
+            k[0] = (v0.x & 0xFFFFFFC0u) | (unsigned)(part * 8 + 0); k[1] = (v0.y & 0xFFFFFFC0u) | (unsigned)(part * 8 + 1);
+            k[2] = (v0.z & 0xFFFFFFC0u) | (unsigned)(part * 8 + 2); k[3] = (v0.w & 0xFFFFFFC0u) | (unsigned)(part * 8 + 3);
+            k[4] = (v1.x & 0xFFFFFFC0u) | (unsigned)(part * 8 + 4); k[5] = (v1.y & 0xFFFFFFC0u) | (unsigned)(part * 8 + 5);
+            k[6] = (v1.z & 0xFFFFFFC0u) | (unsigned)(part * 8 + 6); k[7] = (v1.w & 0xFFFFFFC0u) | (unsigned)(part * 8 + 7);
+        }
+        if (!(dbg & 1)) nbc_group_sort64(k);
+        // neighbouring keys that agree in the upper 26 bits of d2 (two hits within 2^-17 of each other, or tied): the exact path
+        // decides that query.  (k[7] against the next lane's k[0]; the last lane of a group has no successor)
+        bool clash = false;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) clash = clash || ((k[r] ^ k[r + 1]) < 64u);
+        const unsigned nx = (unsigned)__builtin_amdgcn_mov_dpp((int)k[0], 0x101, 0xF, 0xF, true);    // row_shl:1: lane + 1's k[0]
+        clash = clash || (part != 7 && (k[7] ^ nx) < 64u);
+        if (dbg & 2) clash = false;
+        const bool live = nqd >= 0 && i0 + qd <= i;
+        const unsigned long long cm = __ballot(clash && live);
+        const bool redo = ((cm >> (lane & 56)) & 0xFFull) != 0ull;       // some lane of this group saw a clash
+        if (live && !redo) {
+            int* row = out + (size_t)qiq * ld;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int e = part * 8 + r;
+                if (e < width) row[e] = (e < nqd) ? lidx[qd * 64 + (int)(k[r] & 63u)] : pad;
+            }
+            for (int e = 64 + part; e < width; e += 8) row[e] = pad;         // (rows wider than the list: padding only)
+        }
         NBC_T1(4);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i < cnt; ++i) {
-        int* grow = out + (size_t)nbc_rl(vqi, i) * ld;
-        for (int j = lane; j < width; j += 64) grow[j] = orow[i * width + j];
+        // ---- exact rank counting over the list of every query that saw a clash (whole wavefront per query) ------------------
+        unsigned long long todo = cm;
+        while (todo && !(dbg & 4)) {
+            const int g = (int)(__builtin_ctzll(todo) >> 3);
+            todo &= ~(0xFFull << (8 * g));
+            const int m = nbc_rl(vn, i0 + g);
+            int* row = out + (size_t)nbc_rl(vqi, i0 + g) * ld;
+            const unsigned md = ld2[g * 64 + (lane < m ? lane : 0)];
+            const int mi = lidx[g * 64 + (lane < m ? lane : 0)];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) {
+                const unsigned od = ld2[g * 64 + j];
+                const int oi = lidx[g * 64 + j];
+                rank += (od < md || (od == md && oi < mi)) ? 1 : 0;
+            }
+            if (lane < m && rank < width) row[rank] = mi;
+            for (int j = m + lane; j < width; j += 64) row[j] = pad;
+        }
+        // the batch is done: its queries must not be ordered again with the next batch's lists
+        vn = (lane >= i0 && lane <= i) ? -1 : vn;
+        __builtin_amdgcn_wave_barrier();
     }
 #undef NBC_LOAD_CHUNK
     NBC_T1(5);

@@ -560,21 +560,20 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
     const bool cell_form = !(cf_env && atoi(cf_env) == 0);
     if (!first_only && cell_form) {
         cap = (cap + 1) & ~1;
-        // queries per wavefront: consecutive queries share a stencil when they come in cell order, but a wavefront works through
-        // its queries one after the other -- a small launch keeps one query per wavefront (all of them in flight at once)
+        // queries per wavefront: consecutive queries share a stencil when they come in cell order, and sixteen rows are ordered at
+        // once -- but a wavefront works through its queries one after the other: a small launch keeps fewer per wavefront (all of
+        // them in flight at once)
         const char* q_env = getenv("D3F_NBC_Q");
         const int q_forced = q_env ? atoi(q_env) : 0;
-        int Q = q_forced > 0 ? q_forced : Nq / 8192;
+        int Q = q_forced > 0 ? q_forced : Nq / 2048;
         Q = Q < 1 ? 1 : (Q > 16 ? 16 : Q);
         if (Q > NBC_QMAX) Q = NBC_QMAX;
-        while (Q > 1 && (size_t)4 * (2 * cap + Q * width + 1) * sizeof(int) > 48 * 1024) Q >>= 1;   // finished rows wait in LDS
         const char* dbg_env = getenv("D3F_NBC_DBG");       // measurement only: skip phases (results are then wrong)
         const int dbg = dbg_env ? atoi(dbg_env) : 0;
-        const char* prof_env = getenv("D3F_NBC_PROF");     // measurement only: device address of 16 u64 counters (hex)
+        const char* prof_env = getenv("D3F_NBC_PROF");     // measurement only: device address of 8 u64 words per wavefront (hex)
         unsigned long long* prof = prof_env ? (unsigned long long*)strtoull(prof_env, nullptr, 16) : nullptr;
         const int blocks = d3f_cdiv(d3f_cdiv(Nq, Q), 4);
-        const size_t lds = (size_t)4 * ((2 * cap + Q * width + 1) & ~1) * sizeof(int);
-        if (lds > 64 * 1024) return D3F_ERR_ARG;      // (width > ~3000 columns: not a neighbourhood matrix)
+        const size_t lds = (size_t)4 * ((size_t)cap * 8 + NBC_BATCH * 64 * 8);
         if (queries_are_supports)
             nb_cell_search_kernel<true><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
                                                                       pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof);
