@@ -34,6 +34,7 @@ SIGNATURES = {
     "d3f_neighbor_grid_order_offset": (_sz, [_i, _i]),
     "d3f_neighbor_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp]),
     "d3f_neighbor_grid_search": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "d3f_neighbor_grid_nearest": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _vp, _sz, _vp, _i, _i, _i, _f, _vp]),
     "d3f_row_positive": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp,
                                   _vp, _i, _vp]),

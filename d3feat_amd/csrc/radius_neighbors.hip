@@ -225,7 +225,7 @@ __device__ __forceinline__ void
 nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
                const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                const float4* __restrict__ sorted,
-               const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
+               const float4* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
                int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QPB = 64 * NB_WAVES_PER_BLOCK / LPQ;   // queries per workgroup
@@ -255,8 +255,8 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
     // (order -> point) chain of dependent loads: one round trip less on the kernel's critical path
     int qi = wq;
     float qx, qy, qz;
-    if (qorder) {
-        const float4 me = sorted[wq];
+    if (qorder) {               // the cell-sorted records of the grid the queries were sorted by (their own, or this one)
+        const float4 me = qorder[wq];
         qi = __float_as_int(me.w);
         qx = me.x; qy = me.y; qz = me.z;
     } else {
@@ -439,13 +439,14 @@ __global__ void __launch_bounds__(64 * NB_WAVES_PER_BLOCK)
 nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                  const float4* __restrict__ sorted,
-                 const int* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
+                 const float4* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
                  int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
     nb_search_body<FIRST_ONLY, LPQ, HINT>(q, Nq, qlens, B, el, cell_start, cell_base, sorted, qorder, r2, pad, ns_dev, out, ld, width,
                                           cap, status, want_kmax, nn_hint);
 }
 
 #include "nb_cell_search.h"
+#include "nb_nearest.h"
 
 // ------------------------------------------------------------------------------------------------
 // cells the grid may use: 4 per support (surface clouds occupy ~0.3 cells per point at cell edge = radius; a sparser cloud gets
@@ -537,51 +538,63 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
     return D3F_OK;
 }
 
-extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
-                                        const int* q_lens_dev, int B, float radius, int queries_are_supports,
-                                        int* out, int ld, int width, int pad_value, int cap, int first_only,
-                                        float nn_hint, int reset_status, int* status_dev, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
-    if (!(nn_hint >= 0.f) || nn_hint >= radius) nn_hint = 0.f;        // a hint only helps below the radius
-    if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
-    if (!grid || !status_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
-    if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
-    if (reset_status & 1) { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
-    const int want_kmax = (reset_status & D3F_NB_NO_KMAX) ? 0 : 1;
-    if (Nq == 0) return D3F_OK;
-    NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
-    if (!g.ok) return D3F_ERR_WORKSPACE;
+// ---- the searches of a built grid: one dispatcher ---------------------------------------------------------------------------------
+// qsorted: cell-sorted records {x, y, z, index} of a grid built over the QUERIES -- the visiting order (neighbouring wavefronts /
+// lane groups then read the same support runs); the grid's own records when the queries ARE its supports; NULL: plain order.
+// Three kernels, chosen by what is asked and by the size of the launch (profiles/r06_experiments.txt n10; us per launch at the
+// engine's F = 4 shapes, stand-alone):
+//   full rows, queries = supports   nb_cell_search_kernel (one wavefront per query, stencil shared by a cell, rows ordered eight
+//                                   at a time in registers) from 40 k queries on (235 k: 102 -> 82) and below 6 k (the lane-group
+//                                   kernel has a ~18 us floor there: 3.6 k: 18.8 -> 13.1, 0.8 k: 19.5 -> 6.8); in between the
+//                                   launch is less than a round of wavefronts and the lane-group kernel's four queries per
+//                                   wavefront keep more loads in flight (14.5 k: 20.7 against 28.0)
+//   full rows, other queries        nb_search_kernel (16 / 32 lanes per query): without a shared stencil a wavefront per query only
+//                                   adds latency (58 k pool queries: 35 against 53)
+//   nearest only, no Kmax           nb_nearest_kernel (four lanes per query, a stencil row per lane) from 40 k queries on
+//                                   (235 k: 59 -> 48 with the queries' own cell order, 58 k: 25 -> 20); nb_search_kernel below
+// D3F_NB_CELL / D3F_NB_NEAREST = 0: never, = 2: always (A/B measurements; read per call so that one process can switch).
+static int nb_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int nb_search_dispatch(const NbGrid& g, const float* queries, int Nq, const int* q_lens_dev, int B, float radius,
+                              const float4* qsorted, bool queries_are_supports, int* out, int ld, int width, int pad_value, int cap,
+                              int first_only, float nn_hint, int want_kmax, int* status_dev, hipStream_t stream) {
     const float r2 = radius * radius;
-    const int* qorder = queries_are_supports ? g.order : nullptr;
-    // full lists: one wavefront per query, the stencil shared by the queries of a cell (nb_cell_search.h); D3F_NB_CELL=0 keeps the
-    // 16 / 32-lanes-per-query kernel (A/B measurements)
-    const char* cf_env = getenv("D3F_NB_CELL");      // (read per call: a measurement script switches forms in one process)
-    const bool cell_form = !(cf_env && atoi(cf_env) == 0);
-    if (!first_only && cell_form) {
-        cap = (cap + 1) & ~1;
-        // queries per wavefront: consecutive queries share a stencil when they come in cell order, and sixteen rows are ordered at
-        // once -- but a wavefront works through its queries one after the other: a small launch keeps fewer per wavefront (all of
-        // them in flight at once)
-        const char* q_env = getenv("D3F_NBC_Q");
-        const int q_forced = q_env ? atoi(q_env) : 0;
-        int Q = q_forced > 0 ? q_forced : Nq / 2048;
-        Q = Q < 1 ? 1 : (Q > 16 ? 16 : Q);
-        if (Q > NBC_QMAX) Q = NBC_QMAX;
-        const char* dbg_env = getenv("D3F_NBC_DBG");       // measurement only: skip phases (results are then wrong)
-        const int dbg = dbg_env ? atoi(dbg_env) : 0;
-        const char* prof_env = getenv("D3F_NBC_PROF");     // measurement only: device address of 8 u64 words per wavefront (hex)
-        unsigned long long* prof = prof_env ? (unsigned long long*)strtoull(prof_env, nullptr, 16) : nullptr;
-        const int blocks = d3f_cdiv(d3f_cdiv(Nq, Q), 4);
-        const size_t lds = (size_t)4 * ((size_t)cap * 8 + NBC_BATCH * 64 * 8);
-        if (queries_are_supports)
+    if (first_only && !want_kmax) {
+        const int mode = nb_env("D3F_NB_NEAREST", 1);
+        if (mode == 2 || (mode == 1 && Nq >= 40000)) {
+            const int blocks = d3f_cdiv(Nq, 64);
+            if (nn_hint > 0.f)
+                nb_nearest_kernel<true><<<blocks, 256, 0, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted,
+                                                                    r2, pad_value, g.soffs + B, out, ld, width, nn_hint);
+            else
+                nb_nearest_kernel<false><<<blocks, 256, 0, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted,
+                                                                     r2, pad_value, g.soffs + B, out, ld, width, nn_hint);
+            D3F_LAUNCH_CHECK();
+            return D3F_OK;
+        }
+    }
+    if (!first_only && queries_are_supports) {
+        const int mode = nb_env("D3F_NB_CELL", 1);
+        if (mode == 2 || (mode == 1 && (Nq >= 40000 || Nq < 6000))) {
+            cap = (cap + 1) & ~1;
+            // queries per wavefront: consecutive queries share a stencil, and eight rows are ordered at once -- but a wavefront works
+            // through its queries one after the other: a small launch keeps fewer per wavefront (all of them in flight at once)
+            const int q_forced = nb_env("D3F_NBC_Q", 0);
+            int Q = q_forced > 0 ? q_forced : Nq / 2048;
+            Q = Q < 1 ? 1 : (Q > 16 ? 16 : Q);
+            if (Q > NBC_QMAX) Q = NBC_QMAX;
+            const int dbg = nb_env("D3F_NBC_DBG", 0);         // measurement only: skip phases (results are then wrong)
+            const char* prof_env = getenv("D3F_NBC_PROF");     // measurement only: device address of 8 u64 words per wavefront (hex)
+            unsigned long long* prof = prof_env ? (unsigned long long*)strtoull(prof_env, nullptr, 16) : nullptr;
+            const int blocks = d3f_cdiv(d3f_cdiv(Nq, Q), 4);
+            const size_t lds = (size_t)4 * ((size_t)cap * 8 + NBC_BATCH * 64 * 8);
             nb_cell_search_kernel<true><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
                                                                       pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof);
-        else
-            nb_cell_search_kernel<false><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
-                                                                       pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof);
-        D3F_LAUNCH_CHECK();
-        return D3F_OK;
+            D3F_LAUNCH_CHECK();
+            return D3F_OK;
+        }
     }
     // lanes per query: 32 (two queries per wavefront) unless the ordering budget is large (rare, dense clouds)
     cap = (cap + 3) & ~3;   // LDS segments are read four hits at a time
@@ -598,17 +611,56 @@ extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int
 #define D3F_NB(FO_, LPQ_)                                                                                              \
     if (FO_ && nn_hint > 0.f)                                                                                          \
         nb_search_kernel<FO_, LPQ_, FO_><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                             \
-            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
+            queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted, r2, pad_value, g.soffs + B, out, ld, width, \
             kcap, status_dev, want_kmax, nn_hint);                                                                     \
     else                                                                                                               \
     nb_search_kernel<FO_, LPQ_, false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                               \
-        queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qorder, r2, pad_value, g.soffs + B, out, ld, width, \
+        queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted, r2, pad_value, g.soffs + B, out, ld, width, \
         kcap, status_dev, want_kmax, nn_hint)
     if (first_only) { if (lpq == 64) D3F_NB(true, 64); else if (lpq == 32) D3F_NB(true, 32); else D3F_NB(true, 16); }
     else { if (lpq == 64) D3F_NB(false, 64); else if (lpq == 32) D3F_NB(false, 32); else D3F_NB(false, 16); }
 #undef D3F_NB
     D3F_LAUNCH_CHECK();
     return D3F_OK;
+}
+
+extern "C" int d3f_neighbor_grid_nearest(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                                         const int* q_lens_dev, int B, float radius, const void* query_grid, size_t query_grid_bytes,
+                                         int* out, int ld, int width, int pad_value, float nn_hint, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
+    if (!(nn_hint >= 0.f) || nn_hint >= radius) nn_hint = 0.f;        // a hint only helps below the radius
+    if (!grid || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
+    if (Nq == 0) return D3F_OK;
+    NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
+    if (!g.ok) return D3F_ERR_WORKSPACE;
+    const float4* qsorted = nullptr;
+    if (query_grid) {
+        NbGrid qg = nb_carve((void*)query_grid, query_grid_bytes, Nq, B);
+        if (!qg.ok) return D3F_ERR_WORKSPACE;
+        qsorted = qg.sorted;
+    }
+    return nb_search_dispatch(g, queries, Nq, q_lens_dev, B, radius, qsorted, false, out, ld, width, pad_value, 4, 1, nn_hint, 0, nullptr,
+                              stream);
+}
+
+extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                                        const int* q_lens_dev, int B, float radius, int queries_are_supports,
+                                        int* out, int ld, int width, int pad_value, int cap, int first_only,
+                                        float nn_hint, int reset_status, int* status_dev, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
+    if (!(nn_hint >= 0.f) || nn_hint >= radius) nn_hint = 0.f;        // a hint only helps below the radius
+    if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
+    if (!grid || !status_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
+    if (queries_are_supports && Nq != Ns) return D3F_ERR_ARG;
+    if (reset_status & 1) { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
+    const int want_kmax = (reset_status & D3F_NB_NO_KMAX) ? 0 : 1;
+    if (Nq == 0) return D3F_OK;
+    NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
+    if (!g.ok) return D3F_ERR_WORKSPACE;
+    return nb_search_dispatch(g, queries, Nq, q_lens_dev, B, radius, queries_are_supports ? g.sorted : nullptr, queries_are_supports != 0,
+                              out, ld, width, pad_value, cap, first_only, nn_hint, want_kmax, status_dev, stream);
 }
 
 // ---- scoring of rigid-transform hypotheses against a built grid (downstream matching, registration.hip) --------------------

@@ -163,11 +163,13 @@ class Dataset:
                     grid = grids[key] = ops.NeighborGrid(s_, sl_, r_)
                     if getattr(s_, 'order', None) is None:
                         s_.order = grid.order   # cell-sorted visiting order of this level's points (ops._order)
+                        s_.grid = grid          # ... and the grid itself: the visiting order of the searches these points QUERY
                 # one launch per search: issuing the two or three searches of a grid as ONE launch (blockIdx.y = query set) was
                 # measured 5-7 % slower end to end (profiles/r03_experiments.txt x8)
                 for (q, _, ql, _, _, lim, fo, hint, sink, at) in grp:
                     out, status = grid.search(q, ql, lim, cap=cap, first_only=fo, status=status_all[len(pending)],
-                                              reset_status=False, want_kmax=False, nn_hint=hint)
+                                              reset_status=False, want_kmax=False, nn_hint=hint,
+                                              query_grid=getattr(q, 'grid', None) if fo else None)
                     pending.append(status)
                     sink[at] = out
 

@@ -298,11 +298,13 @@ class NeighborGrid:
         self.order = self.mem[off: off + 4 * max(self.Ns, 1)].view(torch.int32)
 
     def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None,
-               reset_status=True, want_kmax=True, nn_hint=0.0):
+               reset_status=True, want_kmax=True, nn_hint=0.0, query_grid=None):
         """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation.  reset_status=False: the caller has
         zeroed `status` (saves one launch per search).  want_kmax=False: status[0] (largest neighbour count) is not maintained
         (callers that allocate a fixed number of columns do not need it; see D3F_NB_NO_KMAX).  nn_hint (first_only): the distance
-        within which the caller expects the nearest support -- a speed hint only, see include/d3feat_amd.h."""
+        within which the caller expects the nearest support -- a speed hint only, see include/d3feat_amd.h.
+        query_grid (first_only without want_kmax): a NeighborGrid built over `queries` themselves -- its cell order becomes the
+        visiting order of the nearest-support kernel (d3f_neighbor_grid_nearest); results do not depend on it."""
         lib = _lib.load()
         queries = _req(queries, torch.float32, "queries", 2).contiguous()
         dev = queries.device
@@ -319,6 +321,19 @@ class NeighborGrid:
         if pad_value is None:
             # BatchOrderedNeighbors pads with the number of supports: known only on the device in capacity mode
             pad_value = _lib.PAD_NUM_SUPPORTS if getattr(self.supports, "n_dev", None) is not None else self.Ns
+        if (first_only and not want_kmax and query_grid is not None and query_grid.Ns == Nq and query_grid.B == self.B
+                and query_grid.supports.data_ptr() == queries.data_ptr()):
+            if reset_status:
+                status.zero_()
+            with _timed("nb_nearest", dict(Nq=Nq, Ns=self.Ns, width=int(width)), dev):
+                rc = lib.d3f_neighbor_grid_nearest(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq, ql.data_ptr(),
+                                                   self.B, self.radius, query_grid.mem.data_ptr(), query_grid.nbytes, out.data_ptr(),
+                                                   ld, int(width), int(pad_value), float(nn_hint), _stream(dev))
+            _lib.check(rc, "neighbor_grid_nearest")
+            o = getattr(queries, "order", None)
+            if o is not None:
+                out.order = o
+            return _tag(out, queries), status
         with _timed("nb_search", dict(Nq=Nq, Ns=self.Ns, width=int(width), first_only=int(bool(first_only))), dev):
             rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
                                               ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),

@@ -163,6 +163,16 @@ int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const 
                              const int* q_lens_dev, int B, float radius, int queries_are_supports,
                              int* out, int ld, int width, int pad_value, int cap, int first_only, float nn_hint,
                              int reset_status, int* status_dev, void* stream);
+/* Column 0 only -- the nearest support inside the radius, ties by the smaller index (neighbors.cpp:125-208 row[0]; the only column
+ * closest_pool reads of the upsampling matrices, models/network_blocks.py:81, datasets/common.py:1375) -- with one lane per query.
+ * Same result as d3f_neighbor_grid_search(first_only = 1); columns 1..width-1 are filled with pad_value; no status words.
+ *   query_grid   optional: a grid built by d3f_neighbor_grid_build over `queries` themselves (any radius; Nq rows capacity, the
+ *                same B): the queries are then visited in ITS cell order, so neighbouring lanes walk the same support runs.
+ *                NULL: plain order.  Results do not depend on it. */
+int d3f_neighbor_grid_nearest(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                              const int* q_lens_dev, int B, float radius, const void* query_grid, size_t query_grid_bytes,
+                              int* out, int ld, int width, int pad_value, float nn_hint, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * KPConv, phase 1: neighbour gather + kernel-point influence + weighted aggregation.

@@ -67,6 +67,7 @@ def main():
         dl *= 2
     r = 0.03 * 2.5
     rows = []
+    qgrid_prev = None
     for l, (p, pl) in enumerate(levels):
         grid = ops.NeighborGrid(p, pl, r)
         rows.append(("L%d build        %7d" % (l, p.shape[0]), lambda p=p, pl=pl, r=r: ops.NeighborGrid(p, pl, r)))
@@ -83,15 +84,20 @@ def main():
             q, ql = levels[l - 1]
             g2 = ops.NeighborGrid(p, pl, r)     # (radius of level l: 2 x the radius of level l - 1, the reference's up_i radius)
             o3 = torch.empty((q.shape[0], 1), dtype=torch.int32, device=dev)
+            qg = qgrid_prev
             rows.append(("L%d up search    %7d" % (l, q.shape[0]),
+                         lambda g2=g2, q=q, ql=ql, o3=o3, st=st, qg=qg, h=1.75 * 0.03 * 2 ** l: g2.search(q, ql, 1, cap=192, first_only=True, out=o3, status=st, reset_status=False,
+                                                                                          want_kmax=False, nn_hint=h, query_grid=qg)))
+            rows.append(("L%d up search-nq %6d" % (l, q.shape[0]),
                          lambda g2=g2, q=q, ql=ql, o3=o3, st=st, h=1.75 * 0.03 * 2 ** l: g2.search(q, ql, 1, cap=192, first_only=True, out=o3, status=st, reset_status=False,
                                                                                           want_kmax=False, nn_hint=h)))
+        qgrid_prev = grid
         if l + 1 < len(levels):
             rows.append(("L%d subsample    %7d" % (l, p.shape[0]), lambda p=p, pl=pl, d=0.06 * 2 ** l: ops.batch_grid_subsample(p, pl, d)))
         r *= 2
     variants = [("default", {})]
     if args.ab:
-        variants.append(("lane-group", {"D3F_NB_CELL": "0"}))
+        variants.append(("lane-group", {"D3F_NB_CELL": "0", "D3F_NB_NEAREST": "0"}))
     for qv in [x for x in args.q.split(",") if x]:
         if ":" in qv:
             variants.append(("Q%s d%s" % tuple(qv.split(":")), {"D3F_NBC_Q": qv.split(":")[0], "D3F_NBC_DBG": qv.split(":")[1]}))
@@ -104,14 +110,14 @@ def main():
             continue
         line = "%-28s" % name
         for vi, (vn, env) in enumerate(variants):
-            for k in ("D3F_NB_CELL", "D3F_NBC_Q", "D3F_NBC_DBG"):
+            for k in ("D3F_NB_CELL", "D3F_NBC_Q", "D3F_NBC_DBG", "D3F_NB_NEAREST"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             t = timeit(fn, iters=args.iters, graph=("search" in name))
             sums[vi] += t
             line += "%12.1f" % t
         print(line)
-    for k in ("D3F_NB_CELL", "D3F_NBC_Q", "D3F_NBC_DBG"):
+    for k in ("D3F_NB_CELL", "D3F_NBC_Q", "D3F_NBC_DBG", "D3F_NB_NEAREST"):
         os.environ.pop(k, None)
     print("%-28s" % "sum (us)" + "".join("%12.1f" % s for s in sums))
     # equality of the two forms on every full search of the pyramid
@@ -126,6 +132,18 @@ def main():
                 b, _ = grid.search(q, ql, limits[l], cap=192)
                 os.environ.pop("D3F_NB_CELL", None)
                 print("L%d %s: forms equal: %s   (rows %d)" % (l, tag, bool(torch.equal(a, b)), q.shape[0]))
+            if l > 0:
+                q, ql = levels[l - 1]
+                g2 = ops.NeighborGrid(p, pl, r)
+                qg = ops.NeighborGrid(q, ql, r / 2)
+                h = 1.75 * 0.03 * 2 ** l
+                os.environ["D3F_NB_NEAREST"] = "0"
+                b, _ = g2.search(q, ql, 1, cap=192, first_only=True, want_kmax=False, nn_hint=h)
+                os.environ.pop("D3F_NB_NEAREST", None)
+                for tag2, kw in (("ordered", dict(query_grid=qg)), ("plain", {}), ("no hint", dict(query_grid=qg, hint0=True))):
+                    hh = 0.0 if kw.pop("hint0", False) else h
+                    a, _ = g2.search(q, ql, 1, cap=192, first_only=True, want_kmax=False, nn_hint=hh, **kw)
+                    print("L%d up (%s): forms equal: %s   (rows %d)" % (l, tag2, bool(torch.equal(a, b)), q.shape[0]))
             r *= 2
 
 
