@@ -732,7 +732,8 @@ def compact_line(res, detail_path=None):
     rf = res.get("roofline")
     if rf:
         r = _pick(rf, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_flops_per_launch", "alg_bytes_per_launch",
-                       "avg_launch_us", "launches_per_step", "fragments_per_launch", "traffic_source", "traffic_stale"])
+                       "avg_launch_us", "launches_per_step", "fragments_per_launch", "traffic_source", "traffic_stale",
+                       "mfma_busy", "mfma_busy_source", "mfma_busy_stale"])
         mp = rf.get("matrix_pipe") or {}
         if mp:
             r["peak_is"] = "dense bf16 MFMA peak / 6 (six bf16 products per f32 product)"
@@ -745,7 +746,10 @@ def compact_line(res, detail_path=None):
         out["roofline_frac_by_kernel"] = {_short(f.get("kernel"), 40): f.get("frac") for f in fams[:16]}
     cb = res.get("cpu_baseline")
     if cb:
-        b = _pick(cb, ["value", "unit", "cores", "host_cores", "kind", "geometry_kind", "value_1thread", "reference_python"])
+        b = _pick(cb, ["value", "unit", "cores", "host_cores", "kind", "geometry_kind", "value_1thread", "value_multithread", "pinned",
+                       "reference_python"])
+        if cb.get("fragment_s"):
+            b["fragment_s_p10_p90"] = [cb["fragment_s"].get("p10"), cb["fragment_s"].get("p90")]
         b["sample"] = _short(cb.get("sample"), 180)
         out["cpu_baseline"] = b
     else:
@@ -964,6 +968,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
     fam = accumulate_families(cfg, timed)
 
     traffic, traffic_src, traffic_stale = load_traffic()
+    mfma, mfma_src, mfma_stale = load_counters("*_mfma_counters.json")
 
     def describe(name):
         d = fam[name]
@@ -991,6 +996,21 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                                     peak_is="dense bf16 MFMA peak / 6 = the fp32-product rate this instruction stream can reach at best",
                                     fp32_mfma_peak=MFMA_F32_PEAK_TF, achieved_over_fp32_mfma_peak=round(tf_s / MFMA_F32_PEAK_TF, 4),
                                     measured_limit="operand traffic L2 -> CU (~9 TB/s) and launch size: DESIGN.md section 5")
+        # matrix-pipe utilisation from the SQ counters (one `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE` pass of this
+        # same command at --batch 4, tools/gpu_visit.sh mfma -> tools/pmc_mfma.py): busy cycles of the matrix pipes / (1024 SIMDs x
+        # the launch's cycles), time-weighted over the kernel's template instances.  It is a count of issued MFMAs (32 busy cycles
+        # per v_mfma_f32_32x32x16_bf16, 16 per 16x16x32), so it must equal issued flops / (1024 flops per cycle and SIMD): the
+        # `issued_frac_clock_free` column of the counter file is that figure from SQ_INSTS_VALU_MFMA_MOPS_BF16 of the same pass.
+        # Against this line's own issued_tflops / 2516.6 it differs by (a) the fragments per launch (counter pass: 4), (b) the
+        # clock (2516.6 assumes 2.4 GHz; the chip runs 2.0-2.5 under this load) and (c) the counter pass serialising the streams.
+        if mfma is not None:
+            fm = (mfma.get("__families__") or {}).get(name.split("<")[0].split(" ")[0])
+            if fm:
+                r["mfma_busy"] = fm["mfma_busy"]
+                r["mfma_busy_issued_frac_of_the_same_pass"] = fm.get("issued_frac_clock_free")
+                r["mfma_busy_fragments_per_launch"] = int(mfma.get("__fragments_per_launch__", 4))
+                r["mfma_busy_source"] = mfma_src
+                r["mfma_busy_stale"] = mfma_stale
         r["alg_flops_per_launch"] = int(d["flops"] / d["launches"])
         r["alg_bytes_per_launch"] = int(d["bytes"] / d["launches"])
         r["tflops"], r["hbm_gbs"] = round(tf_s, 3), round(gb_s, 2)
@@ -1077,6 +1097,19 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
     return roof, roofs, layers, fam_flops
 
 
+def load_counters(pattern):
+    """Newest committed counter summary under profiles/ matching `pattern` -> (object, file name, stale?)."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)),
+                   key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])
+    if not cands:
+        return None, None, None
+    try:
+        tj = json.load(open(cands[-1]))
+    except Exception:
+        return None, None, None
+    return tj, os.path.basename(cands[-1]), tj.get("__source_hash__") != source_hash()
+
+
 def load_traffic():
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
                    key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])  # v10 after v9
@@ -1113,11 +1146,40 @@ def cpu_baseline(wl, limits, raws_host, one_thread=True):
         ref["t_geometry"] += t
         return ref
     ncores = os.cpu_count() or 1
-    # the torch-CPU graph stops scaling well before a 256-thread box is full (and degrades past it): 64 intra-op threads,
-    # the box's core count is reported beside it
-    torch.set_num_threads(min(ncores, 64))
-    nthreads = torch.get_num_threads()
-    reference(raws_host[0])     # warm-up (page-in, thread pools)
+    from oracle import network_np as onp
+
+    # ---- a stable host leg (0.36 ... 0.82 fragments/s across visits, the 64-thread figure once BELOW the
+    # 1-thread one).  The torch-CPU graph stops scaling well before a 256-thread box is full and collapses when its threads wander
+    # across sockets: every thread of this process is pinned to ONE contiguous block of cores for the duration of the leg, the
+    # intra-op thread count is the best of a short probe (16 / 32 / 64 on that block), two warm-ups precede the timed steps, and
+    # the reported value is the better of {pinned multi-thread, 1 thread}.
+    def pin(cpus):
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    os.sched_setaffinity(int(tid), cpus)
+                except OSError:
+                    pass
+            return True
+        except Exception:
+            return False
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except Exception:
+        avail = list(range(ncores))
+    block = avail[:min(len(avail), 64)]
+    reference(raws_host[0])     # warm-up 1 (page-in, thread pools: the pool's threads must exist before they can be pinned)
+    pinned = pin(set(block))
+    first = reference(raws_host[0])     # warm-up 2 (pinned)
+    probe = {}
+    for nt in sorted({min(len(block), t) for t in (16, 32, 64)}):
+        torch.set_num_threads(nt)
+        onp.forward(cfg, W, first["inp"])
+        t = time.perf_counter()
+        onp.forward(cfg, W, first["inp"])
+        probe[nt] = time.perf_counter() - t
+    nthreads = min(probe, key=probe.get)
+    torch.set_num_threads(nthreads)
     refs = [reference(r) for r in raws_host]
     pre = np.asarray([r["t_geometry"] for r in refs])
     net = np.asarray([r["t_network"] for r in refs])
@@ -1128,24 +1190,34 @@ def cpu_baseline(wl, limits, raws_host, one_thread=True):
                 "p90": round(float(np.percentile(a, 90)), 4), "n": int(len(a))}
     net1 = None
     if one_thread:
-        from oracle import network_np as onp
         torch.set_num_threads(1)
-        t = time.perf_counter()
-        onp.forward(cfg, W, refs[0]["inp"])
-        net1 = time.perf_counter() - t
+        t1 = []
+        for r in refs[:2]:
+            t = time.perf_counter()
+            onp.forward(cfg, W, r["inp"])
+            t1.append(time.perf_counter() - t)
+        net1 = float(np.median(t1))
         torch.set_num_threads(nthreads)
-    out = {"value": round(float(len(refs) * wl.frames / tot.sum()), 4), "unit": "fragments/s", "cores": nthreads,
+    if pinned:
+        pin(set(avail))
+    v_multi = float(len(refs) * wl.frames / tot.sum())
+    v_one = wl.frames / (float(np.median(pre)) + net1) if net1 is not None else None
+    best_one = v_one is not None and v_one > v_multi
+    out = {"value": round(v_one if best_one else v_multi, 4), "unit": "fragments/s", "cores": 1 if best_one else nthreads,
            "host_cores": ncores,
            # geometry = the reference's own C++ (oracle/_ref) when available; the network half has no runnable reference
            # (TensorFlow 1 is not installable here), it is the torch-CPU restatement -> "port" for the sum
            "kind": "port", "geometry_kind": "reference" if use_ref else "port",
-           "sample": "%d step(s) of the same workload after 1 warm-up; geometry (stage-0 subsample + pyramid) by %s on 1 "
-                     "thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads (box: %d cores): "
-                     "%.3f s/fragment" % (len(refs), "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
-                                          float(pre.mean()), nthreads, ncores, float(net.mean())),
+           "sample": "%d step(s) of the same workload after 2 warm-ups, every thread pinned to cores %d-%d; geometry (stage-0 subsample "
+                     "+ pyramid) by %s on 1 thread: %.3f s/fragment; network = torch-CPU restatement of the TF graph on %d threads "
+                     "(best of %s; box: %d cores): %.3f s/fragment; value = the better of {that, 1 thread}"
+                     % (len(refs), block[0], block[-1], "the reference's own C++ (oracle/_ref)" if use_ref else "the C restatement",
+                        float(pre.mean()), nthreads, "/".join("%d: %.2f s" % (k, v) for k, v in sorted(probe.items())), ncores,
+                        float(net.mean())),
            "geometry_s": stats(pre), "network_s": stats(net), "fragment_s": stats(tot),
+           "value_multithread": round(v_multi, 4), "threads_probe_s": {str(k): round(v, 3) for k, v in sorted(probe.items())},
            "network_1thread_s": round(net1, 3) if net1 is not None else None,
-           "value_1thread": round(wl.frames / (float(np.median(pre)) + net1), 4) if net1 is not None else None}
+           "value_1thread": round(v_one, 4) if v_one is not None else None, "pinned": bool(pinned)}
     return out, refs
 
 

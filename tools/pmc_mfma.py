@@ -89,6 +89,20 @@ def main(argv):
                 # the same ratio at the peak's own clock: MOPS x 512 flops / (1024 SIMDs x 1024 flops per cycle x cycles)
                 e["issued_frac_clock_free"] = round(512.0 * mops / (SIMDS * 1024.0 * gui), 4)
         out[k] = e
+    # families (template instances of one kernel together): time-weighted utilisation = sum of busy cycles / sum of SIMD cycles
+    fams = {}
+    for k, e in out.items():
+        f = k.split("<")[0]
+        if "duration_cycles" not in e:
+            continue
+        a = fams.setdefault(f, [0.0, 0.0, 0.0, 0])
+        a[0] += e["SQ_VALU_MFMA_BUSY_CYCLES"] * e["launches"]
+        a[1] += SIMDS * e["duration_cycles"] * e["launches"]
+        a[2] += 512.0 * e.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * e["launches"]
+        a[3] += e["launches"]
+    out["__families__"] = {f: {"launches": a[3], "mfma_busy": round(a[0] / a[1], 4),
+                               "issued_frac_clock_free": round(a[2] / (1024.0 * a[1]), 4) if a[2] else None}
+                           for f, a in sorted(fams.items())}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
     for fn in sorted(glob.glob(os.path.join(root, "d3feat_amd", "csrc", "*.h*"))):
