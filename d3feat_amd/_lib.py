@@ -27,6 +27,7 @@ SIGNATURES = {
     "d3f_grid_subsample_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_batch_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_batch_grid_subsample_async": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_batch_grid_subsample_async_inplace": (_i, [_vp, _i, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d3f_stack_self_pair": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "d3f_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
     "d3f_batch_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -569,19 +569,24 @@ __global__ void __launch_bounds__(256) gs_order_place_kernel(GsOrderArgs A, int 
 //   (iteration-order rounds on the voxel keys, as in the hash form)
 //   gs_emit_kernel      barycentres to their rows
 // Results are identical to the hash form (same voxel ids, keys, per-voxel point order).
-__global__ void __launch_bounds__(RS_THREADS) gs_sortkey_kernel(const float* __restrict__ pts, const int* __restrict__ offs, int B,
+__global__ void __launch_bounds__(RS_THREADS) gs_sortkey_kernel(const float* __restrict__ pts, const float* const* __restrict__ ptrs,
+                                                                const int* __restrict__ offs, int B,
                                                                 float dl, const GsElem* __restrict__ el,
                                                                 const RsMeta* __restrict__ smeta, unsigned* __restrict__ skey,
                                                                 unsigned* __restrict__ hist, int* __restrict__ status) {
     __shared__ unsigned sHist[256];
     __shared__ int sOffs[D3F_MAX_BATCH + 1];
     __shared__ GsElem sEl[D3F_MAX_BATCH];
+    __shared__ const float* sBase[D3F_MAX_BATCH];     // virtual base of every element: row i of the stack = sBase[b] + 3 i
     const int n = smeta->n, kb = smeta->kb;
     const int tile = blockIdx.x;
     if ((long long)tile * RS_TILE >= (long long)n) return;
     // the element table goes through LDS: a per-point search through `offs` in memory was a chain of dependent loads
     for (int t = threadIdx.x; t <= B; t += RS_THREADS) sOffs[t] = offs[t];
-    for (int t = threadIdx.x; t < B; t += RS_THREADS) sEl[t] = el[t];
+    for (int t = threadIdx.x; t < B; t += RS_THREADS) {
+        sEl[t] = el[t];
+        sBase[t] = ptrs ? ptrs[t] - 3 * (size_t)offs[t] : pts;       // (in place: the clouds of a replay are never stacked)
+    }
     __syncthreads();
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int base = tile * RS_TILE + w * RS_WAVE_ITEMS + lane;
@@ -604,9 +609,10 @@ __global__ void __launch_bounds__(RS_THREADS) gs_sortkey_kernel(const float* __r
             // 32-bit index arithmetic: this kernel only runs when NX NY NZ <= 2^kb <= 2^32 (gs_prep; otherwise n == 0), and
             // the bounding box keeps every index below its dimension
             const unsigned NX = (unsigned)sEl[b].NX, NY = (unsigned)sEl[b].NY;
-            const float fx = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 0], ox), dl));
-            const float fy = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], oy), dl));
-            const float fz = floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], oz), dl));
+            const float* __restrict__ P = sBase[b];
+            const float fx = floorf(__fdiv_rn(__fsub_rn(P[3 * (size_t)i + 0], ox), dl));
+            const float fy = floorf(__fdiv_rn(__fsub_rn(P[3 * (size_t)i + 1], oy), dl));
+            const float fz = floorf(__fdiv_rn(__fsub_rn(P[3 * (size_t)i + 2], oz), dl));
             if (fx < 0.f || fy < 0.f || fz < 0.f) st |= D3F_ST_NEG_CELL;
             const unsigned ix = (unsigned)fmaxf(fx, 0.f), iy = (unsigned)fmaxf(fy, 0.f), iz = (unsigned)fmaxf(fz, 0.f);
             const unsigned k = ix + NX * (iy + NY * iz);                 // < NX NY NZ <= 2^kb
@@ -647,7 +653,8 @@ struct GsBitsIn {
 __global__ void __launch_bounds__(256) gs_runs_kernel(int N, const RsMeta* __restrict__ smeta, const unsigned* __restrict__ key0,
                                                       const unsigned* __restrict__ key1, const unsigned* __restrict__ val0,
                                                       const unsigned* __restrict__ val1, GsRankBits rank,
-                                                      const float* __restrict__ pts, unsigned long long* __restrict__ vkey,
+                                                      const float* __restrict__ pts, const float* const* __restrict__ ptrs,
+                                                      const int* __restrict__ offs, unsigned long long* __restrict__ vkey,
                                                       float* __restrict__ bary) {
     __shared__ float sx[256], sy[256], sz[256];
     __shared__ unsigned sk[256];
@@ -663,6 +670,10 @@ __global__ void __launch_bounds__(256) gs_runs_kernel(int N, const RsMeta* __res
         k = ks[j];
         pi = vs[j];
         kprev = j > 0 ? ks[j - 1] : 0u;
+        if (ptrs) {              // in place: the element is the key's upper field, its array starts at stack row offs[b]
+            const int b = smeta->kb < 32 ? (int)(k >> smeta->kb) : 0;
+            pts = ptrs[b] - 3 * (size_t)offs[b];
+        }
         px = pts[3 * (size_t)pi + 0]; py = pts[3 * (size_t)pi + 1]; pz = pts[3 * (size_t)pi + 2];
     }
     sx[t] = px; sy[t] = py; sz[t] = pz;
@@ -679,7 +690,7 @@ __global__ void __launch_bounds__(256) gs_runs_kernel(int N, const RsMeta* __res
         az = __fadd_rn(az, sz[t + c]);
         ++c;
     }
-    if (t + c == 256) {                                 // the run may go on in the next workgroup's positions
+    if (t + c == 256) {                                 // the run may go on in the next workgroup's positions (same key: same element)
         while (j + c < n && ks[j + c] == k) {
             const size_t q = vs[j + c];
             ax = __fadd_rn(ax, pts[3 * q + 0]);
@@ -854,9 +865,9 @@ static int gs_run_small(const float* points, int N, const int* lens_dev, int B, 
 static int gs_run(const float* points, int N, const int* lens_dev, int B, float dl, const float* features, int fdim,
                   const int* classes, int ldim, float* sub_points, int M_cap, int elem_cap, int elem_points, float* sub_features,
                   int* sub_classes, int* sub_lens_dev, int* status_host, int* status_dev, void* workspace,
-                  size_t workspace_bytes, hipStream_t stream) {
+                  size_t workspace_bytes, hipStream_t stream, const float* const* ptrs = nullptr) {
     const bool async = status_dev != nullptr;
-    if (async && !features && ldim == 0) {
+    if (async && !features && ldim == 0 && !ptrs) {
         // one workgroup per cloud when the caller's capacities fit it: every cloud <= 16384 points and <= 5087 voxels (a cloud
         // beyond its stated capacity is reported by either form, so the choice adds no failure mode)
         const int pc = (elem_points > 0 && elem_points < N) ? elem_points : N;
@@ -931,14 +942,14 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
                        : d3f_begin_launch(lens_dev, B, offs, bbox, counters, ncounters, D3fFill{(unsigned*)tkey, ones_words, 0xFFFFFFFFu},
                                           D3fFill{(unsigned*)meta, zero_words, 0u}, none, none, stream)) != D3F_OK) return rc;
     GsPrepEpi prep{bbox, offs, B, dl, el, meta, use_sort ? smeta : nullptr, N};
-    if ((rc = d3f_bbox_launch_t(points, offs, B, N, bbox, counters, prep, stream)) != D3F_OK) return rc;
+    if ((rc = d3f_bbox_launch_t(points, offs, B, N, bbox, counters, prep, stream, ptrs)) != D3F_OK) return rc;
     const int nblk = d3f_cdiv(N, 256);
     const int elem_lim = async ? elem_cap : 0x7fffffff;
     int M, maxM;       // sizes of the voxel-indexed launches
     if (use_sort) {
         // storage reuse: sort keys in slot / pnext, point indices in pvid / sorted, word scan in vscan / vbase
         unsigned *key0 = (unsigned*)slot, *key1 = (unsigned*)pnext, *val0 = (unsigned*)pvid, *val1 = (unsigned*)sorted;
-        gs_sortkey_kernel<<<rs_tiles(N), RS_THREADS, 0, stream>>>(points, offs, B, dl, el, smeta, key0, rs_hist, meta);
+        gs_sortkey_kernel<<<rs_tiles(N), RS_THREADS, 0, stream>>>(points, ptrs, offs, B, dl, el, smeta, key0, rs_hist, meta);
         D3F_LAUNCH_CHECK();
         if ((rc = rs_sort_launch(smeta, N, key0, key1, val0, val1, rs_hist, stream)) != D3F_OK) return rc;
         gs_heads_kernel<<<nblk, 256, 0, stream>>>(N, smeta, key0, key1, val0, val1, fbits);
@@ -947,7 +958,7 @@ static int gs_run(const float* points, int N, const int* lens_dev, int B, float 
         GsMoffsEpi<GsRankBits> mepi{offs, B, rank, meta, moffs, sub_lens_dev, status_dev, M_cap, elem_lim};
         if ((rc = d3f_scan_fold_launch(GsBitsIn{fbits}, N / 32 + 1, nullptr, vscan, vbase, counters + 1, mepi, stream)) != D3F_OK)
             return rc;
-        gs_runs_kernel<<<nblk, 256, 0, stream>>>(N, smeta, key0, key1, val0, val1, rank, points, vkey, bary);
+        gs_runs_kernel<<<nblk, 256, 0, stream>>>(N, smeta, key0, key1, val0, val1, rank, points, ptrs, offs, vkey, bary);
         D3F_LAUNCH_CHECK();
         M = N < M_cap ? N : M_cap;
         maxM = elem_cap;
@@ -1034,6 +1045,19 @@ extern "C" int d3f_batch_grid_subsample_async(const float* points, int N_cap, co
     if (!points || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
     return gs_run(points, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, elem_cap, elem_points_cap, nullptr,
                   nullptr, sub_lens_dev, nullptr, status_dev, workspace, workspace_bytes, stream);
+}
+
+// The same call with the clouds read IN PLACE: cloud b is its own array clouds_dev[b] (f32[lens[b], 3], any address), nothing is
+// stacked.  N_cap bounds the SUM of the lengths (workspace and launch sizes).  What a replayed launch sequence needs to take its
+// inputs where the producer left them: the pointer table and the lengths are the only per-replay uploads.
+extern "C" int d3f_batch_grid_subsample_async_inplace(const float* const* clouds_dev, int N_cap, const int* lens_dev, int B, float dl,
+                                                      float* sub_points, int M_cap, int elem_cap, int* sub_lens_dev, int* status_dev,
+                                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N_cap < 1 || N_cap > (1 << 30) || M_cap < 1 || elem_cap < 0 || B < 1 || B > D3F_MAX_BATCH || !(dl > 0.f)) return D3F_ERR_ARG;
+    if (!clouds_dev || !lens_dev || !sub_points || !sub_lens_dev || !status_dev) return D3F_ERR_ARG;
+    return gs_run(nullptr, N_cap, lens_dev, B, dl, nullptr, 0, nullptr, 0, sub_points, M_cap, elem_cap, 0, nullptr, nullptr, sub_lens_dev,
+                  nullptr, status_dev, workspace, workspace_bytes, stream, clouds_dev);
 }
 
 // np.concatenate([pts, pts]) of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:

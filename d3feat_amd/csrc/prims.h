@@ -81,11 +81,15 @@ static inline int d3f_begin_launch(const int* lens, int B, int* offs, unsigned* 
 
 // Bounding boxes per batch element, grid (chunks, B); min / max are exact and order independent, so the result equals
 // cpp_utils/cloud/cloud.cpp:27-66 bit for bit.  epi(b_first, b_step) is run by the last workgroup with all 256 threads.
+// ptrs != NULL: element b's points are read IN PLACE from ptrs[b] (its own array, rows 0 .. len_b - 1) instead of from rows
+// [offs[b], offs[b + 1]) of the stacked array `pts` (the stage-0 clouds of a replay are never copied into one buffer).
 template <class Epi>
-__global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pts, const int* __restrict__ offs, int B,
+__global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pts, const float* const* __restrict__ ptrs,
+                                                   const int* __restrict__ offs, int B,
                                                    unsigned* __restrict__ bbox, unsigned* __restrict__ counter, Epi epi) {
     const int b = blockIdx.y;
     const int lo = offs[b], hi = offs[b + 1];
+    if (ptrs) pts = ptrs[b] - 3 * (size_t)lo;          // virtual base: row i of the stack = row i - lo of the element
     unsigned mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
     // four points per thread and trip: twelve loads in flight (one point per trip was a chain of dependent HBM round trips --
     // 60 us for the 1.2 M points of a stage-0 stack)
@@ -135,14 +139,14 @@ __global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ pts
 
 template <class Epi>
 static inline int d3f_bbox_launch_t(const float* pts, const int* offs, int B, int N, unsigned* bbox, unsigned* counter, Epi epi,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, const float* const* ptrs = nullptr) {
     // about one workgroup per CU over all elements: every workgroup ends with a ticket on ONE counter, and same-address
     // atomics serialise at ~12 ns each, so thousands of (mostly idle) workgroups cost more than the boxes themselves
     // (N is the whole stack: an element holds about N / B points; eight points per thread)
     int chunks = d3f_cdiv(d3f_cdiv(N > 0 ? N : 1, B), 256 * 8);
     const int per_elem = 512 / B > 1 ? 512 / B : 1;
     if (chunks > per_elem) chunks = per_elem;
-    bbox_kernel<Epi><<<dim3(chunks, B), 256, 0, stream>>>(pts, offs, B, bbox, counter, epi);
+    bbox_kernel<Epi><<<dim3(chunks, B), 256, 0, stream>>>(pts, ptrs, offs, B, bbox, counter, epi);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -140,9 +140,12 @@ class FragmentEngine:
     def _sequence(self, sl):
         cfg = self.cfg
         if self.stage0:
-            sub, sub_l, st0 = ops.batch_grid_subsample_async(sl.raw, sl.raw_len, cfg.first_subsampling_dl, self.F * self.n0_cap,
+            # the raw clouds are read IN PLACE through a table of addresses (sl.raw_ptrs): a cloud that already lives in HBM is
+            # never copied into the slot; one that arrives from the host (or as file records) is written to the slot's staging
+            # buffer sl.raw and its address there goes into the table
+            sub, sub_l, st0 = ops.batch_grid_subsample_async(None, sl.raw_len, cfg.first_subsampling_dl, self.F * self.n0_cap,
                                                              status=sl.status0, m_hint=self.F * self.n0_hint,
-                                                             elem_cap=self.n0_cap)
+                                                             elem_cap=self.n0_cap, clouds=sl.raw_ptrs, n_cap=self.F * self.raw_cap)
         else:
             sub, sub_l = sl.raw, sl.raw_len            # already at first_subsampling_dl: the stack is made of the clouds as fed
             sub.n_hint = self.F * self.n0_hint
@@ -164,9 +167,14 @@ class FragmentEngine:
         sl = _Slot()
         sl.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         sl.raw = torch.zeros((self.F * self.raw_cap, 3), dtype=torch.float32, device=dev)
-        sl.raw_len = torch.zeros((self.nin,), dtype=torch.int32, device=dev)
+        # per-replay uploads, ONE block [addresses of the nin clouds (int64) | their lengths (int32)] and its pinned host mirror
+        sl.meta_dev = torch.zeros((3 * self.nin,), dtype=torch.int32, device=dev)
+        sl.meta_host = torch.zeros((3 * self.nin,), dtype=torch.int32).pin_memory()
+        sl.raw_ptrs = sl.meta_dev[: 2 * self.nin].view(torch.int64)
+        sl.raw_len = sl.meta_dev[2 * self.nin:]
+        sl.host_ptrs = sl.meta_host[: 2 * self.nin].view(torch.int64)
+        sl.host_n = sl.meta_host[2 * self.nin:]
         sl.status0 = torch.zeros((2,), dtype=torch.int32, device=dev)
-        sl.host_n = torch.zeros((self.nin,), dtype=torch.int32).pin_memory()
         sl.ds = FragmentDataset([], fast=True)
         sl.ds.device = dev
         sl.ds.neighborhood_limits = self.limits
@@ -188,6 +196,7 @@ class FragmentEngine:
             warm = (torch.rand((per * self.nin, 3), generator=g) * torch.tensor([1.0, 1.0, 0.05])).to(dev)
             sl.raw[: per * self.nin].copy_(warm)
             sl.raw_len.fill_(per)
+            sl.raw_ptrs.copy_(torch.tensor([sl.raw.data_ptr() + 12 * per * i for i in range(self.nin)], dtype=torch.int64))
             with ops.private_workspace():
                 _, _, _, w_status, w_lens = self._sequence(sl)
             w_status[:, 1].zero_()        # the searches' flag words are sticky: the replay's last node clears them (pack_status)
@@ -245,13 +254,24 @@ class FragmentEngine:
             # still be being copied out there
             sl.stream.wait_stream(cur)
             o = 0
-            for p in parts:
+            sl.keep_in = []
+            for i, p in enumerate(parts):
+                n = int(p.shape[0])
                 if isinstance(p, ops.RawRecords):      # file records: bytes to the device, xyz decoded in place (stage-0 ingestion)
-                    p.decode(self.device, out=sl.raw[o:o + p.shape[0]])
-                elif p.data_ptr() != sl.raw[o:].data_ptr():     # a producer may have written straight into the slot's buffer
-                    sl.raw[o:o + p.shape[0]].copy_(p, non_blocking=True)
-                o += int(p.shape[0])
-            sl.raw_len.copy_(sl.host_n, non_blocking=True)
+                    p.decode(self.device, out=sl.raw[o:o + n])
+                    addr = sl.raw[o:].data_ptr()
+                elif self.stage0 and isinstance(p, torch.Tensor) and p.is_cuda and p.device == self.device:
+                    # already in HBM: read where it is (the tensor is kept alive until the slot is fetched)
+                    q = p if (p.dtype == torch.float32 and p.is_contiguous()) else p.to(torch.float32).contiguous()
+                    sl.keep_in.append(q)
+                    addr = q.data_ptr()
+                else:
+                    if p.data_ptr() != sl.raw[o:].data_ptr():     # a producer may have written straight into the slot's buffer
+                        sl.raw[o:o + n].copy_(p, non_blocking=True)
+                    addr = sl.raw[o:].data_ptr()
+                sl.host_ptrs[i] = addr
+                o += n
+            sl.meta_dev.copy_(sl.meta_host, non_blocking=True)
             sl.graph.replay()          # ends by packing [n_total | status0 | statuses | lens] into dev_stat
             sl.host_stat.copy_(sl.dev_stat, non_blocking=True)
             sl.done.record(sl.stream)

@@ -203,16 +203,22 @@ def batch_grid_subsample(points, lens, dl, features=None, classes=None):
     return sub_p[:M], sub_l, (sub_f[:M] if fdim else None), (sub_c[:M] if ldim else None)
 
 
-def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0, elem_cap=0, elem_points=0):
+def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0, elem_cap=0, elem_points=0, clouds=None, n_cap=0):
     """Capacity mode of batch_grid_subsample (points only): no host synchronisation.
+    clouds (device int64[B]: the ADDRESS of every cloud's own f32[len, 3] array) with points=None and n_cap = bound of sum(lens):
+    the clouds are read in place, nothing is stacked (d3f_batch_grid_subsample_async_inplace).
     points f32[N_cap,3] (sum(lens) rows valid) -> (sub_points f32[m_cap,3] tagged with n_dev, sub_lens i32[B] device,
     status i32[2] device = [M, flags]).  elem_cap: capacity of ONE cloud of the stack (0: m_cap); a cloud above it raises
     the overflow flag like a stack above m_cap does.  elem_points: capacity of one cloud in POINTS (0: all rows of `points`);
     at most 16384 selects the one-workgroup-per-cloud form (the coarse pyramid levels: 2 launches instead of ~25)."""
     lib = _lib.load()
-    points = _req(points, torch.float32, "points", 2).contiguous()
-    dev = points.device
-    N = points.shape[0]
+    if clouds is not None:
+        assert points is None and clouds.dtype == torch.int64 and clouds.is_contiguous() and int(n_cap) > 0
+        dev, N = clouds.device, int(n_cap)
+    else:
+        points = _req(points, torch.float32, "points", 2).contiguous()
+        dev = points.device
+        N = points.shape[0]
     lens_t = as_lens(lens, dev)
     B = lens_t.numel()
     sub_p = torch.empty((int(m_cap), 3), dtype=torch.float32, device=dev)
@@ -222,9 +228,15 @@ def batch_grid_subsample_async(points, lens, dl, m_cap, status=None, m_hint=0, e
     nbytes = lib.d3f_grid_subsample_workspace_bytes(N, B, 0, 0)
     ws = workspace(nbytes, dev)
     with _timed("grid_subsample", dict(N=N, M=int(m_cap)), dev):
-        rc = lib.d3f_batch_grid_subsample_async(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl), sub_p.data_ptr(),
-                                                int(m_cap), int(elem_cap), int(elem_points), sub_l.data_ptr(), status.data_ptr(), ws.data_ptr(),
-                                                ws.numel(), _stream(dev))
+        if clouds is not None:
+            assert clouds.numel() == B
+            rc = lib.d3f_batch_grid_subsample_async_inplace(clouds.data_ptr(), N, lens_t.data_ptr(), B, float(dl), sub_p.data_ptr(),
+                                                            int(m_cap), int(elem_cap), sub_l.data_ptr(), status.data_ptr(),
+                                                            ws.data_ptr(), ws.numel(), _stream(dev))
+        else:
+            rc = lib.d3f_batch_grid_subsample_async(points.data_ptr(), N, lens_t.data_ptr(), B, float(dl), sub_p.data_ptr(),
+                                                    int(m_cap), int(elem_cap), int(elem_points), sub_l.data_ptr(), status.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), _stream(dev))
     _lib.check(rc, "batch_grid_subsample_async")
     sub_p.n_dev = status[0:1]
     sub_p.n_hint = int(m_hint)

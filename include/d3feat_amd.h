@@ -94,6 +94,14 @@ size_t d3f_grid_subsample_workspace_bytes(int N, int B, int fdim, int ldim);
 int d3f_batch_grid_subsample_async(const float* points, int N_cap, const int* lens_dev, int B, float dl,
                                    float* sub_points, int M_cap, int elem_cap, int elem_points_cap, int* sub_lens_dev,
                                    int* status_dev, void* workspace, size_t workspace_bytes, void* stream);
+/* d3f_batch_grid_subsample_async with the clouds read IN PLACE: cloud b is its own device array clouds_dev[b] (f32[lens_dev[b], 3])
+ * instead of rows of one stacked array -- the stage-0 call of a replayed fragment sequence takes its raw clouds where the
+ * producer left them (no copy into a staging buffer: datasets/ThreeDMatch.py:186-192 hands the generator separate arrays too).
+ * clouds_dev: device array of B device pointers; N_cap bounds sum(lens_dev).  Results are those of the stacked call. */
+int d3f_batch_grid_subsample_async_inplace(const float* const* clouds_dev, int N_cap, const int* lens_dev, int B, float dl,
+                                           float* sub_points, int M_cap, int elem_cap, int* sub_lens_dev, int* status_dev,
+                                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* The self-pair stacking of the reference's test generators (datasets/ThreeDMatch.py:190-192, demo_registration.py:72-79:
  * np.concatenate([pts, pts])) for B stacked clouds whose row counts live in HBM (lens_in_dev i32[B]): cloud b is written
  * twice in a row -- out f32[2*M_cap,3] = [c_0; c_0; c_1; c_1; ...], lens_out_dev i32[2B] = [m_0, m_0, m_1, m_1, ...],
