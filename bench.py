@@ -386,12 +386,16 @@ def main():
     # replays run; every rank holds the same number of steps, so the collective order is the same everywhere)
     dst = None if args.gather_to == "all" else int(args.gather_to)
     frag_rows = (int(n0_max * wl.cap_factor) + 1023) // 1024 * 1024
-    if world > 1 and args.gather_chunk > 0:
-        strides = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(strides, torch.tensor([frag_rows], dtype=torch.int64, device=device))
-        assert all(int(x.item()) == frag_rows for x in strides), "fragment stride differs between ranks: %s" % [int(x.item()) for x in strides]
-        shard = parallel.ShardCollector(rows_cap=(args.steps + args.gather_chunk) * frag_rows, width=36, device=device,
-                                        chunk_frags=args.gather_chunk, frag_rows=frag_rows, dst=dst)
+    if args.gather_chunk > 0:
+        # fixed stride per step: the replays write their records straight into the shard (FragmentEngine.submit(out=...)), and
+        # with N > 1 finished chunks are exchanged while the next replays run
+        if world > 1:
+            strides = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+            dist.all_gather(strides, torch.tensor([frag_rows], dtype=torch.int64, device=device))
+            assert all(int(x.item()) == frag_rows for x in strides), "fragment stride differs between ranks: %s" % [int(x.item()) for x in strides]
+        keep_steps = (max(args.steps, 128) if world == 1 else args.steps) + args.gather_chunk
+        shard = parallel.ShardCollector(rows_cap=keep_steps * frag_rows * (2 if wl.two else 1), width=36, device=device,
+                                        chunk_frags=args.gather_chunk, frag_rows=frag_rows * (2 if wl.two else 1), dst=dst)
     else:
         shard = parallel.ShardCollector(rows_cap=((max(args.steps, 128) if world == 1 else args.steps) + 8) * int(n0_max * 1.02 + 64),
                                         width=36, device=device, dst=dst)
@@ -407,10 +411,12 @@ def main():
         S, F = len(engine.slots), engine.F
         busy = [False] * S
 
+        inplace = [False] * S
+
         def drain(sl):
             for rec in engine.fetch(sl, packed=True):
                 if collect is not None:
-                    collect.add(wl.kept(rec))
+                    collect.add(rec if inplace[sl] else wl.kept(rec))      # (submit(out=...): the kept clouds only, already)
             busy[sl] = False
         i = k = 0
         sizes = schedule if (schedule and nsteps == args.steps and engine.F >= max(schedule)) else None
@@ -419,7 +425,9 @@ def main():
             if busy[sl]:
                 drain(sl)
             nb = min(F, nsteps - i) if sizes is None else sizes[k]
-            engine.submit(sl, [pool[(i + j) % len(pool)] for j in range(nb)])
+            dsts = collect.slots(nb) if (collect is not None and not engine.mirror) else None
+            inplace[sl] = dsts is not None
+            engine.submit(sl, [pool[(i + j) % len(pool)] for j in range(nb)], out=dsts)
             busy[sl] = True
             i += nb
             k += 1
@@ -1257,7 +1265,7 @@ def parity_check(cfg, engine, step, raws_dev, refs, device, tol):
                 outs = engine.fetch(sl, packed=True)
                 slot = engine.slots[sl]
                 graph_path = engine.fallbacks == fb0 and not engine.mirror   # (a fallback's pyramid is not the slot's)
-                nb0 = slot.flat[cfg.num_layers].cpu().numpy() if graph_path else None
+                nb0 = engine.reference_order_flat(sl)[cfg.num_layers].cpu().numpy() if graph_path else None
                 total = int(slot.pts.n_dev.item()) if graph_path else None
                 row0 = 0
                 for j in range(nb):

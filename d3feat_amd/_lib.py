@@ -35,7 +35,9 @@ SIGNATURES = {
     "d3f_neighbor_grid_order_offset": (_sz, [_i, _i]),
     "d3f_neighbor_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp]),
     "d3f_neighbor_grid_search": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "d3f_neighbor_grid_nearest": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _vp, _sz, _vp, _i, _i, _i, _f, _vp]),
+    "d3f_neighbor_grid_search_ordered": (_i, [_vp, _sz, _i, _vp, _i, _vp, _i, _f, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "d3f_neighbor_grid_inv_offset": (_sz, [_i, _i]),
+    "d3f_neighbor_grid_xyz_offset": (_sz, [_i, _i]),
     "d3f_row_positive": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp,
                                   _vp, _i, _vp]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "d3f_closest_pool_cat": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_affine_act": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
     "d3f_pack_descriptors": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "d3f_pack_descriptors_to": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "d3f_feature_nn_workspace_bytes": (_sz, [_i]),
     "d3f_feature_nn": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d3f_mutual_matches_workspace_bytes": (_sz, [_i]),

@@ -143,7 +143,9 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
                       const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                       const float4* __restrict__ sorted, float r2, int pad, const int* __restrict__ ns_dev,
                       int* __restrict__ out, int ld, int width, int cap, int* __restrict__ status, int want_kmax, int Q, int dbg,
-                      unsigned long long* __restrict__ prof) {
+                      unsigned long long* __restrict__ prof, const int* __restrict__ inv) {
+    // inv != NULL: the INTERNAL numbering -- row j of `out` is the j-th query in cell order and the entries are positions in the
+    // cell-sorted support arrays (inv[index]); the order of a row is the reference's all the same (ties by the ORIGINAL index)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ NbElem sel[NB_EL_LDS];
     __shared__ int sOff[NB_EL_LDS + 1];
@@ -204,6 +206,9 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         vcz = min(max(vcz, -2), e.dims[2] + 1);
     }
 
+    // internal numbering: the hit records hold POSITIONS in the cell-sorted array; the original index (the reference's tie-break,
+    // read in the rare exact paths only when two d2 are bit-equal) is one gather away
+#define NBC_ORIG(Y_) (inv ? __float_as_int(sorted[Y_].w) : (Y_))
     float4 cand[NBC_SLOTS];
     int cb = -1, ccx = 0, ccy = 0, ccz = 0;     // the stencil in registers: batch element and cell (wave-uniform)
     int T = 0;                                   // candidates of the stencil
@@ -226,7 +231,11 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
                 o = (v >= pre1) ? off1 : o; o = (v >= pre2) ? off2 : o; o = (v >= pre3) ? off3 : o;            \
                 o = (v >= pre4) ? off4 : o; o = (v >= pre5) ? off5 : o; o = (v >= pre6) ? off6 : o;            \
                 o = (v >= pre7) ? off7 : o; o = (v >= pre8) ? off8 : o;                                        \
-                if (v < T) cand[u] = sorted[v + o];                                                            \
+                if (v < T) {                                                                                   \
+                    cand[u] = sorted[v + o];                                                                   \
+                    /* internal numbering: the record's POSITION is what the rows hold (its index only breaks ties) */ \
+                    if (inv) cand[u].w = __int_as_float(v + o);                                                \
+                }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
@@ -301,7 +310,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         } else {
             // ---- dense neighbourhood (rare): ordered now, by the whole wavefront, from the hit array ----------------------
             const int m = min(n, cap);
-            int* row = out + (size_t)nbc_rl(vqi, i) * ld;
+            int* row = out + (size_t)(inv ? p0 + i : nbc_rl(vqi, i)) * ld;
             bool need_exact = true;
             if (n <= 128 && n <= cap && width < 64) {
                 // 128 keys, two per lane (upper 25 bits of d2 | slot); the row is the head of elements 0..63
@@ -321,7 +330,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
                     int rank = 0;
                     for (int j = 0; j < m; ++j) {
                         const uint2 o = hk[j];
-                        rank += (o.x < mine.x || (o.x == mine.x && (int)o.y < (int)mine.y)) ? 1 : 0;
+                        rank += (o.x < mine.x || (o.x == mine.x && NBC_ORIG((int)o.y) < NBC_ORIG((int)mine.y))) ? 1 : 0;
                     }
                     if (ei < m && rank < width) row[rank] = (int)mine.y;
                 }
@@ -336,7 +345,8 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         __builtin_amdgcn_wave_barrier();
         const int i0 = i & ~(NBC_BATCH - 1);         // first query of the batch
         const int qd = lane >> 3, part = lane & 7;
-        const int nqd = __shfl(vn, i0 + qd), qiq = __shfl(vqi, i0 + qd);    // hits / row of this lane's query (-1: nothing to do)
+        const int nqd = __shfl(vn, i0 + qd);                                // hits of this lane's query (-1: nothing to do)
+        const int qiq = inv ? p0 + i0 + qd : __shfl(vqi, i0 + qd);          // its row
         unsigned k[8];
         {
             const uint4* src = (const uint4*)(ld2 + qd * 64 + part * 8);
@@ -363,7 +373,11 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int e = part * 8 + r;
-                if (e < width) row[e] = (e < nqd) ? lidx[qd * 64 + (int)(k[r] & 63u)] : pad;
+                if (e < width) {
+                    int v = pad;
+                    if (e < nqd) v = lidx[qd * 64 + (int)(k[r] & 63u)];
+                    row[e] = v;
+                }
             }
             for (int e = 64 + part; e < width; e += 8) row[e] = pad;         // (rows wider than the list: padding only)
         }
@@ -374,14 +388,14 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
             const int g = (int)(__builtin_ctzll(todo) >> 3);
             todo &= ~(0xFFull << (8 * g));
             const int m = nbc_rl(vn, i0 + g);
-            int* row = out + (size_t)nbc_rl(vqi, i0 + g) * ld;
+            int* row = out + (size_t)(inv ? p0 + i0 + g : nbc_rl(vqi, i0 + g)) * ld;
             const unsigned md = ld2[g * 64 + (lane < m ? lane : 0)];
             const int mi = lidx[g * 64 + (lane < m ? lane : 0)];
             int rank = 0;
             for (int j = 0; j < m; ++j) {
                 const unsigned od = ld2[g * 64 + j];
                 const int oi = lidx[g * 64 + j];
-                rank += (od < md || (od == md && oi < mi)) ? 1 : 0;
+                rank += (od < md || (od == md && NBC_ORIG(oi) < NBC_ORIG(mi))) ? 1 : 0;
             }
             if (lane < m && rank < width) row[rank] = mi;
             for (int j = m + lane; j < width; j += 64) row[j] = pad;
@@ -391,6 +405,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         __builtin_amdgcn_wave_barrier();
     }
 #undef NBC_LOAD_CHUNK
+#undef NBC_ORIG
     NBC_T1(5);
     if (prof && lane == 0) {        // one record per wavefront (no atomics: they would serialise the launch being measured)
         for (int k = 0; k < 6; ++k) prof[(size_t)wg * 8 + k] = tp[k];

@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(256)
 nb_nearest_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B, const NbElem* __restrict__ el,
                   const int* __restrict__ cell_start, const int* __restrict__ cell_base, const float4* __restrict__ sorted,
                   const float4* __restrict__ qsorted, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out, int ld,
-                  int width, float nn_hint) {
+                  int width, float nn_hint, const int* __restrict__ inv) {
+    // inv != NULL: INTERNAL numbering -- row p (the visit position) instead of row qi, the entry = inv[index]
     __shared__ NbElem sel[NB_EL_LDS];
     __shared__ int sOff[NB_EL_LDS + 1];
     const bool staged = B <= NB_EL_LDS;
@@ -152,7 +153,7 @@ nb_nearest_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ q
         best.quad_min();
         found = best.bidx != 0x7fffffff;
     }
-    int* row = out + (size_t)qi * ld;
-    if (part == 0 && width > 0) row[0] = found ? best.bidx : pad;
+    int* row = out + (size_t)(inv ? p : qi) * ld;
+    if (part == 0 && width > 0) row[0] = found ? (inv ? inv[best.bidx] : best.bidx) : pad;
     for (int j = 1 + part; j < width; j += 4) row[j] = pad;
 }

@@ -569,30 +569,92 @@ extern "C" int d3f_affine_act(const float* x, int ldx, int M, int N, const float
 // fragment (utils/tester.py:215-229 keeps points / features / scores together) and that the multi-GPU runner gathers once
 // at the end.  One thread per output element; rows are contiguous, so a fragment's records are ONE contiguous block.
 // ------------------------------------------------------------------------------------------------
+// One lane per 16 output bytes: a block of rows is one contiguous run of the output, so the stores of a wavefront are full lines
+// (one thread per 4-byte element with two integer divisions was 60-80 us per call for the 2 M rows of an eight-fragment stack).
+// Destinations: rows are written to `out` (row n at n * ldo) unless the row belongs to one of the first `keep` clouds of a fragment
+// whose entry in dst_ptrs is non-zero -- then to that address, the fragment's kept rows packed from its row 0: a replayed sequence
+// puts a fragment's records where its consumer wants them (the rank's shard), no copy afterwards.  A fragment = `group` consecutive
+// clouds of the stack (lens_dev: B entries).
 __global__ void __launch_bounds__(256) pack_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ desc, int ldd,
                                                         int C, const float* __restrict__ score, int N,
-                                                        const int* __restrict__ N_dev, float* __restrict__ out, int ldo) {
+                                                        const int* __restrict__ N_dev, float* __restrict__ out, int ldo,
+                                                        const int* __restrict__ lens_dev, int B, int group, int keep,
+                                                        const long long* __restrict__ dst_ptrs, const int* __restrict__ row_map) {
+    __shared__ int sStart[D3F_MAX_BATCH + 1];
+    N = d3f_dyn(N, N_dev);
+    if (dst_ptrs) {
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int b = 0; b < B; ++b) { sStart[b] = s; s += lens_dev[b]; }
+            sStart[B] = s;
+        }
+        __syncthreads();
+    }
+    const int W = C + 4, Q = W >> 2;                    // floats / 16-byte pieces per record (W % 4 == 0: checked by the launcher)
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * Q) return;
+    const int n = (int)(t / Q), q = (int)(t - (long long)n * Q);
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = 4 * q + u;
+        v[u] = c < 3 ? xyz[3 * (size_t)n + c] : (c < 3 + C ? desc[(size_t)n * ldd + (c - 3)] : score[n]);
+    }
+    // row_map: the inputs are in an internal row order, record n belongs at row row_map[n] (a cloud's rows stay inside its range)
+    const int no = row_map ? row_map[n] : n;
+    float* dst = out + (size_t)no * ldo + 4 * q;
+    if (dst_ptrs) {
+        int b = 0;
+        while (b + 1 < B && no >= sStart[b + 1]) ++b;
+        const int f = b / group;
+        const long long base = dst_ptrs[f];
+        if (base != 0 && b - f * group < keep) dst = (float*)base + (size_t)(no - sStart[f * group]) * ldo + 4 * q;
+    }
+    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// any record width (one thread per element): descriptor widths that are not a multiple of four floats
+__global__ void __launch_bounds__(256) pack_rows_scalar_kernel(const float* __restrict__ xyz, const float* __restrict__ desc, int ldd,
+                                                               int C, const float* __restrict__ score, int N,
+                                                               const int* __restrict__ N_dev, float* __restrict__ out, int ldo) {
     N = d3f_dyn(N, N_dev);
     const int W = C + 4;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * W) return;
     const int n = (int)(t / W), c = (int)(t % W);
-    float v;
-    if (c < 3) v = xyz[3 * (size_t)n + c];
-    else if (c < 3 + C) v = desc[(size_t)n * ldd + (c - 3)];
-    else v = score[n];
-    out[(size_t)n * ldo + c] = v;
+    out[(size_t)n * ldo + c] = c < 3 ? xyz[3 * (size_t)n + c] : (c < 3 + C ? desc[(size_t)n * ldd + (c - 3)] : score[n]);
+}
+
+static int pack_launch(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out, int ldo,
+                       const int* N_dev, const int* lens_dev, int B, int group, int keep, const long long* dst_ptrs, const int* row_map,
+                       hipStream_t stream) {
+    if (N < 0 || C < 1 || ldd < C || ldo < C + 4) return D3F_ERR_ARG;
+    if (N == 0) return D3F_OK;
+    if (!xyz || !desc || !score || !out) return D3F_ERR_ARG;
+    if (((C + 4) & 3) || (ldo & 3) || ((uintptr_t)out & 15)) {
+        if (dst_ptrs || row_map) return D3F_ERR_ARG;           // (per-fragment destinations / row maps: 16-byte pieces only)
+        pack_rows_scalar_kernel<<<d3f_cdiv((long long)N * (C + 4), 256), 256, 0, stream>>>(xyz, desc, ldd, C, score, N, N_dev, out, ldo);
+        D3F_LAUNCH_CHECK();
+        return D3F_OK;
+    }
+    pack_rows_kernel<<<d3f_cdiv((long long)N * ((C + 4) / 4), 256), 256, 0, stream>>>(xyz, desc, ldd, C, score, N, N_dev, out, ldo, lens_dev,
+                                                                                   B, group, keep, dst_ptrs, row_map);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
 }
 
 extern "C" int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
                                     int ldo, const int* N_dev, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (N < 0 || C < 1 || ldd < C || ldo < C + 4) return D3F_ERR_ARG;
-    if (N == 0) return D3F_OK;
-    if (!xyz || !desc || !score || !out) return D3F_ERR_ARG;
-    pack_rows_kernel<<<d3f_cdiv((long long)N * (C + 4), 256), 256, 0, stream>>>(xyz, desc, ldd, C, score, N, N_dev, out, ldo);
-    D3F_LAUNCH_CHECK();
-    return D3F_OK;
+    return pack_launch(xyz, desc, ldd, C, score, N, out, ldo, N_dev, nullptr, 0, 1, 0, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int d3f_pack_descriptors_to(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
+                                       int ldo, const int* N_dev, const int* lens_dev, int B, int group, int keep,
+                                       const long long* dst_ptrs_dev, const int* row_map_dev, void* stream_) {
+    if (dst_ptrs_dev && (!lens_dev || B < 1 || B > D3F_MAX_BATCH || group < 1 || keep < 0 || keep > group)) return D3F_ERR_ARG;
+    if (!dst_ptrs_dev && !row_map_dev) return D3F_ERR_ARG;
+    return pack_launch(xyz, desc, ldd, C, score, N, out, ldo, N_dev, lens_dev, B, group, keep, dst_ptrs_dev, row_map_dev,
+                       (hipStream_t)stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -120,13 +120,17 @@ __global__ void __launch_bounds__(256) nb_scatter_kernel(const float* __restrict
                                                          const int* __restrict__ cell_of,
                                                          const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                                                          int* __restrict__ cell_cur,
-                                                         float4* __restrict__ sorted, int* __restrict__ order) {
+                                                         float4* __restrict__ sorted, int* __restrict__ order,
+                                                         int* __restrict__ inv, float* __restrict__ xyz) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(Ns, *ns_dev)) return;
     const int c = cell_of[i];
     const int pos = d3f_scan_at(cell_start, cell_base, c) + atomicAdd(&cell_cur[c], 1);
-    sorted[pos] = make_float4(s[3 * (size_t)i], s[3 * (size_t)i + 1], s[3 * (size_t)i + 2], __int_as_float(i));
+    const float x = s[3 * (size_t)i], y = s[3 * (size_t)i + 1], z = s[3 * (size_t)i + 2];
+    sorted[pos] = make_float4(x, y, z, __int_as_float(i));
     order[pos] = i;
+    inv[i] = pos;
+    xyz[3 * (size_t)pos] = x; xyz[3 * (size_t)pos + 1] = y; xyz[3 * (size_t)pos + 2] = z;
 }
 
 // ---- search: one wavefront per query -----------------------------------------------------------------
@@ -226,7 +230,8 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
                const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                const float4* __restrict__ sorted,
                const float4* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
-               int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
+               int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint, const int* __restrict__ inv) {
+    // inv != NULL: INTERNAL numbering -- row wq (the visit position) instead of row qi, entries = inv[index]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QPB = 64 * NB_WAVES_PER_BLOCK / LPQ;   // queries per workgroup
     const int grp = threadIdx.x / LPQ, lane = threadIdx.x % LPQ;
@@ -376,9 +381,9 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
         if (want_kmax && n > __hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[0], n);
         if (!FIRST_ONLY && n > cap) atomicOr(&status[1], D3F_ST_HIT_OVERFLOW);
     }
-    int* row = out + (size_t)qi * ld;
+    int* row = out + (size_t)(inv ? wq : qi) * ld;
     if (FIRST_ONLY) {
-        if (lane == 0 && width > 0) row[0] = (n > 0) ? bidx : pad;
+        if (lane == 0 && width > 0) row[0] = (n > 0) ? (inv ? inv[bidx] : bidx) : pad;
         for (int j = 1 + lane; j < width; j += LPQ) row[j] = pad;
         return;
     }
@@ -399,7 +404,7 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
         const int mw = min(m, width);
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl)
-            if (lane + 16 * sl < mw) row[lane + 16 * sl] = (int)l4[sl];
+            if (lane + 16 * sl < mw) row[lane + 16 * sl] = inv ? inv[(int)l4[sl]] : (int)l4[sl];
         for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
         return;
     }
@@ -409,8 +414,8 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
         if (lane + 32 < m) { h1 = __float_as_uint(hd2[lane + 32]); l1 = (unsigned)hidx[lane + 32]; }
         nb_bitonic64(lane, h0, l0, h1, l1);
         const int mw = min(m, width);
-        if (lane < mw) row[lane] = (int)l0;
-        if (lane + 32 < mw) row[lane + 32] = (int)l1;
+        if (lane < mw) row[lane] = inv ? inv[(int)l0] : (int)l0;
+        if (lane + 32 < mw) row[lane + 32] = inv ? inv[(int)l1] : (int)l1;
         for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
         return;
     }
@@ -428,7 +433,7 @@ nb_search_body(const float* __restrict__ q, int Nq, const int* __restrict__ qlen
                 rank += (dj.z < kd || (dj.z == kd && ij.z < ki)) ? 1 : 0;
                 rank += (dj.w < kd || (dj.w == kd && ij.w < ki)) ? 1 : 0;
             }
-            if (rank < width) row[rank] = ki;
+            if (rank < width) row[rank] = inv ? inv[ki] : ki;
         }
     }
     for (int j = m + lane; j < width; j += LPQ) row[j] = pad;
@@ -440,9 +445,9 @@ nb_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ ql
                  const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                  const float4* __restrict__ sorted,
                  const float4* __restrict__ qorder, float r2, int pad, const int* __restrict__ ns_dev, int* __restrict__ out,
-                 int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint) {
+                 int ld, int width, int cap, int* __restrict__ status, int want_kmax, float nn_hint, const int* __restrict__ inv) {
     nb_search_body<FIRST_ONLY, LPQ, HINT>(q, Nq, qlens, B, el, cell_start, cell_base, sorted, qorder, r2, pad, ns_dev, out, ld, width,
-                                          cap, status, want_kmax, nn_hint);
+                                          cap, status, want_kmax, nn_hint, inv);
 }
 
 #include "nb_cell_search.h"
@@ -463,6 +468,8 @@ static long long nb_cell_budget(int Ns) {
 struct NbGrid {
     int* soffs; unsigned* bbox; NbElem* el; int* ncells; unsigned* counters; int* cell_cnt; int* cell_cur; int* cell_start; int* cell_of;
     float4* sorted; int* order; int* stmp;
+    int* inv;          // inverse of `order`: position of support i in the cell-sorted arrays (the INTERNAL numbering of the level)
+    float* xyz;        // f32[Ns, 3]: the supports in cell-sorted order (what a model running on the internal numbering reads)
     long long cells;
     bool ok;
 };
@@ -483,6 +490,8 @@ static NbGrid nb_carve(void* ws, size_t bytes, int Ns, int B) {
     g.sorted = ar.take<float4>(ns);
     g.order = ar.take<int>(ns);
     g.stmp = ar.take<int>(d3f_scan_base_ints((int)g.cells));
+    g.inv = ar.take<int>(ns);
+    g.xyz = ar.take<float>(3 * ns);
     g.ok = ar.ok;
     return g;
 }
@@ -496,6 +505,7 @@ extern "C" size_t d3f_neighbor_grid_bytes(int Ns, int B) {
     bytes += d3f_align((size_t)cells * 2 * sizeof(int)) + d3f_align((size_t)cells * sizeof(int));
     bytes += 2 * d3f_align(ns * sizeof(int)) + d3f_align(ns * sizeof(float4));
     bytes += d3f_align(d3f_scan_base_ints((int)cells) * sizeof(int));
+    bytes += d3f_align(ns * sizeof(int)) + d3f_align(3 * ns * sizeof(float));
     return bytes + 1024;
 }
 
@@ -505,6 +515,18 @@ extern "C" size_t d3f_neighbor_grid_order_offset(int Ns, int B) {
     if (Ns < 0 || B < 1) return 0;
     NbGrid g = nb_carve((void*)0x1000, (size_t)1 << 60, Ns, B);
     return (size_t)((char*)g.order - (char*)0x1000);
+}
+
+// byte offsets of `inv` i32[Ns] (position of support i in cell order) and `xyz` f32[Ns, 3] (the supports in cell order)
+extern "C" size_t d3f_neighbor_grid_inv_offset(int Ns, int B) {
+    if (Ns < 0 || B < 1) return 0;
+    NbGrid g = nb_carve((void*)0x1000, (size_t)1 << 60, Ns, B);
+    return (size_t)((char*)g.inv - (char*)0x1000);
+}
+extern "C" size_t d3f_neighbor_grid_xyz_offset(int Ns, int B) {
+    if (Ns < 0 || B < 1) return 0;
+    NbGrid g = nb_carve((void*)0x1000, (size_t)1 << 60, Ns, B);
+    return (size_t)((char*)g.xyz - (char*)0x1000);
 }
 
 extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int* s_lens_dev, int B, float radius,
@@ -532,7 +554,7 @@ extern "C" int d3f_neighbor_grid_build(const float* supports, int Ns, const int*
                                    stream)) != D3F_OK) return rc;
     if (Ns > 0) {
         nb_scatter_kernel<<<d3f_cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.soffs + B, g.cell_of, g.cell_start, g.stmp,
-                                                                 g.cell_cur, g.sorted, g.order);
+                                                                 g.cell_cur, g.sorted, g.order, g.inv, g.xyz);
         D3F_LAUNCH_CHECK();
     }
     return D3F_OK;
@@ -559,18 +581,21 @@ static int nb_env(const char* name, int dflt) {
 }
 static int nb_search_dispatch(const NbGrid& g, const float* queries, int Nq, const int* q_lens_dev, int B, float radius,
                               const float4* qsorted, bool queries_are_supports, int* out, int ld, int width, int pad_value, int cap,
-                              int first_only, float nn_hint, int want_kmax, int* status_dev, hipStream_t stream) {
+                              int first_only, float nn_hint, int want_kmax, int* status_dev, hipStream_t stream, bool internal = false) {
     const float r2 = radius * radius;
+    // internal numbering (D3F_NB_INTERNAL): rows by visit position (needs a visiting order), entries through the grid's `inv`
+    if (internal && !qsorted) return D3F_ERR_ARG;
+    const int* inv = internal ? g.inv : nullptr;
     if (first_only && !want_kmax) {
         const int mode = nb_env("D3F_NB_NEAREST", 1);
         if (mode == 2 || (mode == 1 && Nq >= 40000)) {
             const int blocks = d3f_cdiv(Nq, 64);
             if (nn_hint > 0.f)
                 nb_nearest_kernel<true><<<blocks, 256, 0, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted,
-                                                                    r2, pad_value, g.soffs + B, out, ld, width, nn_hint);
+                                                                    r2, pad_value, g.soffs + B, out, ld, width, nn_hint, inv);
             else
                 nb_nearest_kernel<false><<<blocks, 256, 0, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted,
-                                                                     r2, pad_value, g.soffs + B, out, ld, width, nn_hint);
+                                                                     r2, pad_value, g.soffs + B, out, ld, width, nn_hint, inv);
             D3F_LAUNCH_CHECK();
             return D3F_OK;
         }
@@ -591,7 +616,7 @@ static int nb_search_dispatch(const NbGrid& g, const float* queries, int Nq, con
             const int blocks = d3f_cdiv(d3f_cdiv(Nq, Q), 4);
             const size_t lds = (size_t)4 * ((size_t)cap * 8 + NBC_BATCH * 64 * 8);
             nb_cell_search_kernel<true><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
-                                                                      pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof);
+                                                                      pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof, inv);
             D3F_LAUNCH_CHECK();
             return D3F_OK;
         }
@@ -612,11 +637,11 @@ static int nb_search_dispatch(const NbGrid& g, const float* queries, int Nq, con
     if (FO_ && nn_hint > 0.f)                                                                                          \
         nb_search_kernel<FO_, LPQ_, FO_><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                             \
             queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted, r2, pad_value, g.soffs + B, out, ld, width, \
-            kcap, status_dev, want_kmax, nn_hint);                                                                     \
+            kcap, status_dev, want_kmax, nn_hint, inv);                                                                \
     else                                                                                                               \
     nb_search_kernel<FO_, LPQ_, false><<<blocks, 64 * NB_WAVES_PER_BLOCK, lds, stream>>>(                               \
         queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, qsorted, r2, pad_value, g.soffs + B, out, ld, width, \
-        kcap, status_dev, want_kmax, nn_hint)
+        kcap, status_dev, want_kmax, nn_hint, inv)
     if (first_only) { if (lpq == 64) D3F_NB(true, 64); else if (lpq == 32) D3F_NB(true, 32); else D3F_NB(true, 16); }
     else { if (lpq == 64) D3F_NB(false, 64); else if (lpq == 32) D3F_NB(false, 32); else D3F_NB(false, 16); }
 #undef D3F_NB
@@ -624,24 +649,33 @@ static int nb_search_dispatch(const NbGrid& g, const float* queries, int Nq, con
     return D3F_OK;
 }
 
-extern "C" int d3f_neighbor_grid_nearest(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
-                                         const int* q_lens_dev, int B, float radius, const void* query_grid, size_t query_grid_bytes,
-                                         int* out, int ld, int width, int pad_value, float nn_hint, void* stream_) {
+extern "C" int d3f_neighbor_grid_search_ordered(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                                                const int* q_lens_dev, int B, float radius, const void* query_grid,
+                                                size_t query_grid_bytes, int* out, int ld, int width, int pad_value, int cap,
+                                                int first_only, float nn_hint, int flags, int* status_dev, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (Nq < 0 || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || width < 0 || ld < width || !(radius >= 0.f)) return D3F_ERR_ARG;
     if (!(nn_hint >= 0.f) || nn_hint >= radius) nn_hint = 0.f;        // a hint only helps below the radius
-    if (!grid || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
+    if (cap < 1 || cap > D3F_NEIGHBOR_CAP) return D3F_ERR_ARG;
+    if (!grid || !status_dev || !q_lens_dev || (Nq > 0 && (!queries || (width > 0 && !out)))) return D3F_ERR_ARG;
+    if (flags & 1) { int rc0 = d3f_fill_u32(status_dev, 2, 0u, stream); if (rc0 != D3F_OK) return rc0; }
+    const int want_kmax = (flags & D3F_NB_NO_KMAX) ? 0 : 1;
     if (Nq == 0) return D3F_OK;
     NbGrid g = nb_carve((void*)grid, grid_bytes, Ns, B);
     if (!g.ok) return D3F_ERR_WORKSPACE;
     const float4* qsorted = nullptr;
-    if (query_grid) {
+    bool same = false;
+    if (query_grid == grid) {              // the queries ARE the supports
+        if (Nq != Ns) return D3F_ERR_ARG;
+        qsorted = g.sorted;
+        same = true;
+    } else if (query_grid) {
         NbGrid qg = nb_carve((void*)query_grid, query_grid_bytes, Nq, B);
         if (!qg.ok) return D3F_ERR_WORKSPACE;
         qsorted = qg.sorted;
     }
-    return nb_search_dispatch(g, queries, Nq, q_lens_dev, B, radius, qsorted, false, out, ld, width, pad_value, 4, 1, nn_hint, 0, nullptr,
-                              stream);
+    return nb_search_dispatch(g, queries, Nq, q_lens_dev, B, radius, qsorted, same, out, ld, width, pad_value, cap, first_only, nn_hint,
+                              want_kmax, status_dev, stream, (flags & D3F_NB_INTERNAL) != 0);
 }
 
 extern "C" int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,

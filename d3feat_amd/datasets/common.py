@@ -101,6 +101,8 @@ class Dataset:
         """
         if caps is not None:
             exact_shapes = False
+            if getattr(self, 'internal_order', False):
+                return self._descriptor_input_internal(config, stacked_points, stacked_features, stacked_lengths, caps)
         dev = stacked_points.device
         first_points, first_lengths = stacked_points, stacked_lengths
         lens_dev = ops.as_lens(stacked_lengths, dev)
@@ -264,6 +266,86 @@ class Dataset:
             stacked_batch_inds_1 = None
         li = input_points + input_neighbors + input_pools + input_upsamples
         li += [stacked_features, stacked_weights, stacked_batch_inds_0, stacked_batch_inds_1]
+        return li
+
+    def _descriptor_input_internal(self, config, stacked_points, stacked_features, stacked_lengths, caps):
+        """The capacity-mode pyramid in the INTERNAL numbering (round 6): every level lives in the cell order of its own conv grid.
+        Rows of neighbors[l] / pools[l] / upsamples[l] are the queries in their grid's cell order, the entries are positions in
+        the supports' cell order, points[l] is the level's cloud in that order (views into the grid objects).  Which supports
+        a row holds, and in which order, is exactly the reference's (datasets/common.py:1301-1413): renumbering back gives the
+        reference-order matrices bit for bit (FragmentEngine.reference_order_flat, tests/test_gpu_internal_order.py).  The
+        per-point kernels of the model then gather rows that are neighbours in MEMORY as well as in space; the subsamplings
+        still read the reference-order clouds (the barycentres are fp32 sums in input order), and the one return to the
+        reference's row order is the last kernel of the sequence (ops.pack_descriptors row_map = orders[0]).
+        -> the flat list; self.orders[l] (device i32: internal row -> reference row) / self.level_lengths beside it."""
+        dev = stacked_points.device
+        lens_dev = ops.as_lens(stacked_lengths, dev)
+        r_normal = config.first_subsampling_dl * config.KP_extent * 2.5
+        status_all = getattr(self, "_status_all", None)
+        if status_all is None or status_all.device != dev:
+            status_all = self._status_all = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+        elif not torch.cuda.is_current_stream_capturing():
+            status_all[:, 1].zero_()
+        arch = config.architecture
+        cap = getattr(self, '_neighbor_cap', 192)
+        pending = []
+
+        def status():
+            st = status_all[len(pending)]
+            pending.append(st)
+            return st
+
+        def search(grid, q, ql, qgrid, layer, first_only=False, nn_hint=0.0):
+            lim = 1 if first_only else int(self.neighborhood_limits[layer])
+            out, _ = grid.search(q, ql, lim, cap=cap, first_only=first_only, status=status(), reset_status=False, want_kmax=False,
+                                 nn_hint=nn_hint, query_grid=qgrid, internal=True)
+            return out
+        empty_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+        points, lens_l, grids = [stacked_points], [lens_dev], []
+        neighbors, pools, ups = [], [], []
+        layer_blocks = []
+        hints = getattr(self, 'hints', None)
+        units = max(int(getattr(self, 'cap_units', 1)), 1)
+        grids.append(ops.NeighborGrid(stacked_points, lens_dev, r_normal))
+        for block_i, block in enumerate(arch):
+            if 'global' in block or 'upsample' in block:
+                break
+            if 'deformable' in block:
+                raise ValueError("internal numbering: deformable blocks are outside the inference path")
+            if not ('pool' in block or 'strided' in block):
+                layer_blocks += [block]
+                if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
+                    continue
+            layer = len(neighbors)
+            P, L, G = points[layer], lens_l[layer], grids[layer]
+            pooled = 'pool' in block or 'strided' in block
+            if pooled:      # the next level's points and its grid first: pool_i's queries bring their own cell order
+                dl = 2 * r_normal / (config.KP_extent * 2.5)
+                pool_p, pool_b, _ = ops.batch_grid_subsample_async(P, L, dl, caps[layer + 1], status=status(),
+                                                                   m_hint=hints[layer + 1] if hints else 0,
+                                                                   elem_cap=-(-caps[layer + 1] // units),
+                                                                   elem_points=-(-caps[layer] // units))
+                Gn = ops.NeighborGrid(pool_p, pool_b, 2 * r_normal)
+            neighbors.append(search(G, P, L, G, layer) if layer_blocks else empty_i)
+            if pooled:
+                pools.append(search(G, pool_p, pool_b, Gn, layer))
+                # the supports of up_i are the voxel barycentres (edge dl) of the queries themselves: a hint, never a constraint
+                ups.append(search(Gn, P, L, G, layer, first_only=True, nn_hint=1.75 * dl))
+                points.append(pool_p)
+                lens_l.append(pool_b)
+                grids.append(Gn)
+            else:
+                pools.append(empty_i)
+                ups.append(empty_i)
+            r_normal *= 2
+            layer_blocks = []
+        self.static_status = status_all[:len(pending)]
+        self.level_lengths = lens_l
+        self.orders = [g.order for g in grids]            # internal row -> reference row, per level
+        self.level_points = points                        # the reference-order clouds (what the subsamplings read)
+        self._grids = grids                               # (the index matrices and point views live in the grid objects)
+        li = [g.xyz for g in grids] + neighbors + pools + ups
+        li += [stacked_features, None, ops.StackGroups(getattr(self, 'stack_group', 0)), None]
         return li
 
     # ---- neighbour-limit calibration -----------------------------------------------------------------------------------

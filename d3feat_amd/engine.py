@@ -53,7 +53,7 @@ class _Slot:
 class FragmentEngine:
     def __init__(self, config, weights, neighborhood_limits, raw_cap=320000, n0_cap=40000, level_ratio=0.4, slots=2,
                  device=None, seed=42, n0_hint=None, mirror_self_pair=False, streams=None, two_clouds=False, batch=1,
-                 bf16=False, bf16_features=False, stage0=True):
+                 bf16=False, bf16_features=False, stage0=True, internal_order=None):
         """raw_cap / n0_cap: raw points / voxels per FRAGMENT that a slot can take (a fragment beyond them is recomputed by
         the eager path).
         batch: fragments per graph replay.  The per-fragment cost of this path is dominated by the ~270 dependent launches
@@ -71,6 +71,11 @@ class FragmentEngine:
         BASELINE configs[4]) -- NOT the parity path: results differ from fp32 by the operand rounding.
         bf16_features=True (implies bf16): the activations between the layers are additionally STORED as bfloat16 -- "bf16
         features with MFMA contraction"; arithmetic inside every kernel stays fp32.
+        internal_order (default: on; D3F_INTERNAL_ORDER=0 switches it off): inside a replay every level is kept in the cell order of
+        its own neighbour grid -- index matrices, point arrays and activations (datasets/common.py: _descriptor_input_internal) --
+        so that the rows a workgroup gathers are neighbours in memory too; the last kernel of the sequence writes the records
+        back in the reference's row order.  Results are those of the reference numbering (bit for bit in this implementation:
+        every row's arithmetic is unchanged); reference_order_flat(slot) renumbers the slot's pyramid back for parity checks.
         stage0=False: the submitted clouds are ALREADY at the first subsampling resolution (the reference's scripts subsample
         before the dataset sees a cloud: demo_registration.py:24, datasets/ThreeDMatch.py:349) -- no stage-0 voxelisation, the
         cloud is stacked with itself as it is; raw_cap is then the voxel capacity n0_cap.
@@ -86,6 +91,10 @@ class FragmentEngine:
         self.raw_cap, self.n0_cap = int(raw_cap), int(n0_cap)
         self.mirror = bool(mirror_self_pair)
         self.two = bool(two_clouds)
+        if internal_order is None:
+            import os
+            internal_order = os.environ.get("D3F_INTERNAL_ORDER", "1") != "0"
+        self.internal = bool(internal_order)
         self.stage0 = bool(stage0)
         if not self.stage0:
             if self.mirror or self.two:
@@ -99,6 +108,9 @@ class FragmentEngine:
         if self.F < 1 or 2 * self.F * (2 if self.two else 1) > _lib.MAX_BATCH:
             raise ValueError("batch out of range")
         self.nin = self.F * (2 if self.two else 1)            # clouds handed to the stage-0 subsampling per replay
+        # clouds of a fragment's stack whose records a submit(out=...) destination receives: what the reference's testers keep of
+        # a stacked self-pair is its FIRST cloud (utils/tester.py:208-229: in_batches[0]); both frames of a pair of different clouds
+        self.keep_clouds = 2 if self.two else 1
         clouds = self.F * (1 if (self.mirror or self.two) else 2)
         self.level_ratio = float(level_ratio)
         self.caps = level_caps(n0_cap, config.num_layers, level_ratio, clouds)
@@ -157,9 +169,22 @@ class FragmentEngine:
         with ops.bf16_contraction(self.bf16, features=self.bf16_features):
             desc, score = self.model.run(flat)
         # the pyramid itself stays readable after a replay (parity checks, calibration): static buffers of the graph
+        # (internal numbering: in the cell order of every level -- reference_order_flat renumbers it back)
         sl.flat, sl.level_lengths = flat, sl.ds.level_lengths
+        row_map = None
+        if self.internal:
+            row_map = sl.ds.orders[0]                 # internal row -> reference row of level 0
+            ipts = flat[0]
+            ipts.n_dev = pts.n_dev
+            sl.orders = sl.ds.orders
         # one 144-byte record [xyz | desc | score] per point: a fragment's result is one contiguous block (fetch(packed=True))
-        sl.packed = ops.pack_descriptors(pts, desc, score)
+        # (submit(out=...): the records of a fragment's kept clouds go straight to the caller's buffer instead, through sl.dst_ptrs)
+        per = 1 if self.mirror else 2                       # stack entries per fragment
+        sl.packed = ops.pack_descriptors(flat[0] if self.internal else pts, desc, score, lens=lens, group=per, keep=self.keep_clouds,
+                                         dst=sl.dst_ptrs, row_map=row_map)
+        if self.internal:
+            # the separate outputs of fetch(packed=False) in the reference's row order: column views of the record block
+            desc, score = sl.packed[:, 3:3 + desc.shape[1]], sl.packed[:, 3 + desc.shape[1]:]
         return pts, desc, score, sl.ds.static_status, lens
 
     def _build_slot(self, stream=None):
@@ -167,13 +192,17 @@ class FragmentEngine:
         sl = _Slot()
         sl.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         sl.raw = torch.zeros((self.F * self.raw_cap, 3), dtype=torch.float32, device=dev)
-        # per-replay uploads, ONE block [addresses of the nin clouds (int64) | their lengths (int32)] and its pinned host mirror
-        sl.meta_dev = torch.zeros((3 * self.nin,), dtype=torch.int32, device=dev)
-        sl.meta_host = torch.zeros((3 * self.nin,), dtype=torch.int32).pin_memory()
+        # per-replay uploads, ONE block [addresses of the nin clouds (int64) | destinations of the F fragments' records (int64) |
+        # lengths of the clouds (int32)] and its pinned host mirror
+        nw = 2 * self.nin + 2 * self.F
+        sl.meta_dev = torch.zeros((nw + self.nin,), dtype=torch.int32, device=dev)
+        sl.meta_host = torch.zeros((nw + self.nin,), dtype=torch.int32).pin_memory()
         sl.raw_ptrs = sl.meta_dev[: 2 * self.nin].view(torch.int64)
-        sl.raw_len = sl.meta_dev[2 * self.nin:]
+        sl.dst_ptrs = sl.meta_dev[2 * self.nin: nw].view(torch.int64)
+        sl.raw_len = sl.meta_dev[nw:]
         sl.host_ptrs = sl.meta_host[: 2 * self.nin].view(torch.int64)
-        sl.host_n = sl.meta_host[2 * self.nin:]
+        sl.host_dst = sl.meta_host[2 * self.nin: nw].view(torch.int64)
+        sl.host_n = sl.meta_host[nw:]
         sl.status0 = torch.zeros((2,), dtype=torch.int32, device=dev)
         sl.ds = FragmentDataset([], fast=True)
         sl.ds.device = dev
@@ -184,6 +213,7 @@ class FragmentEngine:
         # every fragment is its own reference stack (a pair; one cloud when mirrored): the head's per-cloud normalisation
         # must not see the stack mates (models/D3Feat.py:84-85, datasets/common.py:453-496)
         sl.ds.stack_group = 1 if self.mirror else 2
+        sl.ds.internal_order = self.internal
         sl.ds._neighbor_cap = self.neighbor_cap
         sl.cap = self.neighbor_cap
         sl.map = sl.ds.get_tf_mapping(self.cfg)
@@ -219,9 +249,12 @@ class FragmentEngine:
         return sl
 
     # ---- per-fragment API -------------------------------------------------------------------------------------------
-    def submit(self, slot, raw):
+    def submit(self, slot, raw, out=None):
         """Start a replay on slot `slot`; returns immediately.  `raw`: one fragment (float32 [n,3] on the device or the host;
-        a pair (raw_a, raw_b) with two_clouds), or -- batch > 1 -- a list of up to `batch` fragments."""
+        a pair (raw_a, raw_b) with two_clouds), or -- batch > 1 -- a list of up to `batch` fragments.
+        out (with fetch(packed=True)): one destination per fragment, a contiguous f32[rows >= its kept rows, 36] device tensor -- the
+        [xyz | desc | score] records of the fragment's kept clouds (the first cloud of a stacked self-pair; both of two different
+        clouds) are written THERE by the replay's last kernel and fetch returns a view of it: no copy into the caller's shard."""
         sl = self.slots[slot]
         assert not sl.busy, "slot %d still holds an unfetched fragment" % slot
         if sl.cap != self.neighbor_cap:
@@ -233,6 +266,13 @@ class FragmentEngine:
             raise ValueError("submit: %d fragments for a batch-%d engine" % (len(frags), self.F))
         sl.single, sl.raw_src, sl.nfrag = single, frags, len(frags)
         sl.busy = True
+        outs = None
+        if out is not None and not self.mirror:
+            outs = [out] if (single and isinstance(out, torch.Tensor)) else list(out)
+            assert len(outs) == len(frags) and all(o.is_cuda and o.dtype == torch.float32 and o.is_contiguous() and o.dim() == 2
+                                                   and o.shape[1] == 36 for o in outs)
+        sl.out_dst = outs
+        sl.out_given = outs is not None
         parts = []
         for fr in frags:
             p = list(fr) if self.two else [fr]
@@ -271,6 +311,8 @@ class FragmentEngine:
                     addr = sl.raw[o:].data_ptr()
                 sl.host_ptrs[i] = addr
                 o += n
+            for f in range(self.F):
+                sl.host_dst[f] = sl.out_dst[f].data_ptr() if (sl.out_dst is not None and f < len(sl.out_dst)) else 0
             sl.meta_dev.copy_(sl.meta_host, non_blocking=True)
             sl.graph.replay()          # ends by packing [n_total | status0 | statuses | lens] into dev_stat
             sl.host_stat.copy_(sl.dev_stat, non_blocking=True)
@@ -284,6 +326,11 @@ class FragmentEngine:
         sl = self.slots[slot]
         assert sl.busy, "slot %d is empty" % slot
         sl.busy = False
+        # submit(out=...): every packed result of this fetch holds the KEPT clouds only, whichever path produced it
+        kept_only = packed and getattr(sl, "out_given", False)
+
+        def keep(rec):
+            return rec if (not kept_only or self.two) else rec[: rec.shape[0] // 2]
         outs, flags = None, 0
         if not sl.oversize:
             sl.done.synchronize()
@@ -295,7 +342,14 @@ class FragmentEngine:
                 outs, o = [], 0
                 for i in range(sl.nfrag):
                     n = sum(lens[i * per:(i + 1) * per])
-                    if packed:
+                    if packed and sl.out_dst is not None:
+                        nk = sum(lens[i * per:i * per + self.keep_clouds])
+                        if nk <= sl.out_dst[i].shape[0]:
+                            outs.append(sl.out_dst[i][:nk])              # written in place by the replay (kept clouds only)
+                        else:       # the destination was too small for this fragment: its rows are lost, recompute (never in bench)
+                            outs = None
+                            break
+                    elif packed:
                         r = sl.packed[o:o + n]
                         outs.append(torch.cat([r, r]) if self.mirror else r)
                     else:
@@ -323,11 +377,11 @@ class FragmentEngine:
                     self.fragments += 1
                     self.fallbacks += 1
                     o = self.run_eager(fr)
-                    outs.append(ops.pack_descriptors(*o) if packed else o)
+                    outs.append(keep(ops.pack_descriptors(*o)) if packed else o)
                     continue
                 self.submit(slot, [fr])
                 o = self.fetch(slot, packed)[0]                 # (counts the fragment, and its fallback if it takes one)
-                outs.append(o.clone() if packed else tuple(t.clone() for t in o))   # the slot's buffers are reused at once
+                outs.append(keep(o).clone() if packed else tuple(t.clone() for t in o))   # the slot's buffers are reused at once
             return outs[0] if single else outs
         self.fragments += sl.nfrag
         if outs is None:
@@ -348,8 +402,44 @@ class FragmentEngine:
                               % (self.fallbacks, self.fragments, self.raw_cap, self.n0_cap))
             outs = [self.run_eager(fr) for fr in sl.raw_src]
             if packed:
-                outs = [ops.pack_descriptors(*o) for o in outs]
+                outs = [keep(ops.pack_descriptors(*o)) for o in outs]
         return outs[0] if sl.single else outs
+
+    def reference_order_flat(self, slot):
+        """The pyramid of the slot's LAST replay as the reference numbers it (datasets/common.py:1301-1413): points, neighbors, pools,
+        upsamples of every level, renumbered back from the internal cell order (plain torch indexing on the real rows; a test / parity
+        aid, never on the timed path).  Without the internal numbering: the slot's own flat list.  Rows beyond a level's real count
+        are not defined."""
+        sl = self.slots[slot]
+        if not self.internal:
+            return sl.flat
+        L = self.cfg.num_layers
+        n = [int(sl.flat[l].n_dev.item()) if getattr(sl.flat[l], "n_dev", None) is not None else int(sl.flat[l].shape[0]) for l in range(L)]
+        order = [sl.orders[l][: n[l]].long() for l in range(L)]
+
+        def rows_back(x, l):            # internal row j -> reference row order[l][j]
+            out = torch.empty_like(x[: n[l]])
+            out[order[l]] = x[: n[l]]
+            return out
+
+        def values_back(x, l, pad):     # entries: positions in level l's cell order -> reference indices; padding stays
+            ext = torch.cat([order[l], torch.tensor([0], device=x.device)])
+            v = x.long()
+            valid = (v >= 0) & (v < n[l])
+            return torch.where(valid, ext[torch.where(valid, v, torch.full_like(v, n[l]))], v).to(torch.int32)
+        flat = list(sl.flat)
+        for l in range(L):
+            flat[l] = ops._tag(rows_back(sl.flat[l], l), sl.flat[l])
+            nb = sl.flat[L + l]
+            if nb.shape[0] > 0:
+                flat[L + l] = values_back(rows_back(nb, l), l, None)
+            pool = sl.flat[2 * L + l]
+            if pool.shape[0] > 0:
+                flat[2 * L + l] = values_back(rows_back(pool, l + 1), l, None)
+            up = sl.flat[3 * L + l]
+            if up.shape[0] > 0:
+                flat[3 * L + l] = values_back(rows_back(up, l), l + 1, None)
+        return flat
 
     def run_eager(self, raw):
         if isinstance(raw, ops.RawRecords):

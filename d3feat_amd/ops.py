@@ -308,15 +308,25 @@ class NeighborGrid:
         # support indices sorted by cell (a view into the grid object): a spatially coherent visiting order
         off = lib.d3f_neighbor_grid_order_offset(self.Ns, self.B)
         self.order = self.mem[off: off + 4 * max(self.Ns, 1)].view(torch.int32)
+        # the level in the INTERNAL (cell-sorted) numbering: position of every support in cell order, and the supports in that order
+        off = lib.d3f_neighbor_grid_inv_offset(self.Ns, self.B)
+        self.inv = self.mem[off: off + 4 * max(self.Ns, 1)].view(torch.int32)
+        off = lib.d3f_neighbor_grid_xyz_offset(self.Ns, self.B)
+        self.xyz = self.mem[off: off + 12 * max(self.Ns, 1)].view(torch.float32).view(-1, 3)
+        for a in ("n_dev", "n_hint"):
+            if getattr(self.supports, a, None) is not None:
+                setattr(self.xyz, a, getattr(self.supports, a))
 
     def search(self, queries, q_lens, width, ld=None, pad_value=None, cap=192, first_only=False, out=None, status=None,
-               reset_status=True, want_kmax=True, nn_hint=0.0, query_grid=None):
+               reset_status=True, want_kmax=True, nn_hint=0.0, query_grid=None, internal=False):
         """-> (out i32[Nq, ld], status i32[2] device tensor); no synchronisation.  reset_status=False: the caller has
         zeroed `status` (saves one launch per search).  want_kmax=False: status[0] (largest neighbour count) is not maintained
         (callers that allocate a fixed number of columns do not need it; see D3F_NB_NO_KMAX).  nn_hint (first_only): the distance
         within which the caller expects the nearest support -- a speed hint only, see include/d3feat_amd.h.
-        query_grid (first_only without want_kmax): a NeighborGrid built over `queries` themselves -- its cell order becomes the
-        visiting order of the nearest-support kernel (d3f_neighbor_grid_nearest); results do not depend on it."""
+        query_grid: a NeighborGrid built over `queries` themselves (or this grid when the queries are its supports) -- its cell order
+        becomes the visiting order (d3f_neighbor_grid_search_ordered); results do not depend on it.
+        internal=True (needs query_grid): the INTERNAL numbering -- row j belongs to the j-th query of query_grid's cell order and
+        the entries are positions in this grid's cell order (self.inv) instead of indices; pad_value is written as is."""
         lib = _lib.load()
         queries = _req(queries, torch.float32, "queries", 2).contiguous()
         dev = queries.device
@@ -333,19 +343,23 @@ class NeighborGrid:
         if pad_value is None:
             # BatchOrderedNeighbors pads with the number of supports: known only on the device in capacity mode
             pad_value = _lib.PAD_NUM_SUPPORTS if getattr(self.supports, "n_dev", None) is not None else self.Ns
-        if (first_only and not want_kmax and query_grid is not None and query_grid.Ns == Nq and query_grid.B == self.B
-                and query_grid.supports.data_ptr() == queries.data_ptr()):
-            if reset_status:
-                status.zero_()
-            with _timed("nb_nearest", dict(Nq=Nq, Ns=self.Ns, width=int(width)), dev):
-                rc = lib.d3f_neighbor_grid_nearest(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq, ql.data_ptr(),
-                                                   self.B, self.radius, query_grid.mem.data_ptr(), query_grid.nbytes, out.data_ptr(),
-                                                   ld, int(width), int(pad_value), float(nn_hint), _stream(dev))
-            _lib.check(rc, "neighbor_grid_nearest")
+        if query_grid is not None:
+            if query_grid.Ns != Nq or query_grid.B != self.B or query_grid.supports.data_ptr() != queries.data_ptr():
+                raise ValueError("query_grid was not built over these queries")
+            with _timed("nb_search", dict(Nq=Nq, Ns=self.Ns, width=int(width), first_only=int(bool(first_only))), dev):
+                rc = lib.d3f_neighbor_grid_search_ordered(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq, ql.data_ptr(),
+                                                          self.B, self.radius, query_grid.mem.data_ptr(), query_grid.nbytes,
+                                                          out.data_ptr(), ld, int(width), int(pad_value), int(cap),
+                                                          1 if first_only else 0, float(nn_hint),
+                                                          (1 if reset_status else 0) | (0 if want_kmax else 2) | (4 if internal else 0),
+                                                          status.data_ptr(), _stream(dev))
+            _lib.check(rc, "neighbor_grid_search_ordered")
             o = getattr(queries, "order", None)
-            if o is not None:
+            if o is not None and not internal:
                 out.order = o
             return _tag(out, queries), status
+        if internal:
+            raise ValueError("internal numbering needs the queries' grid")
         with _timed("nb_search", dict(Nq=Nq, Ns=self.Ns, width=int(width), first_only=int(bool(first_only))), dev):
             rc = lib.d3f_neighbor_grid_search(self.mem.data_ptr(), self.nbytes, self.Ns, queries.data_ptr(), Nq,
                                               ql.data_ptr(), self.B, self.radius, same, out.data_ptr(), ld, int(width),
@@ -1083,8 +1097,11 @@ def decode_xyz_records(raw, layout, out=None):
     return out[:n]
 
 
-def pack_descriptors(xyz, desc, score):
-    """-> f32[N, 3 + C + 1] records [xyz | desc | score] (one contiguous block per fragment of a stack)."""
+def pack_descriptors(xyz, desc, score, lens=None, group=1, keep=0, dst=None, row_map=None):
+    """-> f32[N, 3 + C + 1] records [xyz | desc | score] (one contiguous block per fragment of a stack).
+    dst (device int64[fragments] of ADDRESSES, 0 = none) with lens (device i32[B], the stack's clouds), group clouds per fragment:
+    the rows of the first `keep` clouds of fragment f are written to the address dst[f] instead (d3f_pack_descriptors_to).
+    row_map (device i32[N]): the inputs are in an internal row order, record n is written at row row_map[n]."""
     lib = _lib.load()
     xyz = _req(xyz, torch.float32, "xyz", 2).contiguous()
     desc, ldd = _rows(_req(desc, torch.float32, "desc"), "desc")
@@ -1094,8 +1111,20 @@ def pack_descriptors(xyz, desc, score):
         raise ValueError("pack_descriptors: %s points, %s descriptors, %s scores" % (tuple(xyz.shape), tuple(desc.shape),
                                                                                      tuple(score.shape)))
     out = torch.empty((N, Cc + 4), dtype=torch.float32, device=desc.device)
-    rc = lib.d3f_pack_descriptors(xyz.data_ptr(), desc.data_ptr(), ldd, Cc, score.data_ptr(), N, out.data_ptr(), Cc + 4,
-                                  _nd(xyz) or _nd(desc), _stream(desc.device))
+    if dst is not None or row_map is not None:
+        if dst is not None:
+            assert dst.dtype == torch.int64 and dst.is_contiguous() and lens is not None and lens.dtype == torch.int32
+            assert lens.numel() == dst.numel() * int(group)
+        if row_map is not None:
+            assert row_map.dtype == torch.int32 and row_map.is_contiguous() and row_map.numel() >= N
+        rc = lib.d3f_pack_descriptors_to(xyz.data_ptr(), desc.data_ptr(), ldd, Cc, score.data_ptr(), N, out.data_ptr(), Cc + 4,
+                                         _nd(xyz) or _nd(desc), lens.data_ptr() if lens is not None else None,
+                                         lens.numel() if lens is not None else 0, int(group), int(keep),
+                                         dst.data_ptr() if dst is not None else None,
+                                         row_map.data_ptr() if row_map is not None else None, _stream(desc.device))
+    else:
+        rc = lib.d3f_pack_descriptors(xyz.data_ptr(), desc.data_ptr(), ldd, Cc, score.data_ptr(), N, out.data_ptr(), Cc + 4,
+                                      _nd(xyz) or _nd(desc), _stream(desc.device))
     _lib.check(rc, "pack_descriptors")
     return _tag(out, desc)
 

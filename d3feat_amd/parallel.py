@@ -153,6 +153,7 @@ class ShardCollector:
                 w.wait()
         self.rows, self.frag_rows = 0, []
         self._works, self._over = [], []
+        self._reserved = 0
 
     def _grow(self, need):
         grown = torch.empty((max(2 * self.buf.shape[0], need), self.buf.shape[1]), dtype=torch.float32, device=self.buf.device)
@@ -164,6 +165,20 @@ class ShardCollector:
             if w is not None:
                 w.wait()
 
+    def slots(self, nfrags):
+        """Fixed-stride mode: the buffer rows reserved for the NEXT nfrags fragments, one f32[frag_rows, width] view each -- hand
+        them to FragmentEngine.submit(out=...) and the replay writes the records in place; `add` of a tensor that already lives
+        in its slot copies nothing.  None when the mode or the buffer's capacity does not allow it (add then copies, and grows).
+        Fragments must be added in the order they were reserved."""
+        if self.chunk_frags <= 0:
+            return None
+        k0, R = getattr(self, "_reserved", 0), self.frag_rows_cap
+        k0 = max(k0, len(self.frag_rows))
+        if (k0 + nfrags) * R > self.buf.shape[0]:
+            return None
+        self._reserved = k0 + nfrags
+        return [self.buf[(k0 + j) * R:(k0 + j + 1) * R] for j in range(nfrags)]
+
     def add(self, packed):
         n = int(packed.shape[0])
         if self.chunk_frags > 0:
@@ -174,6 +189,8 @@ class ShardCollector:
                 self._grow((k + self.chunk_frags) * R)
             if n > R:
                 self._over.append(packed.clone())      # its slot stays unused; exchanged by the trailing collective
+            elif n > 0 and packed.data_ptr() == self.buf[k * R:].data_ptr():
+                pass                                   # written in place by the replay (slots)
             else:
                 self.buf[k * R:k * R + n].copy_(packed, non_blocking=True)
             self.frag_rows.append(n)

@@ -171,15 +171,27 @@ int d3f_neighbor_grid_search(const void* grid, size_t grid_bytes, int Ns, const 
                              const int* q_lens_dev, int B, float radius, int queries_are_supports,
                              int* out, int ld, int width, int pad_value, int cap, int first_only, float nn_hint,
                              int reset_status, int* status_dev, void* stream);
-/* Column 0 only -- the nearest support inside the radius, ties by the smaller index (neighbors.cpp:125-208 row[0]; the only column
- * closest_pool reads of the upsampling matrices, models/network_blocks.py:81, datasets/common.py:1375) -- with one lane per query.
- * Same result as d3f_neighbor_grid_search(first_only = 1); columns 1..width-1 are filled with pad_value; no status words.
- *   query_grid   optional: a grid built by d3f_neighbor_grid_build over `queries` themselves (any radius; Nq rows capacity, the
- *                same B): the queries are then visited in ITS cell order, so neighbouring lanes walk the same support runs.
- *                NULL: plain order.  Results do not depend on it. */
-int d3f_neighbor_grid_nearest(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
-                              const int* q_lens_dev, int B, float radius, const void* query_grid, size_t query_grid_bytes,
-                              int* out, int ld, int width, int pad_value, float nn_hint, void* stream);
+/* The general form of d3f_neighbor_grid_search: the queries may bring a grid of their own.
+ *   query_grid   a grid built by d3f_neighbor_grid_build over `queries` themselves (any radius; Nq rows capacity, the same B), or
+ *                `grid` itself when the queries ARE the supports, or NULL.  The queries are visited in ITS cell order: neighbouring
+ *                wavefronts then read the same support runs.  Results do not depend on it -- unless D3F_NB_INTERNAL is set.
+ *   flags        bit 0: zero status_dev first; bit 1 (D3F_NB_NO_KMAX); bit 2 (D3F_NB_INTERNAL, needs query_grid): the INTERNAL
+ *                numbering of a pipeline that keeps every level in cell-sorted order -- row j of `out` belongs to the j-th query
+ *                in the query grid's cell order (not to query j), and every entry is the POSITION of that support in `grid`'s cell
+ *                order (d3f_neighbor_grid_inv_offset) instead of its index.  Which supports a row holds and their order (d2, then
+ *                the ORIGINAL index) are exactly those of the reference numbering: renumbering both sides back gives the
+ *                matrix of d3f_neighbor_grid_search bit for bit (tests/test_gpu_internal_order.py).  pad_value is written as is.
+ *   first_only with D3F_NB_NO_KMAX: column 0 by the nearest-support kernel (four lanes per query). */
+#define D3F_NB_INTERNAL 4
+int d3f_neighbor_grid_search_ordered(const void* grid, size_t grid_bytes, int Ns, const float* queries, int Nq,
+                                     const int* q_lens_dev, int B, float radius, const void* query_grid, size_t query_grid_bytes,
+                                     int* out, int ld, int width, int pad_value, int cap, int first_only, float nn_hint, int flags,
+                                     int* status_dev, void* stream);
+/* byte offsets inside a built grid of `inv` i32[Ns] (position of support i in cell order: the inverse of `order`) and of `xyz`
+ * f32[Ns, 3] (the supports in cell order: the point array of a level kept in the internal numbering). */
+size_t d3f_neighbor_grid_inv_offset(int Ns, int B);
+size_t d3f_neighbor_grid_xyz_offset(int Ns, int B);
+
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -347,6 +359,18 @@ int d3f_detect_head(const float* x, int N, int ldx, int C, const int* idx, int l
  * N is an upper bound when N_dev (device int) is given. */
 int d3f_pack_descriptors(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
                          int ldo, const int* N_dev, void* stream);
+/* d3f_pack_descriptors with per-fragment destinations: the stack holds B clouds (lens_dev), a fragment is `group` consecutive
+ * clouds; the rows of the first `keep` clouds of fragment f go to the address dst_ptrs_dev[f] (f32 rows of ldo floats, the
+ * fragment's kept rows packed from row 0) when that entry is non-zero, every other row to `out` as in d3f_pack_descriptors.
+ * What utils/tester.py:208-229 keeps of a stacked self-pair is its first cloud (in_batches[0]): group = 2, keep = 1 writes exactly
+ * that, straight into the caller's shard buffer -- a replayed sequence needs no copy after it.
+ * row_map_dev (optional, i32[N]): the inputs are in an internal row order (the cell order of the level-0 grid), record n belongs
+ * at row row_map_dev[n] of the reference order -- the one place where a pipeline on the internal numbering returns to the
+ * reference's row order.  dst_ptrs_dev may be NULL when only the row map is wanted. */
+int d3f_pack_descriptors_to(const float* xyz, const float* desc, int ldd, int C, const float* score, int N, float* out,
+                            int ldo, const int* N_dev, const int* lens_dev, int B, int group, int keep,
+                            const long long* dst_ptrs_dev, const int* row_map_dev, void* stream);
+
 
 /* LDS-DMA form of the fp32 contractions (round 4): the operator of d3f_gemm_f32 / d3f_gemm_upsample_cat_f32 with the same
  * composite A operand as d3f_gemm_bf16 below -- A f32[., C1] (rows in place when idx == NULL, else the gathered rows x'[idx[m,0]],

@@ -391,3 +391,43 @@ def test_in_place_weight_update_reaches_a_captured_engine(device, setup):
     with pytest.raises(ValueError):
         k = next(k for k in W if k.endswith("kernel_points"))
         eng.refresh_weights({k: W[k] + 1.0})
+
+
+def test_records_written_in_place_equal_the_copied_ones(device, setup):
+    """FragmentEngine.submit(out=...): the replay's last kernel writes the [xyz | desc | score] records of a fragment's KEPT cloud
+    (the first of the stacked self-pair, utils/tester.py:208-229) straight into the caller's buffer (d3f_pack_descriptors_to) and
+    the raw clouds are read in place (d3f_batch_grid_subsample_async_inplace): bit-identical to the slot's own record block, for
+    one fragment and for a batch, also when a fragment of the batch takes the eager fallback."""
+    from d3feat_amd import ops
+    from d3feat_amd.engine import FragmentEngine
+    from d3feat_amd.parallel import ShardCollector
+    cfg, W, limits = setup
+    raws = [torch.from_numpy(_frag(s, n)).to(device) for s, n in ((21, 30000), (22, 26000), (23, 34000))]
+    eng = FragmentEngine(cfg, W, limits, raw_cap=40000, n0_cap=10000, slots=2, device=device, batch=3)
+    eng.submit(0, raws)
+    want = [r.clone() for r in eng.fetch(0, packed=True)]
+    col = ShardCollector(rows_cap=8 * 10240, width=36, device=device, chunk_frags=4, frag_rows=10240)
+    dst = col.slots(3)
+    assert dst is not None and len(dst) == 3
+    eng.submit(1, raws, out=dst)
+    got = eng.fetch(1, packed=True)
+    for w, g, d in zip(want, got, dst):
+        half = w.shape[0] // 2
+        assert g.shape[0] == half and g.data_ptr() == d.data_ptr()
+        assert torch.equal(g, w[:half]) and torch.equal(w[:half, :3], w[half:, :3])
+        col.add(g)
+    assert col.frag_rows == [int(w.shape[0] // 2) for w in want]
+    parts, rows = col.gather(compact=False)[0]
+    assert all(torch.equal(p, w[: w.shape[0] // 2]) for p, w in zip(parts, want))
+    # the raw clouds were read where they are: no copy into the slot's staging buffer happened for device tensors
+    assert int(eng.slots[1].host_ptrs[0]) == raws[0].data_ptr()
+    # a batch with an oversize fragment: that one comes from the eager path (kept half only, a fresh tensor), the others in place
+    big = torch.from_numpy(_frag(24, 60000)).to(device)
+    col.reset()
+    dst = col.slots(2)
+    eng.submit(0, [raws[0], big], out=dst)
+    got = eng.fetch(0, packed=True)
+    assert eng.fallbacks >= 1 and torch.equal(got[0], want[0][: want[0].shape[0] // 2])
+    ep, ed, es = eng.run_eager(big)
+    rec = ops.pack_descriptors(ep, ed, es)
+    assert torch.equal(got[1], rec[: rec.shape[0] // 2])

@@ -75,6 +75,7 @@ def test_config2_full_size_engine_vs_oracle(device, coracle):
         outs = eng.fetch(slot)
         assert eng.fallbacks == 0
         sl = eng.slots[slot]
+        flat = eng.reference_order_flat(slot)      # (the slot's pyramid lives in the internal cell order: renumbered back)
         totals = [int(sl.flat[l].n_dev.item()) for l in range(L)]
         lens = [x.tolist() for x in sl.level_lengths]            # per level: [n_1, n_1, n_2, n_2, ...] (+ stand-ins)
         for j, fi in enumerate(members):
@@ -82,9 +83,9 @@ def test_config2_full_size_engine_vs_oracle(device, coracle):
             offsets = [sum(lens[l][: 2 * j]) for l in range(L)]
             for l in range(L):
                 assert lens[l][2 * j] == lens[l][2 * j + 1] == ref["inp"]["points"][l].shape[0] // 2
-            par.check_pyramid_slice(sl.flat, ref, L, offsets, totals, fast=True)
+            par.check_pyramid_slice(flat, ref, L, offsets, totals, fast=True)
             p, d, s = (t.cpu().numpy() for t in outs[j])
-            c = par.compare_fragment(ref, p, d, s, nb0=sl.flat[L].cpu().numpy(), row0=offsets[0], total=totals[0])
+            c = par.compare_fragment(ref, p, d, s, nb0=flat[L].cpu().numpy(), row0=offsets[0], total=totals[0])
             assert c["points_equal"] and c["idx_equal"], c
             assert c["desc_max_abs"] <= TOL and c["score_max_abs"] <= TOL, c
     # ---- the packed record view is the same data
