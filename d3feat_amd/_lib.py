@@ -49,6 +49,8 @@ SIGNATURES = {
     "d3f_kpconv_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "d3f_kpconv_fused": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i,
                               _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "d3f_kpconv_fused32_mfma": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp,
+                                _i, _vp, _vp, _vp, _vp]),
     "d3f_kpconv_fused32_x3": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp,
                                    _i, _vp, _vp, _vp, _i, _vp]),
     "d3f_kpconv_packed_x3_bytes": (_sz, [_i, _i]),

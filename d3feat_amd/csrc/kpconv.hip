@@ -920,6 +920,246 @@ static int kp_fused32_launch(const float* q, int Nq, const float* s, int Ns, con
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }
+// ------------------------------------------------------------------------------------------------
+// Cin = Cout = 32 with the AGGREGATION on the matrix cores too (round 6).
+// kpconv_fused32_kernel is bound by vector issue: per 8-neighbour chunk and wavefront ~95 instructions of influence arithmetic and
+// ~380 for the 480 multiply-adds per lane (60 accumulators x 8 neighbours as v_pk_fma, plus the LDS broadcasts of the influences).
+// wf[q] = W_q^T F_q is a [15 x K] x [K x 32] product per query -- v_mfma_f32_16x16x1_4b_f32 does FOUR such rank-1 updates per
+// instruction (one per 16-lane block), in exact fp32 and in the same neighbour order as the FMA chains (the instruction IS an fmaf
+// chain over k): lanes 16 b .. 16 b + 15 of a wavefront belong to query b of a group of four; as the A operand lane i supplies the
+// influence of kernel point i on the step's neighbour (one ds_read_b32 from phase A's records), as the B operands channels 2 i and
+// 2 i + 1 of the neighbour's feature row (one 8-byte buffer load; shadows read zeros through the range check).  Two accumulator
+// chains of 16 registers per group; the matrix pipe does the 17.8 k multiply-adds of a query in ~600 cycles while the vector pipe
+// computes the next chunk's influences: the two halves of the old kernel's 1190 cycles per query overlap instead of adding up.
+//   * phase A as before: thread (query, neighbour of the chunk) -> 16 influences in LDS.  The eight queries of a wavefront's
+//     phase B are exactly the queries its own lanes served in phase A: NO workgroup barrier inside the neighbour loop.
+//   * D layout (tools/ubench/mfma_16x16x1_layout.hip, checked on the hardware): register r of lane l holds query r / 4 of the group,
+//     kernel point 4 (l / 16) + r % 4, channel 2 (l % 16) + chain.  The weighted-feature tile goes to LDS with k' = 16 c + p
+//     (channel-major, 16 kernel-point slots, the 16th with zero weights: K' = 512): a lane's four registers of a query are four
+//     consecutive k' -> one 8-byte store per plane.  Four passes of 8 channels (128 k', 26 KB for the three bf16 planes);
+//   * the contraction as in kf32_contract_epilogue_x3: v_mfma_f32_32x32x16_bf16 on the three-plane split, each wavefront two of a
+//     pass's eight 16-deep steps (48 MFMAs per wavefront and tile), W pre-split in fragment order over k' (the packed copy of
+//     K_values permuted to [c][16][n]: d3f_kpconv_pack_weights_x3 of that matrix).
+// The shipped configuration only (15 kernel points, linear influence, sum); fp32 features.
+// ------------------------------------------------------------------------------------------------
+#define KM_PC 16                         // channels per contraction pass: the even ones (chain 0), then the odd ones (chain 1)
+#define KM_KT (KM_PC * 16)               // k' values per pass
+#define KM_TS (KM_KT + 8)                // bf16 per plane row (528 bytes: 16 lanes of a fragment read on 16 distinct 4-bank groups)
+#define KM_REGION (3 * KF_TQ * KM_TS * 2)   // bytes of the three planes of a pass: the largest life of the LDS region
+__global__ void __launch_bounds__(256, 3)
+kpconv_fused32m_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ s, int Ns, const int* __restrict__ idx,
+                       int ld_idx, int K, const float* __restrict__ f, int ldf, const unsigned char* __restrict__ rowpos,
+                       KpParams P, const unsigned short* __restrict__ Wx, KpEpi E, float* __restrict__ out, int ldo,
+                       const int* __restrict__ Nq_dev, const int* __restrict__ Ns_dev, const int* __restrict__ q_order) {
+    Nq = d3f_dyn(Nq, Nq_dev);
+    Ns = d3f_dyn(Ns, Ns_dev);
+    const KpFeatBuf<float> fbuf(f, Ns, ldf);
+    if ((int)(blockIdx.x * KF_TQ) >= Nq) return;
+    const int tile = (int)d3f_xcd_tile(blockIdx.x, (unsigned)((Nq + KF_TQ - 1) / KF_TQ));
+    // one LDS region, three lives: the influence records [32][132] floats of the neighbour loop, then the three bf16 planes
+    // [32][136] of a contraction pass, then the four partial out tiles
+    constexpr int PL = KF_TQ * KM_TS;                        // bf16 per plane
+    static_assert(2 * KF_TQ * KF_WS * 4 <= KM_REGION && 4 * 1024 * 4 <= KM_REGION && KM_REGION % 16 == 0, "region");
+    extern __shared__ __attribute__((aligned(16))) float kf_smem[];
+    float* lw = kf_smem;
+    int* lidx = (int*)(kf_smem + KM_REGION / 4);             // [2][32][8]   (behind the region)
+    int* lcnt = lidx + 2 * KF_TQ * KF_LQ;                    // [32]
+    int* lq = lcnt + KF_TQ;                                  // [32] global query index of each tile row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = tid / KF_LQ, cl = tid % KF_LQ;            // phase A: (query of the tile, neighbour of the chunk)
+    const int qslot = tile * KF_TQ + ql;
+    const int qg = (q_order && qslot < Nq) ? q_order[qslot] : qslot;
+    if (tid < KF_TQ) lcnt[tid] = 0;
+    if (cl == 0) lq[ql] = qslot < Nq ? qg : -1;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (qslot < Nq) { qx = q[3 * (size_t)qg]; qy = q[3 * (size_t)qg + 1]; qz = q[3 * (size_t)qg + 2]; }
+    const int* idrow = idx + (qslot < Nq ? __umul24((unsigned)qg, (unsigned)ld_idx) : 0u);
+    // every index of the tile up front, through LDS (32 rows x K <= 64): the loop below then depends on no load it has just issued
+    // -- one index round trip per tile instead of one per chunk on every wavefront's critical path; the support points of the
+    // first two chunks right behind
+    int* lall = lq + KF_TQ;                                  // [32][64]
+    for (int e = tid; e < KF_TQ * 64; e += 256) {
+        const int r = e >> 6, k = e & 63;
+        const int qs = tile * KF_TQ + r;
+        int v = Ns;
+        if (qs < Nq && k < K) {
+            const int g = q_order ? q_order[qs] : qs;
+            v = idx[__umul24((unsigned)g, (unsigned)ld_idx) + k];
+        }
+        lall[e] = v;
+    }
+    __syncthreads();
+    KpPair pr = kp_pair_fetch(lall[ql * 64 + cl], Ns, s, rowpos);                        // chunk 0's pair
+    KpPair pr2 = kp_pair_fetch(lall[ql * 64 + KF_LQ + cl], Ns, s, rowpos);               // chunk 1's pair
+    // phase B: lane = (query b of the group, kernel point / channel pair i)
+    const int b = lane >> 4, i = lane & 15;
+    int aoff[4];                                             // position of element i inside a record whose quads are rotated by 0..3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) aoff[r] = ((((i >> 2) + r) & 3) << 2) + (i & 3);
+    kp_f32x16 acc[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][0][r] = acc[g][1][r] = 0.f;
+    __syncthreads();                                         // lcnt / lq
+    // The records (influences, row offsets) are double buffered: phase A of chunk c + 1 runs -- vector work -- while the feature rows
+    // of chunk c are on their way and before its rank-1 updates occupy the matrix pipe; nothing in the loop waits for a round trip
+    // it has just started.
+    constexpr int LWB = KF_TQ * KF_WS;                       // floats per record buffer
+    auto phase_a = [&](int buf, int k0_next_index) {
+        float w[KP_MAXP];
+        const bool positive = kp_pair_influences<true>(P, pr, qx, qy, qz, w);
+        kp_count_positive<KF_LQ>(positive, ql, cl, lcnt);
+        // the byte offset of the neighbour's feature row, once per pair (a shadow: beyond the buffer -> the range check returns
+        // zeros), instead of a multiply per lane and step in phase B
+        lidx[buf * (KF_TQ * KF_LQ) + ql * KF_LQ + cl] = pr.id >= 0 ? (int)(__umul24((unsigned)pr.id, (unsigned)ldf) * 4u) : (int)0xfffffff0u;
+        kp_store_w(&lw[buf * LWB + ql * KF_WS + cl * 16], cl, w);
+        (void)k0_next_index;
+    };
+    phase_a(0, 0);
+    pr = pr2;
+    for (int c = 0, k0 = 0; k0 < K; ++c, k0 += KF_LQ) {
+        const int buf = c & 1;
+        // (the records this wavefront reads were written by its own lanes: wavefront-level ordering is enough)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool more = k0 + KF_LQ < K;
+        // the pair of chunk c + 2: in flight over this chunk's loads and updates and the next chunk's phase A
+        if (k0 + 2 * KF_LQ < K) pr2 = kp_pair_fetch(lall[ql * 64 + k0 + 2 * KF_LQ + cl], Ns, s, rowpos);
+        // ---- the chunk's feature rows: all sixteen steps (two groups of four queries x eight neighbours) requested at once ----
+        unsigned offs[2][KF_LQ];
+        float2 fv[2][KF_LQ];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int row = wave * 8 + g * 4 + b;            // tile row of this lane's query
+#pragma unroll
+            for (int k1 = 0; k1 < KF_LQ; ++k1) {
+                offs[g][k1] = (unsigned)lidx[buf * (KF_TQ * KF_LQ) + row * KF_LQ + k1];
+                typedef unsigned kp_u2 __attribute__((ext_vector_type(2)));
+                const unsigned off = offs[g][k1] == 0xfffffff0u ? 0xfffffff0u : offs[g][k1] + 8u * (unsigned)i;   // (lane offset on real rows only)
+                const kp_u2 v = __builtin_amdgcn_raw_buffer_load_b64(fbuf.r, (int)off, 0, 0);
+                fv[g][k1] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+            }
+        }
+        if (more) {
+            phase_a(buf ^ 1, 0);                             // ---- phase A of the NEXT chunk, under the loads ----
+            pr = pr2;
+        }
+        // ---- phase B: one rank-1 update per neighbour and chain, four queries per instruction ----
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int row = wave * 8 + g * 4 + b;
+            float av[KF_LQ];
+#pragma unroll
+            for (int k1 = 0; k1 < KF_LQ; ++k1)               // the record's quads are rotated by slot / 2 (kp_store_w)
+                av[k1] = lw[buf * LWB + row * KF_WS + k1 * 16 + aoff[k1 >> 1]];
+#pragma unroll
+            for (int k1 = 0; k1 < KF_LQ; ++k1) {
+                if (!__any(offs[g][k1] != 0xfffffff0u)) continue;   // (wavefront-uniform) a shadow slot for all four queries
+                acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(av[k1], fv[g][k1].x, acc[g][0], 0, 0, 0);
+                acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(av[k1], fv[g][k1].y, acc[g][1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- contraction: two passes of 16 channels -- the even ones (chain 0), then the odd ones (chain 1): EVERY lane writes the
+    //      registers of one chain per pass (a pass by lane subsets issued every store four times with a quarter of the lanes) ----
+    unsigned short* tile3 = (unsigned short*)kf_smem;
+    kp_f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    const uint4* bw = (const uint4*)Wx + lane;               // + (step * 3 + plane) * 64
+    const unsigned short* ap = tile3 + (lane & 31) * KM_TS + 8 * (lane >> 5);
+#define KM_BLOAD(B_, ST_)                                                                                          \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) B_[pl] = bw[(size_t)((ST_) * 3 + pl) * 64]; \
+    } while (0)
+#define KM_STEP(B_, LS_)                                                                                                       \
+    do {                                                                                                                       \
+        uint4 a_[3];                                                                                                           \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) a_[pl] = *(const uint4*)(ap + pl * PL + 16 * (LS_));                  \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[2]), __builtin_bit_cast(kp_bf16x8, B_[0]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[1]), __builtin_bit_cast(kp_bf16x8, B_[0]), c1, 0, 0, 0); \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[1]), __builtin_bit_cast(kp_bf16x8, B_[1]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[2]), c1, 0, 0, 0); \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[1]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kp_bf16x8, a_[0]), __builtin_bit_cast(kp_bf16x8, B_[0]), c1, 0, 0, 0); \
+    } while (0)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        // this wavefront's four 16-deep steps of the pass: local steps wave, wave + 4, + 8, + 12 (a step = one channel's 16 slots)
+        uint4 b0[3], b1[3];
+        KM_BLOAD(b0, pass * 16 + wave);
+        KM_BLOAD(b1, pass * 16 + wave + 4);
+        __syncthreads();                                     // the region's previous life (records / the last pass's planes) is over
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 pl[3];
+                kx_split4(acc[g][pass][4 * t], acc[g][pass][4 * t + 1], acc[g][pass][4 * t + 2], acc[g][pass][4 * t + 3], pl);
+                // row = query 8 wave + 4 g + t; column = 16 i (this lane's channel 2 i + pass) + 4 b: kernel points 4 b .. 4 b + 3
+                unsigned short* d = tile3 + (wave * 8 + g * 4 + t) * KM_TS + i * 16 + 4 * b;
+                *(uint2*)d = pl[0];
+                *(uint2*)(d + PL) = pl[1];
+                *(uint2*)(d + 2 * PL) = pl[2];
+            }
+        __syncthreads();
+        KM_STEP(b0, wave);
+        KM_BLOAD(b0, pass * 16 + wave + 8);
+        KM_STEP(b1, wave + 4);
+        KM_BLOAD(b1, pass * 16 + wave + 12);
+        KM_STEP(b0, wave + 8);
+        KM_STEP(b1, wave + 12);
+    }
+#undef KM_STEP
+#undef KM_BLOAD
+    __syncthreads();
+    // partial tiles -> LDS (the region is free now), sum of the four in wave order, epilogue (as the other forms)
+    float* red = kf_smem;                                   // [4][32*32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[wave * 1024 + row * 32 + (lane & 31)] = c0[r] + c1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + j * 256, row = e >> 5, o = e & 31;
+        const int gq = lq[row];
+        if (gq < 0) continue;
+        float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+        v *= 1.0f / fmaxf((float)lcnt[row], 1.0f);
+        if (E.col_scale) v *= E.col_scale[o];
+        if (E.col_shift) v += E.col_shift[o];
+        if (E.residual) v += E.residual[(size_t)gq * E.ldr + o];
+        if (E.leaky) v = v > 0.f ? v : v * E.alpha;
+        out[(size_t)gq * ldo + o] = v;
+    }
+}
+
+// W = d3f_kpconv_pack_weights_x3 of the [512, 32] matrix W'[16 s + p][n] = K_values[p][c(s)][n] (p < 15), 0 (p = 15), with
+// c(s) = 2 s for s < 16 (the even channels first), 2 (s - 16) + 1 after
+extern "C" int d3f_kpconv_fused32_mfma(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                                       const float* f, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                                       float KP_extent, int influence, int aggregation, const void* Wx, const float* col_scale,
+                                       const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out,
+                                       int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Nq < 0 || Ns < 0 || K < 0 || ld_idx < K || ldf < 32 || (ldf % 4) || !(KP_extent > 0.f) || ldo < 32 || (residual && ldr < 32))
+        return D3F_ERR_ARG;
+    if (!kp_fast_config(num_kp, influence, aggregation) || K > 64) return D3F_ERR_ARG;      // (eight chunks of eight neighbours)
+    if (Nq == 0) return D3F_OK;
+    if (!q || !s || !idx || !f || !rowpos || !kp_host || !Wx || !out || (((uintptr_t)f | (uintptr_t)Wx) & 15)) return D3F_ERR_ARG;
+    if (!kp_fits_u24(Nq, Ns, ld_idx, ldf)) return D3F_ERR_ARG;
+    const KpParams P = kp_make_params(kp_host, num_kp, KP_extent, influence, aggregation);
+    KpEpi E{col_scale, col_shift, residual, ldr, leaky, alpha};
+    const size_t lds = (size_t)KM_REGION + (size_t)(2 * KF_TQ * KF_LQ + 2 * KF_TQ + KF_TQ * 64) * sizeof(int);
+    kpconv_fused32m_kernel<<<d3f_cdiv(Nq, KF_TQ), 256, lds, stream>>>(q, Nq, s, Ns, idx, ld_idx, K, f, ldf, rowpos, P,
+                                                                      (const unsigned short*)Wx, E, out, ldo, Nq_dev, Ns_dev, q_order);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+}
+
 #define KP_F32_ARGS                                                                                                               \
     const float *q, int Nq, const float *s, int Ns, const int *idx, int ld_idx, int K, const void *f_, int ldf,                   \
         const unsigned char *rowpos, const float *kp_host, int num_kp, float KP_extent, int influence, int aggregation,           \

@@ -512,7 +512,8 @@ def refresh_packed_weights(tensors):
                     off, shape, st0 = key
                     fn(base.as_strided(shape, (st0, 1), off))
                     n += 1
-        for slot, fn in (("_d3f_packed", packed_kpconv_weights), ("_d3f_packed_x3", packed_kpconv_weights_x3)):
+        for slot, fn in (("_d3f_packed", packed_kpconv_weights), ("_d3f_packed_x3", packed_kpconv_weights_x3),
+                         ("_d3f_packed_x3m", packed_kpconv_weights_x3m)):
             hit = getattr(t, slot, None)
             if hit is not None and hit[0] != t._version:
                 fn(t)
@@ -852,7 +853,13 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     if cin != 32 or cout != 32 or f.shape[1] != 32:
         raise ValueError("kpconv_fused32 needs Cin == Cout == 32")
     x3 = KP_X3 and (num_kp * cin) % 32 == 0
-    W = packed_kpconv_weights_x3(K_values) if x3 else _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
+    # the aggregation on the matrix cores as well (d3f_kpconv_fused32_mfma): the shipped configuration, fp32 features
+    mfma = (KP_MFMA and x3 and num_kp == 15 and KP_influence == "linear" and aggregation_mode == "sum" and f.dtype == torch.float32
+            and idx.shape[1] <= 64)
+    if mfma:
+        W = packed_kpconv_weights_x3m(K_values)
+    else:
+        W = packed_kpconv_weights_x3(K_values) if x3 else _req(K_values, torch.float32, "K_values").reshape(num_kp * cin, cout).contiguous()
     Nq, Ns, K = q.shape[0], s.shape[0], idx.shape[1]
     dev = q.device
     out = torch.empty((Nq, cout), dtype=f.dtype, device=dev)
@@ -865,6 +872,17 @@ def kpconv_fused32(query_points, support_points, neighbors_indices, features, K_
     if ns_dev is None:
         ns_dev = _nd(features)
     _lib.check(lib.d3f_row_positive(f.data_ptr(), Ns, ldf, 32, row_pos.data_ptr(), ns_dev, _h(f), st), "row_positive")
+    if mfma:
+        with _timed("kpconv_fused32", dict(Nq=Nq, Ns=Ns, K=K, Cin=32, Cout=32), dev):
+            rc = lib.d3f_kpconv_fused32_mfma(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
+                                             row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
+                                             _AGGREGATION[aggregation_mode], W.data_ptr(),
+                                             col_scale.data_ptr() if col_scale is not None else None,
+                                             col_shift.data_ptr() if col_shift is not None else None,
+                                             residual.data_ptr() if residual is not None else None, ldr, 1 if leaky else 0,
+                                             float(alpha), out.data_ptr(), cout, nq_dev, ns_dev, _order(query_points), st)
+        _lib.check(rc, "kpconv_fused32_mfma")
+        return _tag(out, query_points)
     with _timed("kpconv_fused32", dict(Nq=Nq, Ns=Ns, K=K, Cin=32, Cout=32), dev):
         rc = (lib.d3f_kpconv_fused32_x3 if x3 else lib.d3f_kpconv_fused32)(q.data_ptr(), Nq, s.data_ptr(), Ns, idx.data_ptr(), ld_idx, K, f.data_ptr(), ldf,
                                     row_pos.data_ptr(), kp.ctypes.data, num_kp, float(KP_extent), _INFLUENCE[KP_influence],
@@ -906,6 +924,34 @@ def packed_kpconv_weights(K_values):
 # bf16 planes per operand, six exact products per fp32 product, fp32 accumulate -- fp32 in, fp32 out); D3F_KP_X3=0 keeps the
 # v_mfma_f32_16x16x4_f32 form.
 KP_X3 = os.environ.get("D3F_KP_X3", "1") != "0"
+
+
+# the level-0 KPConv with its aggregation on the matrix cores too (csrc/kpconv.hip: kpconv_fused32m_kernel): OFF by default -- built,
+# verified (tests/test_gpu_kpconv_x3.py) and measured SLOWER than the vector form (profiles/r06_experiments.txt k1-k6: 247-298 against
+# 220-235 us per level-0 launch at F = 4): these kernels are bound by the latency of a workgroup's dependent chain at three workgroups
+# per CU, not by the vector pipe.  D3F_KP_MFMA=1 selects it.
+KP_MFMA = os.environ.get("D3F_KP_MFMA", "0") == "1"
+
+
+def packed_kpconv_weights_x3m(K_values):
+    """K_values f32[15, Cin, Cout] -> the pre-split bf16 planes of W'[16 s + p][n] = K_values[p][c(s)][n] (p < 15; 0 for the 16th slot;
+    c(s) = the even channels, then the odd ones):
+    the channel-major k order in which the matrix-core aggregation leaves its weighted features.  Rides on the tensor like the other
+    packed copies (re-packed in place when the tensor's version changes)."""
+    cached = getattr(K_values, "_d3f_packed_x3m", None)
+    if cached is not None and cached[0] == K_values._version:
+        return cached[1]
+    lib = _lib.load()
+    num_kp, cin, cout = K_values.shape
+    Wp = torch.zeros((cin, 16, cout), dtype=torch.float32, device=K_values.device)
+    order = list(range(0, cin, 2)) + list(range(1, cin, 2))             # the even channels (chain 0 of the kernel), then the odd ones
+    Wp[:, :num_kp] = _req(K_values, torch.float32, "K_values").permute(1, 0, 2)[order]
+    Wp = Wp.reshape(cin * 16, cout).contiguous()
+    Wx = cached[1] if cached is not None else \
+        torch.empty((int(lib.d3f_kpconv_packed_x3_bytes(cin * 16, cout)) // 2,), dtype=torch.int16, device=Wp.device)
+    _lib.check(lib.d3f_kpconv_pack_weights_x3(Wp.data_ptr(), cin * 16, cout, Wx.data_ptr(), _stream(Wp.device)), "kpconv_pack_weights_x3")
+    K_values._d3f_packed_x3m = (K_values._version, Wx)
+    return Wx
 
 
 def packed_kpconv_weights_x3(K_values):

@@ -261,6 +261,18 @@ int d3f_kpconv_pack_weights(const float* W, int K, int N, float* W_packed, void*
 /* (N = 32: the fragment order of d3f_kpconv_fused32_x3, v_mfma_f32_32x32x16_bf16; any other N: d3f_kpconv_fused_x3's.) */
 size_t d3f_kpconv_packed_x3_bytes(int K, int N);
 int d3f_kpconv_pack_weights_x3(const float* W, int K, int N, void* W_planes, void* stream);
+/* The same operator with the AGGREGATION on the matrix cores as well (round 6): wf[q] = influences^T x gathered features is a
+ * [15 x K] x [K x 32] product per query -- v_mfma_f32_16x16x1_4b_f32, four queries per instruction, exact fp32 and in the reference's
+ * neighbour order -- while the vector pipe computes the influences of the next neighbours.  The shipped configuration only
+ * (num_kp = 15, linear influence, sum aggregation; fp32 features).  W_planes = d3f_kpconv_pack_weights_x3 of the [512, 32] matrix
+ * W'[16 s + p][n] = K_values[p][c(s)][n] (p < 15) / 0 (p = 15), c(s) = 0, 2, ..., 30, 1, 3, ..., 31: the channel-major k order the
+ * aggregation leaves on chip.
+ * Other arguments as d3f_kpconv_fused32. */
+int d3f_kpconv_fused32_mfma(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,
+                            const float* f, int ldf, const unsigned char* rowpos, const float* kp_host, int num_kp,
+                            float KP_extent, int influence, int aggregation, const void* W_planes, const float* col_scale,
+                            const float* col_shift, const float* residual, int ldr, int leaky, float alpha, float* out,
+                            int ldo, const int* Nq_dev, const int* Ns_dev, const int* q_order, void* stream);
 /* d3f_kpconv_fused32 (Cin = Cout = 32, the level-0 convolutions) with the split contraction; W_planes =
  * d3f_kpconv_pack_weights_x3(K_values [15*32, 32]).  Arguments as d3f_kpconv_fused32. */
 int d3f_kpconv_fused32_x3(const float* q, int Nq, const float* s, int Ns, const int* idx, int ld_idx, int K,

@@ -137,3 +137,45 @@ def test_split_contraction_generic_modes_against_the_oracle(device, coracle, cin
     assert np.abs(x3 - want).max() <= 1e-4 * scale, np.abs(x3 - want).max()
     assert np.abs(f32 - want).max() <= 1e-4 * scale
     assert np.abs(x3 - f32).max() <= 5e-6 * scale
+
+
+def test_aggregation_on_the_matrix_cores_equals_the_vector_form(device):
+    """d3f_kpconv_fused32_mfma (round 6): the per-query [15 x K] x [K x 32] aggregation as v_mfma_f32_16x16x1_4b_f32 rank-1 updates --
+    the same fp32 multiply-adds in the same neighbour order as the vector form's FMA chains, then the same split contraction over a
+    channel-major k order: results equal to fp32 rounding of the contraction's summation order, and within 5e-6 of float64.
+    Epilogue operands, shadow neighbours (a ragged last tile, all-shadow rows) and a capacity-mode call included."""
+    from d3feat_amd import ops
+    pts, nb, f, W, kp = _operands(32, device, 911, n_raw=30000)
+    n = pts.shape[0]
+    nb = nb.clone()
+    nb[5, :] = n                                   # an all-shadow row
+    nb[7, 3:] = n                                  # three neighbours only
+    rng = np.random.default_rng(2)
+    cs = torch.from_numpy((rng.random(32) + 0.5).astype(np.float32)).to(device)
+    ch = torch.from_numpy(rng.standard_normal(32).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.standard_normal((n, 32)).astype(np.float32)).to(device)
+    keep = ops.KP_MFMA
+    try:
+        for kw in (dict(), dict(col_scale=cs, col_shift=ch, residual=res, leaky=True)):
+            ops.KP_MFMA = True
+            a = ops.kpconv_fused32(pts, pts, nb, f, kp, W, 0.03, **kw)
+            ops.KP_MFMA = False
+            b = ops.kpconv_fused32(pts, pts, nb, f, kp, W, 0.03, **kw)
+            torch.cuda.synchronize()
+            scale = max(1.0, b.abs().max().item())
+            assert (a - b).abs().max().item() <= 2e-6 * scale, (a - b).abs().max().item()
+            assert torch.equal(a[5], b[5])
+        ops.KP_MFMA = True
+        a = ops.kpconv_fused32(pts, pts, nb, f, kp, W, 0.03)
+        ref = _kpconv64(pts, nb, f, torch.from_numpy(kp).to(device), W, 0.03)
+        assert (a.double() - ref).abs().max().item() <= 5e-6 * ref.abs().max().item()
+        # capacity mode: the device-resident row count is smaller than the grid; rows beyond it are not written
+        m = n - 1000
+        q2 = pts.clone()
+        q2.n_dev = torch.tensor([m], dtype=torch.int32, device=device)
+        q2.n_hint = m
+        a2 = ops.kpconv_fused32(q2, pts, nb, f, kp, W, 0.03)
+        torch.cuda.synchronize()
+        assert torch.equal(a2[:m], a[:m])
+    finally:
+        ops.KP_MFMA = keep
