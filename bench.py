@@ -177,6 +177,24 @@ def kpconv_flops(Nq, K, Cin, Cout):
     return 2.0 * Nq * 15 * Cin * Cout, 2.0 * Nq * 15 * K * Cin + 11.0 * Nq * K * 15
 
 
+def contraction_description():
+    """What the contractions of this run are, from the switches that route them (ops.GEMM_X3 / X3_N32 / KP_X3 / KP_MFMA)."""
+    from d3feat_amd import ops
+    split = ("EXACT operand splitting (each f32 operand = 3 bf16 planes, 6 exact bf16 products per f32 product, f32 accumulate on "
+             "v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16: csrc/gemm_x3.h; error vs float64 below the f32 MFMA kernel's, "
+             "tests/test_gpu_gemm_x3.py)")
+    parts = []
+    if ops.GEMM_X3:
+        parts.append("unary contractions%s by %s" % ("" if getattr(ops, "X3_N32", True) else " wider than 32 columns", split))
+    else:
+        parts.append("unary contractions f32 on v_mfma_f32_32x32x2_f32 (D3F_GEMM_X3=0)")
+    parts.append("the fused KPConv kernels (Cin 32 / 64 / 128) contract their LDS tile %s" %
+                 ("in the same operand-split form" if ops.KP_X3 else "on v_mfma_f32_16x16x4_f32 / 32x32x2_f32 (D3F_KP_X3=0)"))
+    if getattr(ops, "KP_MFMA", False):
+        parts.append("level-0 KPConv aggregation on v_mfma_f32_16x16x1_4b_f32 (D3F_KP_MFMA=1)")
+    return "f32 in / f32 out; " + "; ".join(parts)
+
+
 def source_hash():
     """sha256 over the kernel sources: ties a committed counter file (tools/pmc_summary.py stamps it) to the code it measured."""
     h = hashlib.sha256()
@@ -627,11 +645,7 @@ def main():
                        "points_per_cloud": npts, "neighborhood_limits": [int(x) for x in limits],
                        "fragments_per_gpu": args.steps * frames, "parallelism": "fragment-dp%d" % world,
                        "contraction": ("bf16 operands (configs[4])" if args.bf16 else
-                                       "f32 in / f32 out; unary + unfused KPConv contractions wider than 32 columns by EXACT operand "
-                                       "splitting (each f32 operand = 3 bf16 planes, 6 exact bf16 products per f32 product, f32 accumulate "
-                                       "on v_mfma_f32_32x32x16_bf16: csrc/gemm_x3.h; error vs float64 below the f32 MFMA kernel's, "
-                                       "tests/test_gpu_gemm_x3.py), the rest on v_mfma_f32_32x32x2_f32" if __import__("d3feat_amd.ops").ops.GEMM_X3
-                                       else "f32 on v_mfma_f32_32x32x2_f32 (D3F_GEMM_X3=0)"),
+                                       contraction_description()),
                        "rccl": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
                        "final_gather": {"ranks": len(gathered_rows), "to": "rank %d" % dst if dst is not None else "every rank",
                                         "received_on_rank0": received,

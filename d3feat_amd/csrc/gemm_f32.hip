@@ -21,8 +21,6 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
-#include <cstdio>
-#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -939,17 +937,20 @@ static GemmX3Plan gemm_x3_plan(int M, int N, int K, int M_hint) {
     if (M_hint > 0 && M_hint < M) M = M_hint;
     const int nt = K / GX_BK;
     GemmX3Plan p;
-    // measurement aid: D3F_X3_PLAN="tn,waves,S" forces the workgroup shape (1,4 / 2,4 / 4,8) and the K slice count of EVERY call
+#ifdef D3F_GEMM_TUNING      // measurement builds only (tools/ubench/build_variant.sh -DD3F_GEMM_TUNING): never in the shipped library
+    // D3F_X3_PLAN="tn,waves,S" forces the workgroup shape (1,4 / 2,4 / 4,8) and the K slice count of every call it is valid for
     static const char* forced = getenv("D3F_X3_PLAN");
     if (forced) {
         int tn = 0, wv = 0, S = 0;
-        if (sscanf(forced, "%d,%d,%d", &tn, &wv, &S) == 3 && ((tn == 1 && wv == 4) || (tn == 2 && wv == 4) || (tn == 4 && wv == 8)) && S >= 1) {
+        if (sscanf(forced, "%d,%d,%d", &tn, &wv, &S) == 3 && ((tn == 1 && wv == 4) || (tn == 2 && wv == 4) || (tn == 4 && wv == 8)) && S >= 1 &&
+            !(N <= 32 && tn != 1) && S * 4 <= (nt > 4 ? nt : 4)) {       // (the shapes the cost model itself may choose)
             p.tn = tn; p.waves = wv; p.S = S < nt ? S : nt;
             p.tps = d3f_cdiv(nt, p.S);
             p.S = d3f_cdiv(nt, p.tps);
             return p;
         }
     }
+#endif
     p.tn = N <= 32 ? 1 : 2;
     p.waves = 4;
     const long long c_small = gemm_x3_cost((long long)d3f_cdiv(M, 128) * d3f_cdiv(N, 32 * p.tn), 512, nt, 100, p.S);
@@ -1019,12 +1020,16 @@ extern "C" int d3f_gemm_x3(const float* A, int N1, int lda, int C1, const int* i
         const int m_eff = (M_hint > 0 && M_hint < M) ? M_hint : M;
         const size_t wbytes = (size_t)nkt * NG * GX_CHUNK * sizeof(unsigned short);
         if (on && (NG == 1 || NG == 2 || NG == 4) && wbytes + GXR_PATCH_BYTES + GXR_EPI_BYTES <= 160 * 1024 && m_eff >= 65536) {
-            static int cus = 0;
+            // CU count of the CURRENT device (cached per device ordinal: a process may drive several)
+            static std::atomic<int> cus_of[64];
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return D3F_ERR_HIP;
+            int cus = cus_of[dev & 63].load(std::memory_order_relaxed);
             if (!cus) {
-                int dev = 0;
                 hipDeviceProp_t pr;
-                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return D3F_ERR_HIP;
+                if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return D3F_ERR_HIP;
                 cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+                cus_of[dev & 63].store(cus, std::memory_order_relaxed);
             }
             static std::atomic<unsigned long long> lds_done{0};
             const void* const fns[3] = {(const void*)gemm_x3r_kernel<1>, (const void*)gemm_x3r_kernel<2>, (const void*)gemm_x3r_kernel<4>};
