@@ -9,59 +9,17 @@
 //
 // The shadow row can only win where a row has NO valid neighbour at all (a column minimum is <= every real entry), which
 // a pooled barycentre never is -- its own voxel's points lie inside the pooling radius.  So the full pass over x that the
-// column minima cost (the whole feature matrix of the finer level, read only for them) is made lazy: the pooling kernel
-// takes the maximum over the valid neighbours and raises a flag for a row without any; the column-minimum kernels and the
-// patch kernel run in every call (fixed launch sequence) but leave at once unless that flag is up.  Result: bit-identical
-// to the eager formulation in all cases.
-// col_min_dev: u32[C + 4]: [0, C) ordered-uint column minima (valid only when the flag was raised), [C] the flag.
+// column minima cost (the whole feature matrix of the finer level, read only for them) is made lazy and stays inside the
+// ONE pooling launch: a row's threads take the maximum over the valid neighbours, and the threads of a row without any
+// stream the column minima of their own channels (the row's threads cover one whole row of x per step, coalesced).
+// Result: bit-identical to the eager formulation in all cases; the rare path costs N1 row reads per such row.
+// (Rounds 1-5 kept the minima in a scratch vector behind a flag: three more launches per pooling layer that left at once.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) colmin_init_kernel(unsigned* __restrict__ cm, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) cm[c] = 0xFFFFFFFFu;
-    if (c == C) cm[C] = 0u;       // the flag
-}
-
-template <class FT>   // feature storage type (float / unsigned short = bf16, common.h D3fFeat)
-__global__ void __launch_bounds__(256) colmin_kernel(const FT* __restrict__ x, int N1, const int* __restrict__ N1_dev,
-                                                     int ldx, int C, unsigned* __restrict__ cm) {
-    if (cm[C] == 0u) return;      // no row needs the shadow row
-    N1 = d3f_dyn(N1, N1_dev);
-    // thread = channel (coalesced across a row); each block strides over rows
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    unsigned m = 0xFFFFFFFFu;
-    for (int r = blockIdx.y; r < N1; r += gridDim.y) m = min(m, d3f_f2ord(D3fFeat<FT>::ld1(&x[(size_t)r * ldx + c])));
-    atomicMin(&cm[c], m);
-}
-
-// rows without a valid neighbour (or K == 0) take the shadow row
-template <class FT>
-__global__ void __launch_bounds__(256) maxpool_patch_kernel(const unsigned* __restrict__ cm, int C, int N1,
-                                                            const int* __restrict__ idx, int N2, int ld_idx, int K,
-                                                            FT* __restrict__ out, int ldo, const int* __restrict__ N1_dev,
-                                                            const int* __restrict__ N2_dev) {
-    if (cm[C] == 0u) return;
-    N1 = d3f_dyn(N1, N1_dev);
-    N2 = d3f_dyn(N2, N2_dev);
-    // one wavefront per row, grid-stride
-    const int lane = threadIdx.x & 63;
-    const int nw = (gridDim.x * blockDim.x) >> 6;
-    for (int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; n < N2; n += nw) {
-        bool any = false;
-        for (int k = lane; k < K; k += 64) {
-            const int id = idx[(size_t)n * ld_idx + k];
-            any = any || (id >= 0 && id < N1);
-        }
-        if (__any(any)) continue;
-        for (int c = lane; c < C; c += 64) D3fFeat<FT>::st1(&out[(size_t)n * ldo + c], d3f_ord2f(cm[c]));
-    }
-}
-
 // U24: every row count / leading dimension fits the 24-bit addressing of common.h (d3f_fits_u24) -- the launcher decides
 template <int VEC, class FT = float, bool U24 = false>  // channels per thread (4: 16-byte loads; 1: generic)
 __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, int N1, int ldx, int C,
                                                       const int* __restrict__ idx, int N2, int ld_idx, int K,
-                                                      unsigned* __restrict__ flag, FT* __restrict__ out, int ldo,
+                                                      FT* __restrict__ out, int ldo,
                                                       const int* __restrict__ N1_dev, const int* __restrict__ N2_dev,
                                                       const int* __restrict__ row_order) {
     N1 = d3f_dyn(N1, N1_dev);
@@ -110,7 +68,32 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const FT* __restrict__ x, 
 #pragma unroll
             for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], val[j][v]);
     }
-    if (nvalid == 0 && c == 0) atomicOr(flag, 1u);   // this row is the shadow row: patched after the column minima exist
+    if (nvalid == 0) {   // this row is the shadow row: the column minima of x (ordered-uint minimum, as reduce_min keeps -0 < +0 apart)
+        unsigned om[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) om[v] = 0xFFFFFFFFu;
+        for (int r0 = 0; r0 < N1; r0 += 4) {
+            float val[4][VEC];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = min(r0 + j, N1 - 1);
+                const FT* xr = x + ((size_t)r * ldx + c);
+                if (VEC == 4) {
+                    const float4 f = D3fFeat<FT>::ld4(xr);
+                    val[j][0] = f.x; val[j][1 % VEC] = f.y; val[j][2 % VEC] = f.z; val[j][3 % VEC] = f.w;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) val[j][v] = D3fFeat<FT>::ld1(xr + v);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) om[v] = min(om[v], d3f_f2ord(val[j][v]));
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) m[v] = d3f_ord2f(om[v]);
+    }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) D3fFeat<FT>::st1(&out[(size_t)n * ldo + c + v], m[v]);   // (a maximum of bf16 values is a bf16 value)
 }
@@ -121,52 +104,33 @@ extern "C" int d3f_ind_max_pool(const void* x_, int N1, int ldx, int C, const in
     hipStream_t stream = (hipStream_t)stream_;
     const float* x = (const float*)x_;
     float* out = (float*)out_;
+    (void)col_min_dev;   // scratch of rounds 1-5 (kept in the signature; may be NULL)
     if (N1 < 0 || N2 < 0 || C < 1 || ldx < C || ldo < C || K < 0 || ld_idx < K) return D3F_ERR_ARG;
     if (N2 == 0) return D3F_OK;
-    if (!x || !idx || !out || !col_min_dev) return D3F_ERR_ARG;
-    unsigned* cm = (unsigned*)col_min_dev;
+    if (!x || !idx || !out) return D3F_ERR_ARG;
     const bool u24 = d3f_fits_u24(N1, ldx) && d3f_fits_u24(N2, ld_idx) && (long long)N2 * C < (1ll << 31);
-    colmin_init_kernel<<<d3f_cdiv(C + 1, 256), 256, 0, stream>>>(cm, C);
     if (feat_bf16) {
         if (C % 4 || ldx % 4 || ((uintptr_t)x_ & 7)) return D3F_ERR_ARG;
         const unsigned short* xh = (const unsigned short*)x_;
         unsigned short* oh = (unsigned short*)out_;
         if (u24)
             maxpool_kernel<4, unsigned short, true><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(
-                xh, N1, ldx, C, idx, N2, ld_idx, K, cm + C, oh, ldo, N1_dev, N2_dev, row_order);
+                xh, N1, ldx, C, idx, N2, ld_idx, K, oh, ldo, N1_dev, N2_dev, row_order);
         else
             maxpool_kernel<4, unsigned short><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(
-                xh, N1, ldx, C, idx, N2, ld_idx, K, cm + C, oh, ldo, N1_dev, N2_dev, row_order);
-        if (N1 > 0) {
-            int rows = d3f_cdiv(N1, 32);
-            if (rows > 256) rows = 256;
-            colmin_kernel<unsigned short><<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(xh, N1, N1_dev, ldx, C, cm);
-        }
-        int pbh = d3f_cdiv(N2, 4);
-        if (pbh > 256) pbh = 256;
-        maxpool_patch_kernel<unsigned short><<<pbh, 256, 0, stream>>>(cm, C, N1, idx, N2, ld_idx, K, oh, ldo, N1_dev, N2_dev);
+                xh, N1, ldx, C, idx, N2, ld_idx, K, oh, ldo, N1_dev, N2_dev, row_order);
         D3F_LAUNCH_CHECK();
         return D3F_OK;
     }
     if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && u24)
         maxpool_kernel<4, float, true><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
-                                                                                                   cm + C, out, ldo, N1_dev, N2_dev,
-                                                                                                   row_order);
+                                                                                                   out, ldo, N1_dev, N2_dev, row_order);
     else if (C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0)
         maxpool_kernel<4><<<d3f_cdiv((long long)N2 * (C / 4), 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
-                                                                                      cm + C, out, ldo, N1_dev, N2_dev,
-                                                                                      row_order);
+                                                                                      out, ldo, N1_dev, N2_dev, row_order);
     else
-        maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K, cm + C,
+        maxpool_kernel<1><<<d3f_cdiv((long long)N2 * C, 256), 256, 0, stream>>>(x, N1, ldx, C, idx, N2, ld_idx, K,
                                                                                out, ldo, N1_dev, N2_dev, row_order);
-    if (N1 > 0) {
-        int rows = d3f_cdiv(N1, 32);
-        if (rows > 256) rows = 256;
-        colmin_kernel<float><<<dim3(d3f_cdiv(C, 256), rows), 256, 0, stream>>>(x, N1, N1_dev, ldx, C, cm);
-    }
-    int pb = d3f_cdiv(N2, 4);
-    if (pb > 256) pb = 256;
-    maxpool_patch_kernel<float><<<pb, 256, 0, stream>>>(cm, C, N1, idx, N2, ld_idx, K, out, ldo, N1_dev, N2_dev);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
 }

@@ -1049,10 +1049,9 @@ def ind_max_pool(x, inds):
     inds, ldi = _rows(_req(inds, torch.int32, "inds"), "inds")
     dev = x.device
     out = torch.empty((inds.shape[0], x.shape[1]), dtype=x.dtype, device=dev)
-    colmin = torch.empty((x.shape[1] + 4,), dtype=torch.float32, device=dev)    # column minima (lazy) + flag word
     with _timed("ind_max_pool", dict(N1=x.shape[0], N2=inds.shape[0], K=inds.shape[1], C=x.shape[1]), dev):
         rc = lib.d3f_ind_max_pool(x.data_ptr(), x.shape[0], ldx, x.shape[1], inds.data_ptr(), inds.shape[0], ldi,
-                                  inds.shape[1], out.data_ptr(), x.shape[1], colmin.data_ptr(), _nd(x), _nd(inds), _order(inds),
+                                  inds.shape[1], out.data_ptr(), x.shape[1], None, _nd(x), _nd(inds), _order(inds),
                                   _h(x), _stream(dev))
     _lib.check(rc, "ind_max_pool")
     return _tag(out, inds)

@@ -330,8 +330,8 @@ int d3f_gemm_upsample_cat_f32(const float* x, int N1, int ldx, int C1, const int
  *   d3f_ind_max_pool      models/network_blocks.py:51-66  out[n,c] = max_k x'[idx[n,k],c], x' = x + row of column minima
  *   d3f_closest_pool_cat  models/network_blocks.py:69-83 + models/D3Feat.py:63
  *                         out[n, 0:C1] = x'[idx[n,0]] (x' = x + zero row), out[n, C1:C1+C2] = skip[n]  (skip may be NULL, C2 0)
- *   col_min_dev: 4-byte words [C + 4], scratch of d3f_ind_max_pool (column minima, computed only when a row has no valid
- *   neighbour and therefore takes the shadow row, and the flag saying so).
+ *   col_min_dev: unused since round 6 (may be NULL): the column minima are taken inside the one pooling launch, by the
+ *   threads of a row that has no valid neighbour and therefore takes the shadow row.
  * ------------------------------------------------------------------------------------------- */
 int d3f_ind_max_pool(const void* x, int N1, int ldx, int C, const int* idx, int N2, int ld_idx, int K,
                      void* out, int ldo, float* col_min_dev, const int* N1_dev, const int* N2_dev, const int* row_order,
