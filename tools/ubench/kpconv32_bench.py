@@ -1,5 +1,5 @@
-"""kpconv_fused32: the aggregation on the matrix cores (D3F_KP_MFMA) against the vector form, level-0 shapes of F stacked fragments,
-HIP-graph timed (10 launches per replay)."""
+"""kpconv_fused32 A/B on level-0 shapes of F stacked fragments, HIP-graph timed (10 launches per replay): feature rows one chunk
+ahead (D3F_KP_AHEAD) against the round-5 loop; KP_MFMA_AB=1 adds the matrix-core aggregation (D3F_KP_MFMA) against the vector form."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from d3feat_amd import ops, tf_custom_ops as tfo
@@ -29,14 +29,19 @@ def timed(fn, iters=10):
         s.record(); gr.replay(); e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-for dbg in [x for x in os.environ.get("DBGS", "").split(",") if x]:
-    os.environ["D3F_KPM_DBG"] = dbg
-    ops.KP_MFMA = True
-    t = timed(lambda: ops.kpconv_fused32(P, P, nb, f, KP, W, 0.03, leaky=True))
-    print("dbg %s: %.1f us" % (dbg, t))
-os.environ.pop("D3F_KPM_DBG", None)
+ref = None
 for rep in range(2):
+    for ahead in ("0", "1"):
+        os.environ["D3F_KP_AHEAD"] = ahead
+        ops.KP_MFMA = False
+        out = ops.kpconv_fused32(P, P, nb, f, KP, W, 0.03, leaky=True)
+        if ref is None:
+            ref = out.clone()
+        same = bool(torch.equal(out, ref))
+        t = timed(lambda: ops.kpconv_fused32(P, P, nb, f, KP, W, 0.03, leaky=True))
+        print("F=%d rows %d: kpconv_fused32 rows-ahead %s: %.1f us (row_positive included), bit-equal to the first form: %s" % (F, P.shape[0], ahead, t, same))
+if os.environ.get("KP_MFMA_AB"):
     for flag in (True, False):
         ops.KP_MFMA = flag
         t = timed(lambda: ops.kpconv_fused32(P, P, nb, f, KP, W, 0.03, leaky=True))
-        print("F=%d rows %d: kpconv_fused32 %s: %.1f us (row_positive included)" % (F, P.shape[0], "matrix-core aggregation" if flag else "vector aggregation     ", t))
+        print("F=%d rows %d: kpconv_fused32 %s: %.1f us" % (F, P.shape[0], "matrix-core aggregation" if flag else "vector aggregation     ", t))
