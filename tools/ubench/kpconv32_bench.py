@@ -1,5 +1,6 @@
 """kpconv_fused32 A/B on level-0 shapes of F stacked fragments, HIP-graph timed (10 launches per replay): feature rows one chunk
-ahead (D3F_KP_AHEAD) against the round-5 loop; KP_MFMA_AB=1 adds the matrix-core aggregation (D3F_KP_MFMA) against the vector form."""
+ahead (D3F_KP_AHEAD; experiment k7 -- the kernel variant was measured and reverted, the shipped library ignores the switch, so
+the two lines time the same kernel) against the round-5 loop; KP_MFMA_AB=1 adds the matrix-core aggregation (D3F_KP_MFMA) against the vector form."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from d3feat_amd import ops, tf_custom_ops as tfo
