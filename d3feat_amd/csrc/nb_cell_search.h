@@ -137,8 +137,8 @@ __device__ __forceinline__ void nbc_group_sort64(unsigned (&k)[8]) {
 }
 #undef NBC_CE
 
-template <bool SORTED_Q>
-__global__ void __launch_bounds__(256)
+template <bool SORTED_Q, bool INTERNAL = false>   // INTERNAL: `inv` given (compile-time: the two numberings do not share registers)
+__global__ void __launch_bounds__(256, 5)   // five workgroups per CU (96 registers; the INTERNAL instance would take 99 = four)
 nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
                       const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                       const float4* __restrict__ sorted, float r2, int pad, const int* __restrict__ ns_dev,
@@ -208,7 +208,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
 
     // internal numbering: the hit records hold POSITIONS in the cell-sorted array; the original index (the reference's tie-break,
     // read in the rare exact paths only when two d2 are bit-equal) is one gather away
-#define NBC_ORIG(Y_) (inv ? __float_as_int(sorted[Y_].w) : (Y_))
+#define NBC_ORIG(Y_) (INTERNAL ? __float_as_int(sorted[Y_].w) : (Y_))
     float4 cand[NBC_SLOTS];
     int cb = -1, ccx = 0, ccy = 0, ccz = 0;     // the stencil in registers: batch element and cell (wave-uniform)
     int T = 0;                                   // candidates of the stencil
@@ -232,9 +232,14 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
                 o = (v >= pre4) ? off4 : o; o = (v >= pre5) ? off5 : o; o = (v >= pre6) ? off6 : o;            \
                 o = (v >= pre7) ? off7 : o; o = (v >= pre8) ? off8 : o;                                        \
                 if (v < T) {                                                                                   \
-                    cand[u] = sorted[v + o];                                                                   \
-                    /* internal numbering: the record's POSITION is what the rows hold (its index only breaks ties) */ \
-                    if (inv) cand[u].w = __int_as_float(v + o);                                                \
+                    /* internal numbering: the record's POSITION is what the rows hold (its index only breaks ties): 12 bytes */ \
+                    /* are loaded and the fourth register is written at once -- overwriting .w of a 16-byte load would keep  */ \
+                    /* the position in one more register per slot until the load returns (99 registers = four waves)        */ \
+                    if (INTERNAL) {                                                                            \
+                        const float* sp_ = (const float*)&sorted[v + o];                                       \
+                        cand[u].x = sp_[0]; cand[u].y = sp_[1]; cand[u].z = sp_[2];                            \
+                        cand[u].w = __int_as_float(v + o);                                                     \
+                    } else cand[u] = sorted[v + o];                                                            \
                 }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
@@ -310,7 +315,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         } else {
             // ---- dense neighbourhood (rare): ordered now, by the whole wavefront, from the hit array ----------------------
             const int m = min(n, cap);
-            int* row = out + (size_t)(inv ? p0 + i : nbc_rl(vqi, i)) * ld;
+            int* row = out + (size_t)(INTERNAL ? p0 + i : nbc_rl(vqi, i)) * ld;
             bool need_exact = true;
             if (n <= 128 && n <= cap && width < 64) {
                 // 128 keys, two per lane (upper 25 bits of d2 | slot); the row is the head of elements 0..63
@@ -328,9 +333,21 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
                     const int ei = e0 + lane;
                     const uint2 mine = hk[ei < m ? ei : 0];
                     int rank = 0;
-                    for (int j = 0; j < m; ++j) {
-                        const uint2 o = hk[j];
-                        rank += (o.x < mine.x || (o.x == mine.x && NBC_ORIG((int)o.y) < NBC_ORIG((int)mine.y))) ? 1 : 0;
+                    if (INTERNAL) {
+                        // (bit-equal d2 only: the gather of the original indices stays out of the common iteration and out of the
+                        // register budget of the kernel)
+#pragma unroll 1
+                        for (int j = 0; j < m; ++j) {
+                            const uint2 o = hk[j];
+                            bool before = o.x < mine.x;
+                            if (o.x == mine.x && o.y != mine.y) before = NBC_ORIG((int)o.y) < NBC_ORIG((int)mine.y);
+                            rank += before ? 1 : 0;
+                        }
+                    } else {
+                        for (int j = 0; j < m; ++j) {
+                            const uint2 o = hk[j];
+                            rank += (o.x < mine.x || (o.x == mine.x && (int)o.y < (int)mine.y)) ? 1 : 0;
+                        }
                     }
                     if (ei < m && rank < width) row[rank] = (int)mine.y;
                 }
@@ -346,7 +363,7 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
         const int i0 = i & ~(NBC_BATCH - 1);         // first query of the batch
         const int qd = lane >> 3, part = lane & 7;
         const int nqd = __shfl(vn, i0 + qd);                                // hits of this lane's query (-1: nothing to do)
-        const int qiq = inv ? p0 + i0 + qd : __shfl(vqi, i0 + qd);          // its row
+        const int qiq = INTERNAL ? p0 + i0 + qd : __shfl(vqi, i0 + qd);          // its row
         unsigned k[8];
         {
             const uint4* src = (const uint4*)(ld2 + qd * 64 + part * 8);
@@ -388,14 +405,16 @@ nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict
             const int g = (int)(__builtin_ctzll(todo) >> 3);
             todo &= ~(0xFFull << (8 * g));
             const int m = nbc_rl(vn, i0 + g);
-            int* row = out + (size_t)(inv ? p0 + i0 + g : nbc_rl(vqi, i0 + g)) * ld;
+            int* row = out + (size_t)(INTERNAL ? p0 + i0 + g : nbc_rl(vqi, i0 + g)) * ld;
             const unsigned md = ld2[g * 64 + (lane < m ? lane : 0)];
             const int mi = lidx[g * 64 + (lane < m ? lane : 0)];
             int rank = 0;
+            // ties by the ORIGINAL index: lane j holds element j's (one gather per lane in the internal numbering, then lane reads)
+            const int mo = NBC_ORIG(mi);
             for (int j = 0; j < m; ++j) {
                 const unsigned od = ld2[g * 64 + j];
-                const int oi = lidx[g * 64 + j];
-                rank += (od < md || (od == md && NBC_ORIG(oi) < NBC_ORIG(mi))) ? 1 : 0;
+                const int oo = INTERNAL ? __builtin_amdgcn_readlane(mo, j) : lidx[g * 64 + j];
+                rank += (od < md || (od == md && oo < mo)) ? 1 : 0;
             }
             if (lane < m && rank < width) row[rank] = mi;
             for (int j = m + lane; j < width; j += 64) row[j] = pad;

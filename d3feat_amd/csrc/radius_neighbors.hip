@@ -615,8 +615,12 @@ static int nb_search_dispatch(const NbGrid& g, const float* queries, int Nq, con
             unsigned long long* prof = prof_env ? (unsigned long long*)strtoull(prof_env, nullptr, 16) : nullptr;
             const int blocks = d3f_cdiv(d3f_cdiv(Nq, Q), 4);
             const size_t lds = (size_t)4 * ((size_t)cap * 8 + NBC_BATCH * 64 * 8);
-            nb_cell_search_kernel<true><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
-                                                                      pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof, inv);
+            if (inv)
+                nb_cell_search_kernel<true, true><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
+                                                                                pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof, inv);
+            else
+                nb_cell_search_kernel<true, false><<<blocks, 256, lds, stream>>>(queries, Nq, q_lens_dev, B, g.el, g.cell_start, g.stmp, g.sorted, r2,
+                                                                                 pad_value, g.soffs + B, out, ld, width, cap, status_dev, want_kmax, Q, dbg, prof, inv);
             D3F_LAUNCH_CHECK();
             return D3F_OK;
         }

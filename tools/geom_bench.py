@@ -53,9 +53,11 @@ def main():
     ap.add_argument("--q", type=str, default="", help="comma list of D3F_NBC_Q values to try on the full searches")
     ap.add_argument("--only", type=str, default="", help="substring filter on the op names (e.g. 'L0 conv')")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--internal", action="store_true", help="conv searches in the engine's form: query_grid = the grid, internal numbering")
+    ap.add_argument("--limits", type=str, default="", help="comma list of the five matrix widths (default 37,35,36,38,38; bench.py's: 42,42,46,51,49)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    limits = [37, 35, 36, 38, 38]
+    limits = [int(x) for x in args.limits.split(",")] if args.limits else [37, 35, 36, 38, 38]
     subs = [tfo.grid_subsampling(torch.from_numpy(room_fragment(s, n_raw=300000, edge=1.68)).to(dev), 0.03) for s in range(args.frags)]
     pts = torch.cat([x for s in subs for x in (s, s)], 0)
     lens = [int(s.shape[0]) for s in subs for _ in (0, 1)]
@@ -74,7 +76,8 @@ def main():
         st = torch.zeros((2,), dtype=torch.int32, device=dev)
         o1 = torch.empty((p.shape[0], limits[l]), dtype=torch.int32, device=dev)
         rows.append(("L%d conv search  %7d" % (l, p.shape[0]),
-                     lambda grid=grid, p=p, pl=pl, l=l, o1=o1, st=st: grid.search(p, pl, limits[l], cap=192, out=o1, status=st, reset_status=False, want_kmax=False)))
+                     lambda grid=grid, p=p, pl=pl, l=l, o1=o1, st=st: grid.search(p, pl, limits[l], cap=192, out=o1, status=st, reset_status=False, want_kmax=False,
+                                                                                  **(dict(query_grid=grid, internal=True) if args.internal else {}))))
         if l + 1 < len(levels):
             q, ql = levels[l + 1]
             o2 = torch.empty((q.shape[0], limits[l]), dtype=torch.int32, device=dev)
