@@ -1019,11 +1019,12 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                                     fp32_mfma_peak=MFMA_F32_PEAK_TF, achieved_over_fp32_mfma_peak=round(tf_s / MFMA_F32_PEAK_TF, 4),
                                     measured_limit="operand traffic L2 -> CU (~9 TB/s) and launch size: DESIGN.md section 5")
         # matrix-pipe utilisation from the SQ counters (one `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE` pass of this
-        # same command at --batch 4, tools/gpu_visit.sh mfma -> tools/pmc_mfma.py): busy cycles of the matrix pipes / (1024 SIMDs x
+        # same command at the headline's --batch 12 on one slot, the launches of the timed region only, tools/gpu_visit.sh mfma ->
+        # tools/pmc_mfma.py; rounds up to r06_v22 averaged over the warm-up and F = 1 latency replays too): busy cycles of the matrix pipes / (1024 SIMDs x
         # the launch's cycles), time-weighted over the kernel's template instances.  It is a count of issued MFMAs (32 busy cycles
         # per v_mfma_f32_32x32x16_bf16, 16 per 16x16x32), so it must equal issued flops / (1024 flops per cycle and SIMD): the
         # `issued_frac_clock_free` column of the counter file is that figure from SQ_INSTS_VALU_MFMA_MOPS_BF16 of the same pass.
-        # Against this line's own issued_tflops / 2516.6 it differs by (a) the fragments per launch (counter pass: 4), (b) the
+        # Against this line's own issued_tflops / 2516.6 it differs by (a) the fragments per launch when the pass ran another batch, (b) the
         # clock (2516.6 assumes 2.4 GHz; the chip runs 2.0-2.5 under this load) and (c) the counter pass serialising the streams.
         if mfma is not None:
             fm = (mfma.get("__families__") or {}).get(name.split("<")[0].split(" ")[0])
@@ -1031,6 +1032,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                 r["mfma_busy"] = fm["mfma_busy"]
                 r["mfma_busy_issued_frac_of_the_same_pass"] = fm.get("issued_frac_clock_free")
                 r["mfma_busy_fragments_per_launch"] = int(mfma.get("__fragments_per_launch__", 4))
+                r["mfma_busy_timed_region_only"] = bool(mfma.get("__timed_region_only__", False))
                 r["mfma_busy_source"] = mfma_src
                 r["mfma_busy_stale"] = mfma_stale
         r["alg_flops_per_launch"] = int(d["flops"] / d["launches"])
@@ -1069,6 +1071,7 @@ def instrumented_pass(cfg, step, raws, Fp, npass, device):
                 f_pmc = int(traffic.get("__fragments_per_launch__", Fp) or Fp)
                 r["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e["launches"] for e in ent) / nl * Fp / f_pmc)
                 r["traffic_fragments_per_launch_of_counter_run"] = f_pmc
+                r["traffic_timed_region_only"] = bool(traffic.get("__timed_region_only__", False))
                 r["traffic_source"] = traffic_src
                 r["traffic_stale"] = traffic_stale
         return r

@@ -64,17 +64,20 @@ prof1)   # ONE replay in flight: kernel durations without the other streams' ker
   rm -rf $OUT/prof1/*/*.db-journal; find $OUT -name "*.db" -size +20M -delete;;
 pmc)
   cd /tmp
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN > /dev/null 2> $OUT/pmc_fetch.err
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN > /dev/null 2> $OUT/pmc_write.err
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN --no-latency > /dev/null 2> $OUT/pmc_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN --no-latency > /dev/null 2> $OUT/pmc_write.err
   cd $REPO
   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json 2> $OUT/pmc_summary.err
   head -c 600 $OUT/hbm_traffic.json
   find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" -size +2M -delete;;
-mfma)   # matrix-pipe counters of the MFMA kernels (ONE --pmc pass with --kernel-trace only; tools/pmc_mfma.py)
+mfma)   # matrix-pipe counters of the MFMA kernels (ONE --pmc pass with --kernel-trace only; tools/pmc_mfma.py), at the headline's
+        # F = 12 fragments per replay by default so that the family figures are comparable with the line's issued_tflops / 2516.6
+        # (MFMA_BATCH=4: the F = 4 shapes of the one-replay tables)
   cd /tmp
-  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python $REPO/bench.py --steps 16 --warmup 1 --batch 4 $LEAN > /dev/null 2> $OUT/pmc_mfma.err
+  MB=${MFMA_BATCH:-12}
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python $REPO/bench.py --steps $((MB * 2)) --warmup 1 --batch $MB --slots 1 $LEAN --no-latency > /dev/null 2> $OUT/pmc_mfma.err
   cd $REPO
-  python tools/pmc_mfma.py $OUT/pmc_mfma > $OUT/mfma_counters.json 2> $OUT/pmc_mfma_summary.err
+  D3F_PMC_FRAGMENTS_PER_LAUNCH=$MB python tools/pmc_mfma.py $OUT/pmc_mfma > $OUT/mfma_counters.json 2> $OUT/pmc_mfma_summary.err
   head -c 1500 $OUT/mfma_counters.json; tail -3 $OUT/pmc_mfma.err
   find $OUT/pmc_mfma -name "*.csv" -size +2M -delete;;
 sq:*)   # SQ / cache counters of selected kernels on the graph engine's F = 4 shapes:  sq:<kernel-regex>

@@ -39,10 +39,20 @@ def main(argv):
         else:
             dirs.append(a)
     acc, dur = {}, {}
+    region = [0, 0]
     for d in dirs:
         for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(fn, newline="") as f:
-                for row in csv.DictReader(f):
+                rows = list(csv.DictReader(f))
+            # only the launches of bench.py's timed region (see tools/pmc_summary.py)
+            marks = [int(r["Dispatch_Id"]) for r in rows if "d3f_trace_marker_kernel" in (r.get("Kernel_Name") or "")]
+            lo, hi = (min(marks), max(marks)) if len(set(marks)) >= 2 else (None, None)
+            region[0] += 1
+            region[1] += 1 if lo is not None else 0
+            if True:
+                for row in rows:
+                    if lo is not None and not (lo < int(row["Dispatch_Id"]) < hi):
+                        continue
                     k = short(row.get("Kernel_Name") or "")
                     c = row.get("Counter_Name")
                     v = float(row.get("Counter_Value") or 0.0)
@@ -109,6 +119,7 @@ def main(argv):
         h.update(os.path.basename(fn).encode())
         h.update(open(fn, "rb").read())
     out["__source_hash__"] = h.hexdigest()[:16]
+    out["__timed_region_only__"] = region[0] > 0 and region[1] == region[0]
     out["__fragments_per_launch__"] = int(os.environ.get("D3F_PMC_FRAGMENTS_PER_LAUNCH", "4"))
     json.dump(out, sys.stdout, indent=1)
     print()

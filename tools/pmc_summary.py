@@ -22,11 +22,21 @@ def short(name):
 
 def main(dirs):
     acc = {}
+    region = {"files": 0, "with_markers": 0}
     for d in dirs:
         for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(fn, newline="") as f:
-                rd = csv.DictReader(f)
-                for row in rd:
+                rows = list(csv.DictReader(f))
+            # only the launches of bench.py's timed region (between its first and last d3f_trace_marker_kernel): warm-up captures,
+            # the parity pass and the F = 1 latency replays that follow would otherwise dilute the per-launch means
+            marks = [int(r["Dispatch_Id"]) for r in rows if "d3f_trace_marker_kernel" in (r.get("Kernel_Name") or "")]
+            lo, hi = (min(marks), max(marks)) if len(set(marks)) >= 2 else (None, None)
+            region["files"] += 1
+            region["with_markers"] += 1 if lo is not None else 0
+            if True:
+                for row in rows:
+                    if lo is not None and not (lo < int(row["Dispatch_Id"]) < hi):
+                        continue
                     k = short(row.get("Kernel_Name") or row.get("kernel_name") or "")
                     c = row.get("Counter_Name") or row.get("counter_name")
                     v = float(row.get("Counter_Value") or row.get("counter_value") or 0.0)
@@ -54,6 +64,7 @@ def main(dirs):
     out["__source_hash__"] = h.hexdigest()[:16]
     # fragments per replay of the counter run (tools/gpu_visit.sh pmc: --batch 4): per-launch traffic scales with it, bench.py
     # rescales to the fragments per launch of its own instrumented pass
+    out["__timed_region_only__"] = region["files"] > 0 and region["with_markers"] == region["files"]
     out["__fragments_per_launch__"] = int(os.environ.get("D3F_PMC_FRAGMENTS_PER_LAUNCH", "4"))
     json.dump(out, sys.stdout, indent=1)
     print()
