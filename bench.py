@@ -813,17 +813,22 @@ def marginal_costs(args, cfg, W, limits, engine, run, shard, device, nsteps, flo
     from d3feat_amd.engine import FragmentEngine
 
     def timed(eng):
+        # the faster of three windows: one disturbed window (r06_v28: 0.43 instead of 0.34 ms for the ablated engine) would otherwise
+        # halve a family's marginal cost
         run(args.warmup, eng)
-        torch.cuda.synchronize(device)
-        t = time.perf_counter()
-        run(nsteps, eng, collect=shard)                  # same bookkeeping as the headline region
-        torch.cuda.synchronize(device)
-        ms = (time.perf_counter() - t) / nsteps * 1e3
-        shard.reset()
-        return ms
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize(device)
+            t = time.perf_counter()
+            run(nsteps, eng, collect=shard)                  # same bookkeeping as the headline region
+            torch.cuda.synchronize(device)
+            ms = (time.perf_counter() - t) / nsteps * 1e3
+            shard.reset()
+            best = ms if best is None else min(best, ms)
+        return best
     base_ms = timed(engine)
     out = {"method": "throughput of a second engine whose replays leave one op family's library calls out, same fragments, "
-                     "same F x slots; ms_per_fragment = base - ablated", "steps": nsteps, "base_ms_per_fragment": round(base_ms, 4)}
+                     "same F x slots, the fastest of three windows each; ms_per_fragment = base - ablated", "steps": nsteps, "base_ms_per_fragment": round(base_ms, 4)}
     real_load = _lib.load
     try:
         for fam in ("gemm", "kpconv"):
