@@ -440,18 +440,20 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
     const float fc = (float)max(cnt, 1);        // (cnt is already the half-wave's total: counted by ballot)
     float ymax = fmaxf(fmaxf(yv.x, yv.y), fmaxf(yv.z, yv.w));
     ymax = fmaxf(ymax, __shfl_xor(ymax, 1, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, 2, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, 4, 64));
-    const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, ss[4] = {sum.x, sum.y, sum.z, sum.w};
-    float best = -3.402823466e38f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float d = yy[j] - ss[j] / fc;
-        float sp;   // softplus as TF computes it: log1p(exp(d)) with the large/small-argument shortcuts
-        if (d > 15.f) sp = d;
-        else if (d < -15.f) sp = expf(d);
-        else sp = log1pf(expf(d));
-        best = fmaxf(best, sp * (yy[j] / (1e-6f + ymax)));
-    }
+    // The four row slots of a point hold the SAME four channel sums now: slot s evaluates channel 4*cl + s only (round 6).  The softplus
+    // / divide chain is ~130 vector instructions per channel; evaluated for all four channels by all four slots it was 3/4 of the kernel's
+    // vector work, and the kernel is issue-bound (104 M vector instructions per launch at F = 4 = 170 of its 182 us).  Same operations per
+    // element, the maximum over a point's 32 channels is order-free: bit-identical scores.
+    const float yj = slot == 0 ? yv.x : slot == 1 ? yv.y : slot == 2 ? yv.z : yv.w;
+    const float sj = slot == 0 ? sum.x : slot == 1 ? sum.y : slot == 2 ? sum.z : sum.w;
+    const float d = yj - sj / fc;
+    float sp;   // softplus as TF computes it: log1p(exp(d)) with the large/small-argument shortcuts
+    if (d > 15.f) sp = d;
+    else if (d < -15.f) sp = expf(d);
+    else sp = log1pf(expf(d));
+    float best = sp * (yj / (1e-6f + ymax));
     best = fmaxf(best, __shfl_xor(best, 1, 64)); best = fmaxf(best, __shfl_xor(best, 2, 64)); best = fmaxf(best, __shfl_xor(best, 4, 64));
+    best = fmaxf(best, __shfl_xor(best, 8, 64)); best = fmaxf(best, __shfl_xor(best, 16, 64));
     if (active && slot == 0) {
         const float inv = rsqrtf(fmaxf(sq, 1e-10f));
         *(float4*)&desc[(size_t)n * ldd + c4] = make_float4(xv.x * inv, xv.y * inv, xv.z * inv, xv.w * inv);
