@@ -398,38 +398,56 @@ head32_kernel(const float* __restrict__ x, int N, int ldx, const int* __restrict
     const __amdgpu_buffer_rsrc_t xbuf = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)N * (unsigned)ldx * 4u), 0x00020000);
     for (int k0 = 0; k0 < K; k0 += 32) {
         int mine = (k0 + l < K) ? idx[(size_t)n * ld_idx + k0 + l] : -1;   // 32 indices per half-wave load
-        if (mine < 0 || mine >= N) mine = -1;                                // shadow row: zeros, never counted
+        const bool valid = mine >= 0 && mine < N;                            // shadow row (or beyond K): zeros, never counted
         // neighbour count: the row flags of these 32 neighbours, one byte load per lane, one ballot per chunk
-        const bool counts = mine >= 0 && nz[mine] != 0;
+        const bool counts = valid && nz[valid ? mine : 0] != 0;
         cnt += __popcll((__ballot(counts) >> hbase) & 0xFFFFFFFFull);
         const int kn = min(32, K - k0);
-        for (int kk = 0; kk < kn; kk += 16) {      // four loads (16 neighbour rows) in flight per lane, clamped addresses
-            int id[4];
-            float4 v[4];
+        if (U24) {
+            // buffer loads (24-bit row addressing: common.h).  A shadow slot names row N -- one past the buffer: the hardware's range
+            // check returns exact zeros for it (never row 0's values times a zero factor: 0 * Inf = NaN), with no test per row; and
+            // 0 * rden adds nothing, so the rows are accumulated without a select either (round 6: the kernel is vector-issue bound,
+            // the loop went from 54 to ~30 vector instructions per 16 rows).  Slots beyond K hold row N already.
+            mine = valid ? mine : N;
+            for (int kk = 0; kk < kn; kk += 16) {      // four loads (16 neighbour rows) in flight per lane
+                float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kq = kk + u * 4 + slot;
-                id[u] = __shfl(mine, hbase + min(kq, 31), 64);
-                if (kq >= kn) id[u] = -1;
-                if (U24) {
-                    // buffer load (24-bit row addressing: common.h): a shadow slot supplies an offset beyond the buffer and the
-                    // hardware's range check returns exact zeros -- never row 0's values times a zero factor (0 * Inf = NaN)
-                    const unsigned off = id[u] >= 0 ? (__umul24((unsigned)id[u], (unsigned)ldx) + (unsigned)c4) * 4u : 0xfffffff0u;
+                for (int u = 0; u < 4; ++u) {
+                    const int idu = __shfl(mine, hbase + kk + u * 4 + slot, 64);
+                    const unsigned off = (__umul24((unsigned)idu, (unsigned)ldx) + (unsigned)c4) * 4u;
                     typedef unsigned hd_u4 __attribute__((ext_vector_type(4)));
                     const hd_u4 w = __builtin_amdgcn_raw_buffer_load_b128(xbuf, (int)off, 0, 0);
                     v[u] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-                } else {
+                }
+                const hd_f2 r2 = {rden, rden};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // neighbours of a point belong to the point's own cloud (the searches are per batch element): same den
+                    const hd_f2 v01 = {v[u].x, v[u].y}, v23 = {v[u].z, v[u].w};
+                    sum01 = sum01 + v01 * r2;
+                    sum23 = sum23 + v23 * r2;
+                }
+            }
+        } else {
+            if (!valid) mine = -1;
+            for (int kk = 0; kk < kn; kk += 16) {
+                int id[4];
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kq = kk + u * 4 + slot;
+                    id[u] = __shfl(mine, hbase + min(kq, 31), 64);
+                    if (kq >= kn) id[u] = -1;
                     const float4 t = *(const float4*)(x + ((size_t)max(id[u], 0) * ldx + c4));
                     v[u] = id[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : t;
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                // neighbours of a point belong to the point's own cloud (the searches are per batch element): same den
-                const float r = id[u] < 0 ? 0.f : rden;
-                const hd_f2 r2 = {r, r}, v01 = {v[u].x, v[u].y}, v23 = {v[u].z, v[u].w};
-                sum01 = sum01 + v01 * r2;
-                sum23 = sum23 + v23 * r2;
+                for (int u = 0; u < 4; ++u) {
+                    const float r = id[u] < 0 ? 0.f : rden;
+                    const hd_f2 r2 = {r, r}, v01 = {v[u].x, v[u].y}, v23 = {v[u].z, v[u].w};
+                    sum01 = sum01 + v01 * r2;
+                    sum23 = sum23 + v23 * r2;
+                }
             }
         }
     }
@@ -486,7 +504,7 @@ extern "C" int d3f_detect_head(const float* x, int N, int ldx, int C, const int*
         // one flag byte per row, behind the 2 B + 2 scratch words
         unsigned char* nz = (unsigned char*)(scratch_dev + 2 * B + 2);
         head32_rowflag_kernel<<<d3f_cdiv(N, 256), 256, 0, stream>>>(x, N, ldx, offs, B, mx, nz);
-        if (d3f_fits_u24(N, ldx) && (long long)N * ldx < (1ll << 30))
+        if (d3f_fits_u24(N + 1, ldx) && ((long long)N + 1) * ldx < (1ll << 30))      // (row N, one past the end, is the shadow's address)
             head32_kernel<true><<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
         else
             head32_kernel<false><<<blocks, 256, 0, stream>>>(x, N, ldx, idx, ld_idx, K, offs, B, mx, nz, desc, ldd, score, row_order);
