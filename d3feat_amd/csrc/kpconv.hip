@@ -496,23 +496,42 @@ kpconv_c1_kp_kernel(const float* __restrict__ q, int Nq, const float* __restrict
         // (round 5) the walk below has no branches: a slot that holds no neighbour carries f = 0 (its influence, computed from
         // support 0's position, is finite in every mode and multiplies nothing), and the positive neighbours are counted HERE, by
         // one ballot per loaded group, instead of by a sixteenth lane that took its own path through every iteration
+        // records of TWO neighbours, interleaved {xa xb | ya yb | za zb | fa fb} (round 6): the walk evaluates a pair per step with
+        // packed fp32 instructions (v_pk_add / v_pk_mul: the same IEEE result per element, half the issue slots -- the kernel is
+        // vector-issue bound, tools/pmc_issue.sh: 0.87); the accumulation stays one fma per neighbour in neighbour order
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mynb[p + 16 * j] = make_float4(px[j] - qx, py[j] - qy, pz[j] - qz, fv[j]);
+            float* d = (float*)mynb + ((p + 16 * j) >> 1) * 8 + (p & 1);
+            d[0] = px[j] - qx; d[2] = py[j] - qy; d[4] = pz[j] - qz; d[6] = fv[j];
             cnt += (float)__popcll((__ballot(ok[j] && fv[j] > 0.f) >> gshift) & 0xFFFFull);
         }
         __syncthreads();
         const int kn = min(C1_SC, K - k0);
-#pragma unroll 6
-        for (int u = 0; u < kn; ++u) {
-            const float4 v = mynb[u];
-            const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            float h;
-            if (P.influence == 1) h = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2 + 1e-10f) * P.inv_2extent, 0.0f);
-            else if (P.influence == 0) h = 1.0f;
-            else h = expf(-d2 / gden);
-            acc = fmaf(h, v.w, acc);
+        const int np = (kn + 1) >> 1;          // (a slot beyond kn holds a finite position and f = 0: it adds +0)
+        typedef float c1_f2 __attribute__((ext_vector_type(2)));
+        if (P.influence == 1) {
+            const c1_f2 k2x = {kx, kx}, k2y = {ky, ky}, k2z = {kz, kz}, eps = {1e-10f, 1e-10f}, one = {1.0f, 1.0f};
+            const c1_f2 ie = {P.inv_2extent, P.inv_2extent};
+#pragma unroll 4
+            for (int m = 0; m < np; ++m) {
+                const float4 r0 = mynb[2 * m], r1 = mynb[2 * m + 1];
+                const c1_f2 X = {r0.x, r0.y}, Y = {r0.z, r0.w}, Z = {r1.x, r1.y};
+                const c1_f2 dx = X - k2x, dy = Y - k2y, dz = Z - k2z;
+                const c1_f2 d2 = dx * dx + dy * dy + dz * dz + eps;
+                const c1_f2 sq = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                const c1_f2 t = one - sq * ie;
+                acc = fmaf(fmaxf(t.x, 0.0f), r1.z, acc);
+                acc = fmaf(fmaxf(t.y, 0.0f), r1.w, acc);
+            }
+        } else {
+#pragma unroll 2
+            for (int u = 0; u < kn; ++u) {
+                const float* v = (const float*)mynb + (u >> 1) * 8 + (u & 1);
+                const float dx = v[0] - kx, dy = v[2] - ky, dz = v[4] - kz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float h = P.influence == 0 ? 1.0f : expf(-d2 / gden);
+                acc = fmaf(h, v[6], acc);
+            }
         }
     }
     sacc[ql][p] = p == 15 ? cnt : (kp_lane ? acc : 0.f);
