@@ -142,8 +142,18 @@ __global__ void __launch_bounds__(256, 5)   // five workgroups per CU (96 regist
 nb_cell_search_kernel(const float* __restrict__ q, int Nq, const int* __restrict__ qlens, int B,
                       const NbElem* __restrict__ el, const int* __restrict__ cell_start, const int* __restrict__ cell_base,
                       const float4* __restrict__ sorted, float r2, int pad, const int* __restrict__ ns_dev,
-                      int* __restrict__ out, int ld, int width, int cap, int* __restrict__ status, int want_kmax, int Q, int dbg,
-                      unsigned long long* __restrict__ prof, const int* __restrict__ inv) {
+                      int* __restrict__ out, int ld, int width, int cap, int* __restrict__ status, int want_kmax, int Q, int dbg_arg,
+                      unsigned long long* __restrict__ prof_arg, const int* __restrict__ inv) {
+    // measurement aids (phase skipping, per-wavefront phase clocks: tools/ubench/nbc_phase_profile.py) exist in -DD3F_NBC_MEASURE builds
+    // only: as run-time arguments they cost the production kernel scalar registers and a handful of scalar tests per query
+#ifdef D3F_NBC_MEASURE
+    const int dbg = dbg_arg;
+    unsigned long long* const prof = prof_arg;
+#else
+    constexpr int dbg = 0;
+    constexpr unsigned long long* prof = nullptr;
+    (void)dbg_arg; (void)prof_arg;
+#endif
     // inv != NULL: the INTERNAL numbering -- row j of `out` is the j-th query in cell order and the entries are positions in the
     // cell-sorted support arrays (inv[index]); the order of a row is the reference's all the same (ties by the ORIGINAL index)
     extern __shared__ __attribute__((aligned(16))) char smem[];

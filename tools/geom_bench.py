@@ -50,7 +50,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frags", type=int, default=4)
     ap.add_argument("--ab", action="store_true")
-    ap.add_argument("--q", type=str, default="", help="comma list of D3F_NBC_Q values to try on the full searches")
+    ap.add_argument("--q", type=str, default="", help="comma list of D3F_NBC_Q values to try on the full searches (Q:DBG pairs skip phases: -DD3F_NBC_MEASURE builds only)")
     ap.add_argument("--only", type=str, default="", help="substring filter on the op names (e.g. 'L0 conv')")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--internal", action="store_true", help="conv searches in the engine's form: query_grid = the grid, internal numbering")

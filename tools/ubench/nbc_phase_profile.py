@@ -1,4 +1,6 @@
-"""Per-phase shader-clock cycles of nb_cell_search_kernel (D3F_NBC_PROF: s_memtime sums / maxima over the wavefronts)."""
+"""Per-phase shader-clock cycles of nb_cell_search_kernel (D3F_NBC_PROF: s_memtime sums / maxima over the wavefronts).
+Needs a measurement build of the library:  make -C d3feat_amd/csrc -B EXTRA=-DD3F_NBC_MEASURE  (the production kernel ignores the
+measurement arguments: as run-time tests they cost it ~8 % -- profiles/r06_experiments.txt n11)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from d3feat_amd import ops, tf_custom_ops as tfo
